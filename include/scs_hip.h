@@ -1,0 +1,94 @@
+/*
+ * scs_hip.h — C-ABI of libscs_hip.so, the MI355X-native (gfx950) implementation
+ * of SCS's ADMM hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * PART 1 is exactly the core API the reference's CPython glue binds
+ * (SURVEY.md §8 row b6); a maintainer can re-compile R:scs/scsobject.h against
+ * this header + scs_types.h to obtain `scs._scs_hip`.
+ * PART 2 are kernel-level entry points used by the parity tests and bench.py
+ * (they have no counterpart in the reference's public API; each cites the
+ * absent upstream file whose role it plays).
+ */
+#ifndef SCS_HIP_H_GUARD
+#define SCS_HIP_H_GUARD
+
+#include "scs_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ScsHipWork ScsWork;
+
+/* ------------------------------------------------------------------ PART 1 */
+
+/* replaces scs_init — called at R:scs/scsobject.h:903.  Copies all of d,k,stgs
+ * (the glue frees its views right after, :908).  Builds CSR(A) next to the
+ * caller's CSC(A), equilibrates, uploads everything to HBM, pre-solves g.
+ * Returns NULL on invalid data / allocation failure / no usable GPU. */
+ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs);
+
+/* replaces scs_solve — called at R:scs/scsobject.h:986 with the GIL released.
+ * Runs the whole ADMM loop device-resident; only info scalars and the final
+ * x,y,s cross PCIe.  sol holds the warm start on entry when warm_start != 0. */
+scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start);
+
+/* replaces scs_update — called at R:scs/scsobject.h:1217.  b and/or c may be NULL. */
+scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c);
+
+/* replaces scs_finish — called at R:scs/scsobject.h:1240. */
+void scs_finish(ScsWork *w);
+
+/* replaces scs_set_default_settings — called at R:scs/scsobject.h:520. */
+void scs_set_default_settings(ScsSettings *stgs);
+
+/* replaces scs_version — called at R:scs/scsmodule.h:5. */
+const char *scs_version(void);
+
+/* sizeof(scs_int), sizeof(scs_float): what R:scs/scsmodule.h:16-23 report. */
+size_t scs_sizeof_int(void);
+size_t scs_sizeof_float(void);
+
+/* ------------------------------------------------------------------ PART 2 */
+
+/* number of visible HIP devices (0 => library unusable); does not initialise a context */
+int scs_hip_device_count(void);
+/* choose the device used by subsequent scs_init calls of this process (default 0) */
+int scs_hip_set_device(int dev);
+
+/* y (+)= A x or A' x through the hot-path SpMV kernels (row a3; plays the role
+ * of scs_source/linsys/scs_matrix.c accum_by_a / accum_by_atrans, R:meson.build:199-202).
+ * A is CSC with int32 indices; x,y are host pointers.  Returns 0 on success. */
+int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose);
+
+/* Time `reps` launches of the A (transpose=0) or A' (transpose=1) SpMV kernel
+ * with HIP events on the launch stream; inputs already resident in HBM.
+ * Returns average milliseconds per launch, <0 on error.  (bench.py roofline leg) */
+double scs_hip_spmv_bench(const ScsMatrix *A, int transpose, int reps);
+
+/* In-place projection of x (length m, host pointer) onto K (dual=0) or K*
+ * (dual=1) with the hot-path cone kernels (row a5; scs_source/src/cones.c,
+ * exp_cone.c, R:meson.build:188,190). */
+int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual);
+
+/* One indirect KKT solve [[R_x+P, A'],[A,-R_y]] z = rhs (in place, length n+m)
+ * with the device PCG (row a4; scs_source/linsys/cpu/indirect/private.c,
+ * R:meson.build:261).  cg_iters may be NULL. */
+int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs,
+                      scs_float tol, scs_int *cg_iters);
+
+/* Equilibrate (A,P,b,c) exactly as scs_init does (row a7; scs_source/src/normalize.c,
+ * R:meson.build:192).  A->x, P->x, b, c are overwritten; D (m), E (n), sigma (1) filled. */
+int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, const ScsCone *k,
+                      scs_float *D, scs_float *E, scs_float *sigma);
+
+/* Measured device-copy bandwidth ceiling in GB/s (float4 copy of `bytes` bytes). */
+double scs_hip_copy_bandwidth(size_t bytes, int reps);
+
+/* last error message of the calling thread ("" if none) */
+const char *scs_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+"""Synthetic random cone programs with a KNOWN optimal value (bench + tests).
+
+Own implementation of the construction used by the reference's generator
+`gen_feasible` (R:test/gen_random_cone_prob.py:9-24):
+
+    z ~ N(0,1)^m;  y = Pi_{K*}(z);  s = y - z (= Pi_K(-z));
+    A sparse with N(0,1) values;  x ~ N(0,1)^n;  c = -A'y;  b = A x + s;  p* = c'x
+
+so (x, y, s) is a primal-dual optimal triple by construction.  The cone
+projection is injected (`proj_dual`) so that tests can use the oracle and
+bench.py can use the HIP kernels; nothing here imports oracle/ or the product.
+The sparsity pattern is drawn with a fixed number of nonzeros per column
+(uniform random rows), which scales to nnz ~ 2e7 in seconds; the reference uses
+scipy.sparse.rand(density) — same distribution family, different RNG stream
+("the build's generator need not replicate the stream").
+"""
+import numpy as np
+from scipy import sparse
+
+
+def cone_dims(K):
+    m = int(K.get("z", 0)) + int(K.get("l", 0))
+    nb = len(K.get("bu", []))
+    m += nb + 1 if nb else 0
+    m += int(sum(K.get("q", [])))
+    m += int(sum(int(s) * (int(s) + 1) // 2 for s in K.get("s", [])))
+    m += 3 * (int(K.get("ep", 0)) + int(K.get("ed", 0)) + len(K.get("p", [])))
+    return m
+
+
+def random_sparse(m, n, nnz_per_col, rng):
+    """m x n CSC, `nnz_per_col` uniformly random rows per column (duplicates merged), N(0,1) values."""
+    k = int(nnz_per_col)
+    rows = rng.integers(0, m, size=(n, k), dtype=np.int64)
+    rows.sort(axis=1)
+    vals = rng.standard_normal(size=(n, k))
+    # merge duplicates inside a column by zeroing the repeat and summing into the first
+    dup = np.zeros((n, k), dtype=bool)
+    dup[:, 1:] = rows[:, 1:] == rows[:, :-1]
+    if dup.any():
+        A = sparse.csc_matrix((vals.ravel(), rows.ravel().astype(np.int32),
+                               np.arange(0, n * k + 1, k, dtype=np.int64)), shape=(m, n))
+        A.sum_duplicates()
+        A.sort_indices()
+        return A
+    return sparse.csc_matrix((vals.ravel(), rows.ravel().astype(np.int32),
+                              np.arange(0, n * k + 1, k, dtype=np.int32)), shape=(m, n))
+
+
+def gen_feasible(K, n, nnz_per_col, seed, proj_dual):
+    """Returns (data, p_star, (x, y, s)).  proj_dual(z, K) must return Pi_{K*}(z)."""
+    rng = np.random.default_rng(seed)
+    m = cone_dims(K)
+    z = rng.standard_normal(m)
+    y = np.asarray(proj_dual(z, K), dtype=np.float64)
+    s = y - z
+    A = random_sparse(m, n, nnz_per_col, rng)
+    x = rng.standard_normal(n)
+    c = -(A.T @ y)
+    b = A @ x + s
+    return {"A": A, "b": b, "c": c}, float(c @ x), (x, y, s)
+
+
+# ---- named workloads ----
+def workload(name):
+    """name -> (K, n, nnz_per_col, seed)"""
+    if name == "config1_lp":      # BASELINE.json configs[0]
+        return {"l": 4000}, 2000, 50, 1
+    if name == "config2_lp_soc":  # configs[1]: m=2e5, n=1e5, nnz~2e6
+        return {"l": 100000, "q": [10] * 10000}, 100000, 20, 2
+    if name == "target_lp_soc":   # metric workload: m=2e6, n=1e6, nnz~2e7
+        return {"l": 1000000, "q": [10] * 100000}, 1000000, 20, 5
+    if name == "target_lp":
+        return {"l": 2000000}, 1000000, 20, 5
+    if name == "small_lp_soc":    # smoke / CI size
+        return {"l": 2000, "q": [10] * 200}, 2000, 20, 7
+    if name == "config5_small":   # one problem of the 512-problem batch
+        return {"l": 2000, "q": [50] * 20, "s": [20] * 5}, 1350, 40, 1000
+    raise KeyError(name)

@@ -1,0 +1,223 @@
+// host_setup.hpp — init-time (one-off, O(nnz)) host work: validation, cone
+// bookkeeping, CSC->CSR, symmetric expansion of P and data equilibration.
+//
+// Plays the role of scs_source/src/normalize.c + the matrix helpers of
+// scs_source/linsys/scs_matrix.c (R:meson.build:192,200; absent).  Algorithm:
+// SURVEY App. A.6 — 25 Ruiz (inf-norm) passes + 1 l2 pass on [P A'; A 0], row
+// scalings constant inside every non-separable cone, clamped to [1e-4, 1e4];
+// then b,c scaled by D,E and a scalar sigma.
+//   A_hat = D A E,  P_hat = E P E,  b_hat = sigma D b,  c_hat = sigma E c
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/scs_hip.h"
+
+namespace scship {
+
+struct HostCsr {
+  int rows = 0, cols = 0;
+  std::vector<int> rowptr, col;
+  std::vector<double> val;
+};
+
+// Deep copy of the cone (the glue frees its view right after scs_init, R:scs/scsobject.h:908)
+struct HostCone {
+  int z = 0, l = 0, bsize = 0, ep = 0, ed = 0;
+  std::vector<double> bu, bl, p;
+  std::vector<int> q, s;
+  std::vector<int> boundaries;  // [z+l+bsize, q..., s(s+1)/2..., 3 x (ep+ed+psize)]
+  int m = 0;
+  int off_box = 0, off_q = 0, off_s = 0, off_ep = 0, off_ed = 0, off_p = 0;
+};
+
+inline long sd_size(long s) { return s * (s + 1) / 2; }
+
+inline bool build_cone(const ScsCone *k, HostCone &c) {
+  if (k->z < 0 || k->l < 0 || k->bsize < 0 || k->ep < 0 || k->ed < 0) return false;
+  if (k->qsize < 0 || k->ssize < 0 || k->psize < 0 || k->cssize < 0) return false;
+  if (k->cssize > 0) return false;  // complex PSD cone: SURVEY §8f "next"
+  c.z = k->z; c.l = k->l; c.bsize = k->bsize; c.ep = k->ep; c.ed = k->ed;
+  if (k->bsize > 1) {
+    c.bu.assign(k->bu, k->bu + k->bsize - 1);
+    c.bl.assign(k->bl, k->bl + k->bsize - 1);
+    for (int i = 0; i < k->bsize - 1; ++i)
+      if (c.bl[i] > c.bu[i]) return false;
+  }
+  if (k->qsize) c.q.assign(k->q, k->q + k->qsize);
+  if (k->ssize) c.s.assign(k->s, k->s + k->ssize);
+  if (k->psize) c.p.assign(k->p, k->p + k->psize);
+  for (int q : c.q) if (q < 0) return false;
+  for (int s : c.s) if (s < 0 || s > 1024) return false;
+  for (double p : c.p) if (!(p >= -1 && p <= 1)) return false;
+  long cnt = (long)c.z + c.l;
+  c.off_box = (int)cnt; cnt += c.bsize;
+  c.off_q = (int)cnt; for (int q : c.q) cnt += q;
+  c.off_s = (int)cnt; for (int s : c.s) cnt += sd_size(s);
+  c.off_ep = (int)cnt; cnt += 3L * c.ep;
+  c.off_ed = (int)cnt; cnt += 3L * c.ed;
+  c.off_p = (int)cnt; cnt += 3L * (long)c.p.size();
+  if (cnt > 2000000000L) return false;
+  c.m = (int)cnt;
+  c.boundaries.clear();
+  c.boundaries.push_back(c.z + c.l + c.bsize);
+  for (int q : c.q) c.boundaries.push_back(q);
+  for (int s : c.s) c.boundaries.push_back((int)sd_size(s));
+  for (int i = 0; i < c.ep + c.ed + (int)c.p.size(); ++i) c.boundaries.push_back(3);
+  return true;
+}
+
+inline bool validate_matrix(const ScsMatrix *A, int m, int n) {
+  if (!A || !A->p || A->m != m || A->n != n) return false;
+  if (A->p[0] != 0) return false;
+  for (int j = 0; j < n; ++j) {
+    if (A->p[j + 1] < A->p[j]) return false;
+    for (int p = A->p[j]; p < A->p[j + 1]; ++p)
+      if (A->i[p] < 0 || A->i[p] >= m) return false;
+  }
+  return true;
+}
+
+// CSC (m x n) -> CSR (m x n); stable counting sort keeps columns ascending inside a row
+inline void csc_to_csr(int m, int n, const int *cp, const int *ri, const double *x, HostCsr &out) {
+  const long nnz = cp[n];
+  out.rows = m; out.cols = n;
+  out.rowptr.assign(m + 1, 0);
+  out.col.resize(nnz);
+  out.val.resize(nnz);
+  for (long p = 0; p < nnz; ++p) out.rowptr[ri[p] + 1]++;
+  for (int i = 0; i < m; ++i) out.rowptr[i + 1] += out.rowptr[i];
+  std::vector<int> next(out.rowptr.begin(), out.rowptr.end() - 1);
+  for (int j = 0; j < n; ++j)
+    for (int p = cp[j]; p < cp[j + 1]; ++p) {
+      const int q = next[ri[p]]++;
+      out.col[q] = j;
+      out.val[q] = x[p];
+    }
+}
+
+// upper-triangular CSC P -> full symmetric CSR (n x n), plus its diagonal
+inline void sym_expand(int n, const int *cp, const int *ri, const double *x, HostCsr &out, std::vector<double> &diag) {
+  out.rows = out.cols = n;
+  out.rowptr.assign(n + 1, 0);
+  diag.assign(n, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int p = cp[j]; p < cp[j + 1]; ++p) {
+      const int i = ri[p];
+      if (i > j) continue;
+      out.rowptr[i + 1]++;
+      if (i != j) out.rowptr[j + 1]++;
+      else diag[j] += x[p];
+    }
+  for (int i = 0; i < n; ++i) out.rowptr[i + 1] += out.rowptr[i];
+  out.col.resize(out.rowptr[n]);
+  out.val.resize(out.rowptr[n]);
+  std::vector<int> next(out.rowptr.begin(), out.rowptr.end() - 1);
+  // two ordered passes keep every row's columns ascending: first the transposed
+  // (strictly-lower) entries (col = i < row = j), then the upper entries (col = j >= row = i)
+  for (int j = 0; j < n; ++j)  // lower part of row j: entries (i,j) with i<j, visited with i ascending
+    for (int p = cp[j]; p < cp[j + 1]; ++p) {
+      const int i = ri[p];
+      if (i < j) { const int q = next[j]++; out.col[q] = i; out.val[q] = x[p]; }
+    }
+  for (int j = 0; j < n; ++j)  // upper part: row i gets column j, j ascending
+    for (int p = cp[j]; p < cp[j + 1]; ++p) {
+      const int i = ri[p];
+      if (i <= j) { const int q = next[i]++; out.col[q] = j; out.val[q] = x[p]; }
+    }
+}
+
+struct HostScaling {
+  std::vector<double> D, E;
+  double sigma = 1.0;
+};
+
+inline double apply_limit(double x) {
+  x = x < 1e-4 ? 1.0 : x;
+  return x > 1e4 ? 1e4 : x;
+}
+inline double safediv_pos(double x, double y) { return y < 1e-18 ? x / 1e-18 : x / y; }
+
+inline void enforce_cone_boundaries(const HostCone &c, std::vector<double> &vec, bool use_mean) {
+  long count = c.boundaries[0];
+  for (size_t i = 1; i < c.boundaries.size(); ++i) {
+    const int len = c.boundaries[i];
+    if (len > 0) {
+      double w = 0.;
+      if (use_mean) {
+        for (int j = 0; j < len; ++j) w += vec[count + j];
+        w /= (double)len;
+      } else {
+        for (int j = 0; j < len; ++j) w = std::max(w, std::fabs(vec[count + j]));
+      }
+      for (int j = 0; j < len; ++j) vec[count + j] = w;
+    }
+    count += len;
+  }
+}
+
+// Equilibrate in place.  A: CSC (m x n); P: upper-tri CSC or null.  Box bounds in `cone` follow D.
+inline void normalize_a_p(int m, int n, const int *Ap, const int *Ai, double *Ax, const int *Pp, const int *Pi, double *Px,
+                          HostCone &cone, HostScaling &sc) {
+  sc.D.assign(m, 1.0);
+  sc.E.assign(n, 1.0);
+  std::vector<double> Dt(m), Et(n);
+  for (int pass = 0; pass < 25 + 1; ++pass) {
+    const bool l2 = pass >= 25;
+    std::fill(Dt.begin(), Dt.end(), 0.0);
+    std::fill(Et.begin(), Et.end(), 0.0);
+    for (int j = 0; j < n; ++j)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const double v = std::fabs(Ax[p]);
+        const int i = Ai[p];
+        if (l2) { Dt[i] += v * v; Et[j] += v * v; }
+        else { Dt[i] = std::max(Dt[i], v); Et[j] = std::max(Et[j], v); }
+      }
+    if (Pp)
+      for (int j = 0; j < n; ++j)
+        for (int p = Pp[j]; p < Pp[j + 1]; ++p) {
+          const double v = std::fabs(Px[p]);
+          const int i = Pi[p];
+          if (i > j) continue;
+          if (l2) { Et[j] += v * v; if (i != j) Et[i] += v * v; }
+          else { Et[j] = std::max(Et[j], v); Et[i] = std::max(Et[i], v); }
+        }
+    if (l2) {
+      for (auto &d : Dt) d = std::sqrt(d);
+      for (auto &e : Et) e = std::sqrt(e);
+    }
+    enforce_cone_boundaries(cone, Dt, l2);
+    for (auto &d : Dt) d = safediv_pos(1.0, std::sqrt(apply_limit(d)));
+    for (auto &e : Et) e = safediv_pos(1.0, std::sqrt(apply_limit(e)));
+    for (int j = 0; j < n; ++j)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) Ax[p] *= Dt[Ai[p]] * Et[j];
+    if (Pp)
+      for (int j = 0; j < n; ++j)
+        for (int p = Pp[j]; p < Pp[j + 1]; ++p) Px[p] *= Et[Pi[p]] * Et[j];
+    for (int i = 0; i < m; ++i) sc.D[i] *= Dt[i];
+    for (int j = 0; j < n; ++j) sc.E[j] *= Et[j];
+  }
+  if (cone.bsize > 1) {
+    const double *D = &sc.D[cone.off_box];
+    for (int j = 0; j < cone.bsize - 1; ++j) {
+      cone.bu[j] = (cone.bu[j] >= 1e15) ? INFINITY : D[j + 1] * cone.bu[j] / D[0];
+      cone.bl[j] = (cone.bl[j] <= -1e15) ? -INFINITY : D[j + 1] * cone.bl[j] / D[0];
+    }
+  }
+}
+
+inline void normalize_b_c(HostScaling &sc, double *b, int m, double *c, int n) {
+  double nb = 0., nc = 0.;
+  for (int i = 0; i < n; ++i) { c[i] *= sc.E[i]; nc = std::max(nc, std::fabs(c[i])); }
+  for (int i = 0; i < m; ++i) { b[i] *= sc.D[i]; nb = std::max(nb, std::fabs(b[i])); }
+  double sigma = std::max(nc, nb);
+  sigma = sigma < 1e-4 ? 1.0 : sigma;
+  sigma = sigma > 1e4 ? 1e4 : sigma;
+  sigma = safediv_pos(1.0, sigma);
+  for (int i = 0; i < n; ++i) c[i] *= sigma;
+  for (int i = 0; i < m; ++i) b[i] *= sigma;
+  sc.sigma = sigma;
+}
+
+}  // namespace scship

@@ -1,0 +1,381 @@
+// vec.hpp — K4: fused vector kernels of the PCG and of the ADMM step, with
+// fixed-order two-stage reductions and all loop scalars kept on the device.
+//
+// Plays the role of scs_source/src/linalg.c (named at R:meson.build:191; absent)
+// and replaces the cuBLAS level-1 calls of GPU_INDIRECT (R:legacy_setup.py:263).
+// Every kernel is one pass over its vectors (HBM-bound); scalars such as alpha,
+// beta, tau are produced by single-workgroup "finalize" kernels that reduce the
+// per-block partials in a fixed order and are consumed from device memory by
+// the next kernel — no host round trip per CG step (SURVEY §7 "hard parts").
+#pragma once
+#include "common.hpp"
+
+namespace scship {
+
+constexpr int kVecThreads = 256;
+constexpr int kMaxVecBlocks = 2048;
+
+// device scalar slots (double)
+enum : int {
+  S_ZTR = 0, S_ALPHA, S_BETA, S_TOL, S_RNORM, S_TAUT, S_VSCALE, S_GG, S_WSNORM, S_AA_NORMG, S_AA_NORMD,
+  S_AA_NORM, S_AA_REG, S_BOX_T, S_TMP0, S_TMP1, S_TMP2, S_TMP3, S_COUNT = 32
+};
+// device flag slots (int)
+enum : int {
+  F_DONE = 0, F_ITERS, F_AA_SUCCESS, F_AA_ITER, F_AA_ACCEPT, F_AA_REJ_LAPACK, F_AA_REJ_RANK0, F_AA_REJ_NONFINITE,
+  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_COUNT = 32
+};
+
+inline int vec_blocks(long n) {
+  long nb = (n + 4L * kVecThreads - 1) / (4L * kVecThreads);
+  if (nb < 1) nb = 1;
+  if (nb > kMaxVecBlocks) nb = kMaxVecBlocks;
+  return (int)nb;
+}
+
+// ---- single-workgroup reduction of a partial array (fixed order) -------------
+__device__ __forceinline__ double part_sum(const double *part, int np, double *sm) {
+  double s = 0.;
+  for (int i = threadIdx.x; i < np; i += kVecThreads) s += part[i];
+  return block_sum<kVecThreads>(s, sm);
+}
+__device__ __forceinline__ double part_max(const double *part, int np, double *sm) {
+  double s = 0.;
+  for (int i = threadIdx.x; i < np; i += kVecThreads) s = fmax(s, part[i]);
+  return block_max<kVecThreads>(s, sm);
+}
+
+// ||v||_2 partials
+__global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict__ v, long n, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += v[i] * v[i];
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// sc[S_VSCALE] = sqrt(l) / ||v||   (iterate normalisation)
+__global__ __launch_bounds__(kVecThreads) void k_fin_vscale(const double *part, int np, double l, double *sc) {
+  __shared__ double sm[kVecThreads / 64];
+  const double s = part_sum(part, np, sm);
+  if (threadIdx.x == 0) sc[S_VSCALE] = sqrt(l) / fmax(sqrt(s), 1e-300);
+}
+
+// Start of project_lin_sys: normalise v, snapshot v_prev, build the KKT right-hand side
+//   rhs_x = R_x v_x   (into ut_x),   tmp = R_y^{-1} rhs_y = -v_y,
+// and the CG warm start ws = u_x + tau g_x; partial max |ws|.
+__global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *tmp, double *ws,
+                                                      const double *__restrict__ u, const double *__restrict__ g,
+                                                      const double *__restrict__ diag_r, int n, int m, int do_scale,
+                                                      const double *sc, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  const long l = (long)n + m + 1;
+  const double scale = do_scale ? sc[S_VSCALE] : 1.0;
+  const double tau = u[l - 1];
+  double mx = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
+    const double vi = v[i] * scale;
+    v[i] = vi;
+    v_prev[i] = vi;
+    if (i < n) {
+      ut[i] = diag_r[i] * vi;
+      const double w = u[i] + tau * g[i];
+      ws[i] = w;
+      mx = fmax(mx, abs_nan_inf(w));
+    } else if (i < l - 1) {
+      tmp[i - n] = -vi;
+    }
+  }
+  mx = block_max<kVecThreads>(mx, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = mx;
+}
+
+// CG tolerance: tol = max(1e-12, 0.2 * min(res_min, ||ws||_inf / (k+1)^1.5))
+__global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int np, double res_min, double ipow,
+                                                         double fixed_tol, double *sc, int *fl) {
+  __shared__ double sm[kVecThreads / 64];
+  const double ws = part_max(part, np, sm);
+  if (threadIdx.x == 0) {
+    double tol = fixed_tol;
+    if (fixed_tol <= 0.) {
+      tol = 0.2 * fmin(res_min, ws / ipow);
+      tol = fmax(1e-12, tol);
+    }
+    sc[S_TOL] = tol;
+    sc[S_WSNORM] = ws;
+    fl[F_DONE] = 0;
+  }
+}
+
+// r = b - G ws; x = ws; p = M r; partial [max|r| , sum r M r]
+__global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restrict__ b, const double *__restrict__ Gws,
+                                                         const double *__restrict__ ws, const double *__restrict__ M,
+                                                         double *x, double *r, double *p, int n, int have_ws, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double mx = 0., s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    const double ri = have_ws ? b[i] - Gws[i] : b[i];
+    const double zi = M[i] * ri;
+    x[i] = have_ws ? ws[i] : 0.0;
+    r[i] = ri;
+    p[i] = zi;
+    mx = fmax(mx, abs_nan_inf(ri));
+    s += zi * ri;
+  }
+  mx = block_max<kVecThreads>(mx, sm);
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = mx;
+    part[gridDim.x + blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part, int np, double *sc, int *fl) {
+  __shared__ double sm[kVecThreads / 64];
+  const double rn = part_max(part, np, sm);
+  const double ztr = part_sum(part + np, np, sm);
+  if (threadIdx.x == 0) {
+    sc[S_RNORM] = rn;
+    sc[S_ZTR] = ztr;
+    if (rn < fmax(sc[S_TOL], 1e-12)) fl[F_DONE] = 1;
+  }
+}
+
+// alpha = z'r / p'Gp
+__global__ __launch_bounds__(kVecThreads) void k_fin_alpha(const double *part, int np, double *sc, const int *fl) {
+  if (fl[F_DONE]) return;
+  __shared__ double sm[kVecThreads / 64];
+  const double pGp = part_sum(part, np, sm);
+  if (threadIdx.x == 0) sc[S_ALPHA] = sc[S_ZTR] / pGp;
+}
+
+// x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r]
+__global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
+                                                           const double *__restrict__ Gp, const double *__restrict__ M,
+                                                           int n, const double *sc, const int *fl, double *part) {
+  if (fl[F_DONE]) return;
+  __shared__ double sm[kVecThreads / 64];
+  const double alpha = sc[S_ALPHA];
+  double mx = 0., s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * Gp[i];
+    r[i] = ri;
+    mx = fmax(mx, abs_nan_inf(ri));
+    s += (M[i] * ri) * ri;
+  }
+  mx = block_max<kVecThreads>(mx, sm);
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = mx;
+    part[gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// beta = ztr_new / ztr; convergence test on ||r||_inf
+__global__ __launch_bounds__(kVecThreads) void k_fin_beta(const double *part, int np, double *sc, int *fl) {
+  if (fl[F_DONE]) return;
+  __shared__ double sm[kVecThreads / 64];
+  const double rn = part_max(part, np, sm);
+  const double ztr = part_sum(part + np, np, sm);
+  if (threadIdx.x == 0) {
+    sc[S_RNORM] = rn;
+    sc[S_BETA] = ztr / sc[S_ZTR];
+    sc[S_ZTR] = ztr;
+    fl[F_ITERS] += 1;
+    if (rn < sc[S_TOL]) fl[F_DONE] = 1;
+  }
+}
+
+// p = M r + beta p
+__global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r, const double *__restrict__ M,
+                                                        int n, const double *sc, const int *fl) {
+  if (fl[F_DONE]) return;
+  const double beta = sc[S_BETA];
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
+    p[i] = M[i] * r[i] + beta * p[i];
+}
+
+// R-weighted dots for the tau quadratic (root_plus): [p'Rg, p'Rp, p'Rmu, mu'Rg] over the first l-1 entries
+__global__ __launch_bounds__(kVecThreads) void k_tau_dots(const double *__restrict__ p, const double *__restrict__ mu,
+                                                          const double *__restrict__ g, const double *__restrict__ diag_r,
+                                                          long n, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double a = 0., b = 0., c = 0., d = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    const double r = diag_r[i], pi = p[i], mi = mu[i], gi = g[i];
+    a += pi * gi * r;
+    b += pi * pi * r;
+    c += pi * mi * r;
+    d += mi * gi * r;
+  }
+  a = block_sum<kVecThreads>(a, sm);
+  b = block_sum<kVecThreads>(b, sm);
+  c = block_sum<kVecThreads>(c, sm);
+  d = block_sum<kVecThreads>(d, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = a;
+    part[gridDim.x + blockIdx.x] = b;
+    part[2 * gridDim.x + blockIdx.x] = c;
+    part[3 * gridDim.x + blockIdx.x] = d;
+  }
+}
+
+// g'Rg (cached per scale)
+__global__ __launch_bounds__(kVecThreads) void k_gg(const double *__restrict__ g, const double *__restrict__ diag_r, long n,
+                                                    double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double a = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
+    a += g[i] * g[i] * diag_r[i];
+  a = block_sum<kVecThreads>(a, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(kVecThreads) void k_fin_store_sum(const double *part, int np, double *sc, int slot) {
+  __shared__ double sm[kVecThreads / 64];
+  const double s = part_sum(part, np, sm);
+  if (threadIdx.x == 0) sc[slot] = s;
+}
+
+// tau_tilde = positive root of the scalar quadratic
+__global__ __launch_bounds__(kVecThreads) void k_fin_tau(const double *part, int np, const double *v, const double *diag_r,
+                                                         long l, int first_iter, double *sc) {
+  __shared__ double sm[kVecThreads / 64];
+  const double pg = part_sum(part, np, sm);
+  const double pp = part_sum(part + np, np, sm);
+  const double pmu = part_sum(part + 2 * np, np, sm);
+  const double mug = part_sum(part + 3 * np, np, sm);
+  if (threadIdx.x == 0) {
+    double t = 1.0;
+    if (!first_iter) {
+      const double tau_scale = diag_r[l - 1], eta = v[l - 1];
+      const double a = tau_scale + sc[S_GG];
+      const double b = mug - 2 * pg - eta * tau_scale;
+      const double c = pp - pmu;
+      t = (-b + sqrt(fmax(b * b - 4 * a * c, 0.))) / (2 * a);
+    }
+    sc[S_TAUT] = t;
+  }
+}
+
+// u_t -= tau_t g;  u = 2 u_t - v;  free / zero-cone / nonnegative rows finished here
+//   x rows: identity.  zero-cone rows: dual cone is free -> identity.  l rows: max(.,0).
+__global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
+                                                          const double *__restrict__ g, int n, int m, int nz, int nl,
+                                                          int first_iter, const double *sc) {
+  const long l = (long)n + m + 1;
+  const double taut = sc[S_TAUT];
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
+    if (i < l - 1) {
+      const double t = ut[i] - taut * g[i];
+      ut[i] = t;
+      double w = 2 * t - v[i];
+      if (i >= n + nz && i < (long)n + nz + nl) w = fmax(w, 0.);
+      u[i] = w;
+    } else {
+      ut[i] = taut;
+      u[i] = first_iter ? 1.0 : fmax(2 * taut - v[i], 0.);
+    }
+  }
+}
+
+// rsk = R (v + u - 2 u_t)
+__global__ __launch_bounds__(kVecThreads) void k_rsk(double *rsk, const double *__restrict__ v, const double *__restrict__ u,
+                                                     const double *__restrict__ ut, const double *__restrict__ diag_r, long l) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
+    rsk[i] = (v[i] + u[i] - 2 * ut[i]) * diag_r[i];
+}
+
+// v += alpha (u - u_t)
+__global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const double *__restrict__ u, const double *__restrict__ ut,
+                                                          double alpha, long l) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
+    v[i] += alpha * (u[i] - ut[i]);
+}
+
+// after a scale update: v = rsk / R+ + 2 u_t - u
+__global__ __launch_bounds__(kVecThreads) void k_v_rescale(double *v, const double *__restrict__ rsk, const double *__restrict__ u,
+                                                           const double *__restrict__ ut, const double *__restrict__ diag_r, long l) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
+    v[i] = rsk[i] / diag_r[i] + 2 * ut[i] - u[i];
+}
+
+// diag_r = [rho_x (n) | 1/(1000 scale) (z rows) | 1/scale (other rows) | 10]
+__global__ __launch_bounds__(kVecThreads) void k_set_diag_r(double *diag_r, int n, int m, int nz, double rho_x, double scale) {
+  const long l = (long)n + m + 1;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
+    double r;
+    if (i < n) r = rho_x;
+    else if (i < (long)n + nz) r = 1.0 / (1000. * scale);
+    else if (i < l - 1) r = 1.0 / scale;
+    else r = 10.0;
+    diag_r[i] = r;
+  }
+}
+
+// g rhs: g = [c ; -b]
+__global__ __launch_bounds__(kVecThreads) void k_g_rhs(double *g, const double *__restrict__ h, int n, int m) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads)
+    g[i] = i < n ? h[i] : -h[i];
+}
+
+// generic KKT rhs prep for a standalone solve: tmp = rhs_y / r_y, (rhs_x stays)
+__global__ __launch_bounds__(kVecThreads) void k_kkt_prep(const double *__restrict__ rhs, const double *__restrict__ diag_r,
+                                                          double *tmp, int n, int m) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
+    tmp[i] = rhs[n + i] / diag_r[n + i];
+}
+// y = (A x - rhs_y) / r_y, with ax already in `ax`
+__global__ __launch_bounds__(kVecThreads) void k_kkt_y(double *rhs, const double *__restrict__ ax, const double *__restrict__ diag_r,
+                                                       int n, int m) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
+    rhs[n + i] = (ax[i] - rhs[n + i]) / diag_r[n + i];
+}
+
+// Jacobi preconditioner: M_j = 1 / (R_x,j + P_jj + sum_i A_ij^2 / R_y,i)  over CSC(A) columns
+__global__ __launch_bounds__(kVecThreads) void k_precond(const int *__restrict__ colptr, const int *__restrict__ rowidx,
+                                                         const double *__restrict__ val, const double *__restrict__ diag_r,
+                                                         const double *__restrict__ Pdiag, double *M, int n) {
+  for (long j = (long)blockIdx.x * kVecThreads + threadIdx.x; j < n; j += (long)gridDim.x * kVecThreads) {
+    double d = diag_r[j] + (Pdiag ? Pdiag[j] : 0.0);
+    for (int p = colptr[j]; p < colptr[j + 1]; ++p) d += val[p] * val[p] / diag_r[n + rowidx[p]];
+    M[j] = 1.0 / d;
+  }
+}
+
+// final solution in original units: x = E x_hat/(sigma tau) ...; mode selects solved / infeasible / unbounded scaling
+__global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__restrict__ u, const double *__restrict__ rsk,
+                                                             const double *__restrict__ D, const double *__restrict__ E,
+                                                             double sigma, double fx, double fy, double fs, int n, int m,
+                                                             double *x, double *y, double *s) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads) {
+    if (i < n) {
+      x[i] = u[i] * (E ? E[i] / sigma : 1.0) * fx;
+    } else {
+      const long k = i - n;
+      y[k] = u[i] * (D ? D[k] / sigma : 1.0) * fy;
+      s[k] = rsk[i] / (D ? D[k] * sigma : 1.0) * fs;
+    }
+  }
+}
+
+// s.y partial (comp_slack)
+__global__ __launch_bounds__(kVecThreads) void k_dot(const double *__restrict__ a, const double *__restrict__ b, long n, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += a[i] * b[i];
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// collapse k groups of np partials into out[0..k): sums for the first `nsum` groups, max for the rest
+__global__ __launch_bounds__(kVecThreads) void k_fin_multi(const double *part, int np, int nsum, int nmax, double *out) {
+  __shared__ double sm[kVecThreads / 64];
+  for (int k = 0; k < nsum + nmax; ++k) {
+    const double v = k < nsum ? part_sum(part + (size_t)k * np, np, sm) : part_max(part + (size_t)k * np, np, sm);
+    if (threadIdx.x == 0) out[k] = v;
+    __syncthreads();
+  }
+}
+
+}  // namespace scship

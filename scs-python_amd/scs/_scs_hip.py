@@ -1,0 +1,607 @@
+"""scs._scs_hip — the MI355X (gfx950) backend module selected by
+``LinearSolver.HIP_INDIRECT``.
+
+It is the counterpart of one of the reference's per-backend CPython extension
+modules (R:scs/scspy.c, R:scs/scsmodule.h, R:scs/scsobject.h — compiled once per
+backend, R:meson.build:238-391).  Same module surface:
+
+* ``version()``, ``sizeof_int()``, ``sizeof_float()``         (R:scs/scsmodule.h:16-23)
+* type ``SCS(shape, Ax, Ai, Ap, Px, Pi, Pp, b, c, cone, **settings)`` with
+  ``solve(warm_start, x, y, s)`` and ``update(b, c)``          (R:scs/scsobject.h:442-1225)
+
+The reference glue is C against the CPython API; this one is Python over the
+C-ABI of ``libscs_hip.so`` (include/scs_hip.h) via ctypes.  ctypes drops the GIL
+for the duration of every foreign call, which reproduces the reference's
+``Py_BEGIN_ALLOW_THREADS`` around scs_init/scs_solve/scs_update
+(R:scs/scsobject.h:902-905,984-987,1216-1219); a per-instance lock protects
+work/sol exactly as there (:892-899).
+
+There is NO CPU fallback: if the shared library or a GPU is missing this module
+raises (ImportError at import for a missing library; ValueError("ScsWork
+allocation error!") from the constructor when no device is usable).
+"""
+import ctypes as C
+import importlib.util
+import os
+import threading
+import warnings
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libscs_hip.so"
+
+c_int, c_dbl = C.c_int, C.c_double
+_PI, _PD = C.POINTER(c_int), C.POINTER(c_dbl)
+
+
+# ---------------------------------------------------------------- C structs (include/scs_types.h)
+class _ScsMatrix(C.Structure):
+    _fields_ = [("x", _PD), ("i", _PI), ("p", _PI), ("m", c_int), ("n", c_int)]
+
+
+class _ScsData(C.Structure):
+    _fields_ = [("m", c_int), ("n", c_int), ("A", C.POINTER(_ScsMatrix)),
+                ("P", C.POINTER(_ScsMatrix)), ("b", _PD), ("c", _PD)]
+
+
+class _ScsCone(C.Structure):
+    _fields_ = [("z", c_int), ("l", c_int), ("bu", _PD), ("bl", _PD), ("bsize", c_int),
+                ("q", _PI), ("qsize", c_int), ("s", _PI), ("ssize", c_int),
+                ("cs", _PI), ("cssize", c_int), ("ep", c_int), ("ed", c_int),
+                ("p", _PD), ("psize", c_int)]
+
+
+class _ScsSettings(C.Structure):
+    _fields_ = [("normalize", c_int), ("scale", c_dbl), ("adaptive_scale", c_int),
+                ("rho_x", c_dbl), ("max_iters", c_int), ("eps_abs", c_dbl),
+                ("eps_rel", c_dbl), ("eps_infeas", c_dbl), ("alpha", c_dbl),
+                ("time_limit_secs", c_dbl), ("verbose", c_int), ("warm_start", c_int),
+                ("acceleration_lookback", c_int), ("acceleration_interval", c_int),
+                ("acceleration_type_1", c_int), ("acceleration_regularization", c_dbl),
+                ("acceleration_relaxation", c_dbl), ("write_data_filename", C.c_char_p),
+                ("log_csv_filename", C.c_char_p)]
+
+
+class _ScsSolution(C.Structure):
+    _fields_ = [("x", _PD), ("y", _PD), ("s", _PD)]
+
+
+class _ScsAaStats(C.Structure):
+    _fields_ = [("iter", c_int), ("n_accept", c_int), ("n_reject_lapack", c_int),
+                ("n_reject_rank0", c_int), ("n_reject_nonfinite", c_int),
+                ("n_reject_weight_cap", c_int), ("n_safeguard_reject", c_int),
+                ("last_rank", c_int), ("last_aa_norm", c_dbl), ("last_regularization", c_dbl)]
+
+
+class _ScsInfo(C.Structure):
+    _fields_ = [("iter", c_int), ("status", C.c_char * 128), ("lin_sys_solver", C.c_char * 128),
+                ("status_val", c_int), ("scale_updates", c_int), ("pobj", c_dbl), ("dobj", c_dbl),
+                ("res_pri", c_dbl), ("res_dual", c_dbl), ("gap", c_dbl), ("res_infeas", c_dbl),
+                ("res_unbdd_a", c_dbl), ("res_unbdd_p", c_dbl), ("comp_slack", c_dbl),
+                ("setup_time", c_dbl), ("solve_time", c_dbl), ("scale", c_dbl),
+                ("lin_sys_time", c_dbl), ("cone_time", c_dbl), ("accel_time", c_dbl),
+                ("rejected_accel_steps", c_int), ("accepted_accel_steps", c_int),
+                ("aa_stats", _ScsAaStats), ("cg_iters", c_int)]
+
+
+# ---------------------------------------------------------------- library loading
+def _preload_hip_runtime():
+    """Make sure exactly ONE HIP runtime ends up in the process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7,
+    same as /opt/rocm's).  If libscs_hip.so pulled in the system copy first and
+    torch were imported afterwards, torch would load its bundled copy too (it asks
+    for the un-versioned file name) and the process would hold two runtimes.
+    Preloading torch's copy (without importing torch) makes both resolve to it.
+    SCS_HIP_RUNTIME=system skips this.
+    """
+    if os.environ.get("SCS_HIP_RUNTIME", "torch") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def _load():
+    path = os.path.join(_HERE, _LIB_NAME)
+    if not os.path.exists(path):
+        raise ImportError(
+            "scs._scs_hip: %s is not built (run `python __graft_entry__.py` / "
+            "`make -C scs-python_amd`); this backend has no CPU fallback" % path)
+    _preload_hip_runtime()
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise ImportError("scs._scs_hip: cannot load %s: %s" % (path, e))
+    lib.scs_init.restype = C.c_void_p
+    lib.scs_init.argtypes = [C.POINTER(_ScsData), C.POINTER(_ScsCone), C.POINTER(_ScsSettings)]
+    lib.scs_solve.restype = c_int
+    lib.scs_solve.argtypes = [C.c_void_p, C.POINTER(_ScsSolution), C.POINTER(_ScsInfo), c_int]
+    lib.scs_update.restype = c_int
+    lib.scs_update.argtypes = [C.c_void_p, _PD, _PD]
+    lib.scs_finish.restype = None
+    lib.scs_finish.argtypes = [C.c_void_p]
+    lib.scs_set_default_settings.restype = None
+    lib.scs_set_default_settings.argtypes = [C.POINTER(_ScsSettings)]
+    lib.scs_version.restype = C.c_char_p
+    lib.scs_sizeof_int.restype = C.c_size_t
+    lib.scs_sizeof_float.restype = C.c_size_t
+    lib.scs_hip_device_count.restype = c_int
+    lib.scs_hip_set_device.restype = c_int
+    lib.scs_hip_set_device.argtypes = [c_int]
+    lib.scs_hip_last_error.restype = C.c_char_p
+    lib.scs_hip_spmv.restype = c_int
+    lib.scs_hip_spmv.argtypes = [C.POINTER(_ScsMatrix), _PD, _PD, c_int]
+    lib.scs_hip_spmv_bench.restype = c_dbl
+    lib.scs_hip_spmv_bench.argtypes = [C.POINTER(_ScsMatrix), c_int, c_int]
+    lib.scs_hip_proj_cone.restype = c_int
+    lib.scs_hip_proj_cone.argtypes = [_PD, C.POINTER(_ScsCone), c_int, c_int]
+    lib.scs_hip_kkt_solve.restype = c_int
+    lib.scs_hip_kkt_solve.argtypes = [C.POINTER(_ScsMatrix), C.POINTER(_ScsMatrix), _PD, _PD, c_dbl, _PI]
+    lib.scs_hip_normalize.restype = c_int
+    lib.scs_hip_normalize.argtypes = [C.POINTER(_ScsMatrix), C.POINTER(_ScsMatrix), _PD, _PD,
+                                      C.POINTER(_ScsCone), _PD, _PD, _PD]
+    lib.scs_hip_copy_bandwidth.restype = c_dbl
+    lib.scs_hip_copy_bandwidth.argtypes = [C.c_size_t, c_int]
+    return lib
+
+
+_lib = _load()
+
+
+def version():
+    return _lib.scs_version().decode()
+
+
+def sizeof_int():
+    return int(_lib.scs_sizeof_int())
+
+
+def sizeof_float():
+    return int(_lib.scs_sizeof_float())
+
+
+def device_count():
+    return int(_lib.scs_hip_device_count())
+
+
+def set_device(dev):
+    if _lib.scs_hip_set_device(int(dev)) != 0:
+        raise ValueError("invalid HIP device %r" % (dev,))
+
+
+def last_error():
+    return _lib.scs_hip_last_error().decode()
+
+
+# ---------------------------------------------------------------- argument parsing
+def _pd(a):
+    return a.ctypes.data_as(_PD)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_PI)
+
+
+def _float_array(name, a, length=None, exc_len=ValueError, len_msg=None):
+    """1-D numpy float array of any float dtype -> contiguous float64 copy
+    (R:scs/scsobject.h:60-68,574-592; integer arrays are rejected, test
+    R:test/test_scs_coverage.py:1698-1720)."""
+    if not isinstance(a, np.ndarray):
+        raise TypeError("%s must be a 1-D numpy array of floats" % name)
+    if not np.issubdtype(a.dtype, np.floating) or a.ndim != 1:
+        raise TypeError("%s must be a 1-D numpy array of floats" % name)
+    if length is not None and a.shape[0] != length:
+        raise exc_len(len_msg or ("%s has incompatible dimension" % name))
+    return np.array(a, dtype=np.float64, order="C", copy=True)
+
+
+def _int_array(name, a):
+    if not isinstance(a, np.ndarray):
+        raise TypeError("%s must be a 1-D numpy array of ints" % name)
+    if not np.issubdtype(a.dtype, np.integer) or a.ndim != 1:
+        raise TypeError("%s must be a 1-D numpy array of ints" % name)
+    if a.size and (a.max() > np.iinfo(np.int32).max or a.min() < np.iinfo(np.int32).min):
+        raise ValueError("%s does not fit the 32-bit index type of the GPU backend" % name)
+    return np.array(a, dtype=np.int32, order="C", copy=True)
+
+
+def _as_c_int(name, v):
+    """mirrors the 'i' format unit of PyArg_ParseTupleAndKeywords"""
+    if isinstance(v, bool):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        raise TypeError("'float' object cannot be interpreted as an integer")
+    try:
+        iv = v.__index__()
+    except AttributeError:
+        raise TypeError("'%s' object cannot be interpreted as an integer" % type(v).__name__)
+    if not -2 ** 31 <= iv < 2 ** 31:
+        raise OverflowError("signed integer is greater than maximum")
+    return int(iv)
+
+
+def _as_c_double(name, v):
+    """mirrors the 'd' format unit"""
+    if isinstance(v, (str, bytes)) or v is None:
+        raise TypeError("must be real number, not %s" % type(v).__name__)
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        raise TypeError("must be real number, not %s" % type(v).__name__)
+
+
+def _as_bool(name, v):
+    """mirrors 'O!' with PyBool_Type (R:scs/scsobject.h:534-536)"""
+    if not isinstance(v, (bool, np.bool_)):
+        raise TypeError("argument '%s' must be bool, not %s" % (name, type(v).__name__))
+    return 1 if v else 0
+
+
+def _as_filename(name, v):
+    if v is None:
+        return None
+    if isinstance(v, str):
+        return v.encode()
+    raise TypeError("argument '%s' must be str or None, not %s" % (name, type(v).__name__))
+
+
+_INT_SETTINGS = ("max_iters", "acceleration_lookback", "acceleration_interval", "acceleration_type_1")
+_FLOAT_SETTINGS = ("scale", "eps_abs", "eps_rel", "eps_infeas", "alpha", "rho_x", "time_limit_secs",
+                   "acceleration_regularization", "acceleration_relaxation")
+_BOOL_SETTINGS = ("verbose", "normalize", "adaptive_scale")
+_FILE_SETTINGS = ("write_data_filename", "log_csv_filename")
+
+
+def _cone_err(key):
+    return ValueError("Invalid value for cone field '%s'" % key)
+
+
+def _cone_pos_int(cone, key):
+    """R:scs/scsobject.h:86-127 — python ints only, non-negative, must fit scs_int"""
+    if key not in cone:
+        return 0
+    v = cone[key]
+    if isinstance(v, (bool, np.bool_)) or not isinstance(v, (int, np.integer)):
+        raise _cone_err(key)
+    v = int(v)
+    if v < 0 or v >= 2 ** 31:
+        raise _cone_err(key)
+    return v
+
+
+def _cone_int_list(cone, key):
+    """list, bare int or numpy int array of non-negative ints (R:scs/scsobject.h:148-238)"""
+    if key not in cone or cone[key] is None:
+        return np.zeros(0, dtype=np.int32)
+    v = cone[key]
+    if isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_)):
+        v = [int(v)]
+    if isinstance(v, np.ndarray):
+        if v.ndim != 1 or not np.issubdtype(v.dtype, np.integer):
+            raise _cone_err(key)
+        vals = [int(t) for t in v]
+    elif isinstance(v, (list, tuple)):
+        vals = []
+        for t in v:
+            if isinstance(t, (bool, np.bool_)) or not isinstance(t, (int, np.integer)):
+                raise _cone_err(key)
+            vals.append(int(t))
+    else:
+        raise _cone_err(key)
+    for t in vals:
+        if t < 0 or t >= 2 ** 31:
+            raise _cone_err(key)
+    return np.asarray(vals, dtype=np.int32)
+
+
+def _cone_float_list(cone, key):
+    if key not in cone or cone[key] is None:
+        return np.zeros(0, dtype=np.float64)
+    v = cone[key]
+    if isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, (bool, np.bool_)):
+        v = [float(v)]
+    try:
+        arr = np.asarray(v, dtype=np.float64)
+    except (TypeError, ValueError):
+        raise _cone_err(key)
+    if arr.ndim != 1:
+        raise _cone_err(key)
+    return np.ascontiguousarray(arr)
+
+
+class SCS(object):
+    """Raw backend type; `scs.SCS` (scs/__init__.py) is the user-facing wrapper."""
+
+    def __init__(self, shape, Ax, Ai, Ap, Px, Pi, Pp, b, c, cone, **settings):
+        if getattr(self, "_work", None):
+            raise ValueError("Workspace already setup!")
+        self._work = None
+        self._lock = threading.Lock()
+        # ---- shape "(ii)"
+        if not isinstance(shape, tuple) or len(shape) != 2:
+            raise TypeError("argument 1 must be 2-item sequence (m, n)")
+        m, n = _as_c_int("m", shape[0]), _as_c_int("n", shape[1])
+        if not isinstance(cone, dict):
+            raise TypeError("argument 10 must be dict, not %s" % type(cone).__name__)
+        # ---- settings (keyword table R:scs/scsobject.h:467-495)
+        st = _ScsSettings()
+        _lib.scs_set_default_settings(C.byref(st))
+        self._fn_keep = []
+        for key, val in settings.items():
+            if key in _INT_SETTINGS:
+                setattr(st, key, _as_c_int(key, val))
+            elif key in _FLOAT_SETTINGS:
+                setattr(st, key, _as_c_double(key, val))
+            elif key in _BOOL_SETTINGS:
+                setattr(st, key, _as_bool(key, val))
+            elif key in _FILE_SETTINGS:
+                fn = _as_filename(key, val)
+                self._fn_keep.append(fn)
+                setattr(st, key, fn)
+            else:
+                raise TypeError("'%s' is an invalid keyword argument for SCS()" % key)
+        if m <= 0:
+            raise ValueError("m must be a positive integer")
+        if n <= 0:
+            raise ValueError("n must be a positive integer")
+        self.m, self.n = m, n
+        # ---- data
+        Axc = _float_array("Ax", Ax)
+        Aic = _int_array("Ai", Ai)
+        Apc = _int_array("Ap", Ap)
+        if Apc.shape[0] != n + 1 or Axc.shape[0] != Aic.shape[0] or (Apc.size and Apc[-1] != Axc.shape[0]):
+            raise ValueError("A has inconsistent CSC arrays")
+        have_P = Px is not None and Pi is not None and Pp is not None
+        if have_P:
+            Pxc = _float_array("Px", Px)
+            Pic = _int_array("Pi", Pi)
+            Ppc = _int_array("Pp", Pp)
+            if Ppc.shape[0] != n + 1 or Pxc.shape[0] != Pic.shape[0] or (Ppc.size and Ppc[-1] != Pxc.shape[0]):
+                raise ValueError("P has inconsistent CSC arrays")
+        cc = _float_array("c", c, n, ValueError, "c has incompatible dimension with A")
+        bc = _float_array("b", b, m, ValueError, "b has incompatible dimension with A")
+        # ---- cone (R:scs/scsobject.h:684-749)
+        f_tmp = _cone_pos_int(cone, "f")
+        z = _cone_pos_int(cone, "z")
+        if f_tmp > 0:
+            warnings.warn("The 'f' cone field is deprecated; use 'z' (Zero cone) instead. "
+                          "If both 'f' and 'z' are set they are summed.", DeprecationWarning, stacklevel=2)
+            z += f_tmp
+        lcone = _cone_pos_int(cone, "l")
+        bu = _cone_float_list(cone, "bu")
+        bl = _cone_float_list(cone, "bl")
+        if bu.size != bl.size:
+            raise ValueError("bu different dimension to bl")
+        q = _cone_int_list(cone, "q")
+        s = _cone_int_list(cone, "s")
+        cs = _cone_int_list(cone, "cs")
+        p = _cone_float_list(cone, "p")
+        ep = _cone_pos_int(cone, "ep")
+        ed = _cone_pos_int(cone, "ed")
+        # ---- settings validation (R:scs/scsobject.h:810-868)
+        if st.max_iters <= 0:
+            raise ValueError("max_iters must be positive")
+        if st.acceleration_lookback < 0:
+            raise ValueError("acceleration_lookback must be nonnegative (use acceleration_type_1=0 for type-II AA)")
+        if st.acceleration_interval <= 0:
+            raise ValueError("acceleration_interval must be positive")
+        if not np.isfinite(st.acceleration_regularization) or st.acceleration_regularization < 0:
+            raise ValueError("acceleration_regularization must be a nonnegative finite number")
+        if (not np.isfinite(st.acceleration_relaxation) or st.acceleration_relaxation < 0
+                or st.acceleration_relaxation > 2):
+            raise ValueError("acceleration_relaxation must be in [0, 2]")
+        if not np.isfinite(st.scale) or st.scale <= 0:
+            raise ValueError("scale must be a positive finite number")
+        if np.isnan(st.time_limit_secs) or st.time_limit_secs < 0:
+            raise ValueError("time_limit_secs must be nonnegative")
+        if np.isnan(st.eps_abs) or st.eps_abs < 0:
+            raise ValueError("eps_abs must be nonnegative")
+        if np.isnan(st.eps_rel) or st.eps_rel < 0:
+            raise ValueError("eps_rel must be nonnegative")
+        if np.isnan(st.eps_infeas) or st.eps_infeas < 0:
+            raise ValueError("eps_infeas must be nonnegative")
+        if not np.isfinite(st.alpha) or st.alpha <= 0 or st.alpha >= 2:
+            raise ValueError("alpha must be in (0, 2)")
+        if not np.isfinite(st.rho_x) or st.rho_x <= 0:
+            raise ValueError("rho_x must be a positive finite number")
+        st.warm_start = 0
+        # ---- hand over to the C core (it copies everything, R:scs/scsobject.h:908)
+        A = _ScsMatrix(_pd(Axc), _pi(Aic), _pi(Apc), m, n)
+        P = _ScsMatrix(_pd(Pxc), _pi(Pic), _pi(Ppc), n, n) if have_P else None
+        d = _ScsData(m, n, C.pointer(A), C.pointer(P) if have_P else None, _pd(bc), _pd(cc))
+        k = _ScsCone(z, lcone, _pd(bu), _pd(bl), (bu.size + 1) if bu.size > 0 else 0,
+                     _pi(q), q.size, _pi(s), s.size, _pi(cs), cs.size, ep, ed, _pd(p), p.size)
+        self._x = np.zeros(n)
+        self._y = np.zeros(m)
+        self._s = np.zeros(m)
+        work = _lib.scs_init(C.byref(d), C.byref(k), C.byref(st))  # GIL released by ctypes
+        if not work:
+            self._init_error = last_error()
+            raise ValueError("ScsWork allocation error!")
+        self._work = work
+
+    # ------------------------------------------------------------------ solve
+    def _warm(self, name, dst, src):
+        """R:scs/scsobject.h:129-146"""
+        if not isinstance(src, np.ndarray) or not np.issubdtype(src.dtype, np.floating) or src.ndim != 1:
+            raise ValueError("Unable to parse %s warm-start" % name)
+        if src.shape[0] != dst.shape[0]:
+            raise ValueError("Unable to parse %s warm-start" % name)
+        dst[:] = src
+
+    def solve(self, warm_start=True, x=None, y=None, s=None):
+        if not isinstance(warm_start, (bool, np.bool_)):
+            raise TypeError("argument 1 must be bool, not %s" % type(warm_start).__name__)
+        with self._lock:
+            if not self._work:
+                raise ValueError("Workspace not initialized!")
+            if warm_start:
+                if x is not None:
+                    self._warm("x", self._x, x)
+                if y is not None:
+                    self._warm("y", self._y, y)
+                if s is not None:
+                    self._warm("s", self._s, s)
+            sol = _ScsSolution(_pd(self._x), _pd(self._y), _pd(self._s))
+            info = _ScsInfo()
+            _lib.scs_solve(self._work, C.byref(sol), C.byref(info), 1 if warm_start else 0)
+            # fresh copies owning their data (R:scs/scsobject.h:993-1043), taken under the lock
+            xo, yo, so = self._x.copy(), self._y.copy(), self._s.copy()
+        aa = info.aa_stats
+        info_dict = {
+            "status_val": int(info.status_val),
+            "iter": int(info.iter),
+            "scale_updates": int(info.scale_updates),
+            "scale": float(info.scale),
+            "pobj": float(info.pobj),
+            "dobj": float(info.dobj),
+            "res_pri": float(info.res_pri),
+            "res_dual": float(info.res_dual),
+            "gap": float(info.gap),
+            "res_infeas": float(info.res_infeas),
+            "res_unbdd_a": float(info.res_unbdd_a),
+            "res_unbdd_p": float(info.res_unbdd_p),
+            "comp_slack": float(info.comp_slack),
+            "solve_time": float(info.solve_time),
+            "setup_time": float(info.setup_time),
+            "lin_sys_time": float(info.lin_sys_time),
+            "cone_time": float(info.cone_time),
+            "accel_time": float(info.accel_time),
+            "rejected_accel_steps": int(info.rejected_accel_steps),
+            "accepted_accel_steps": int(info.accepted_accel_steps),
+            "status": info.status.decode(),
+            "aa_stats": {
+                "iter": int(aa.iter), "n_accept": int(aa.n_accept),
+                "n_reject_lapack": int(aa.n_reject_lapack), "n_reject_rank0": int(aa.n_reject_rank0),
+                "n_reject_nonfinite": int(aa.n_reject_nonfinite),
+                "n_reject_weight_cap": int(aa.n_reject_weight_cap),
+                "n_safeguard_reject": int(aa.n_safeguard_reject), "last_rank": int(aa.last_rank),
+                "last_aa_norm": float(aa.last_aa_norm),
+                "last_regularization": float(aa.last_regularization),
+            },
+            # extras of this backend (the reference's dict is a subset)
+            "cg_iters": int(info.cg_iters),
+            "lin_sys_solver": info.lin_sys_solver.decode(),
+        }
+        return {"x": xo, "y": yo, "s": so, "info": info_dict}
+
+    # ----------------------------------------------------------------- update
+    def update(self, b=None, c=None):
+        cc = bc = None
+        if c is not None:
+            if not isinstance(c, np.ndarray) or not np.issubdtype(c.dtype, np.floating) or c.ndim != 1:
+                raise TypeError("c_new must be a 1-D numpy array of floats")
+            if c.shape[0] != self.n:
+                raise ValueError("c_new has incompatible dimension with A")
+            cc = np.array(c, dtype=np.float64, order="C", copy=True)
+        if b is not None:
+            if not isinstance(b, np.ndarray) or not np.issubdtype(b.dtype, np.floating) or b.ndim != 1:
+                raise TypeError("b_new must be a 1-D numpy array of floats")
+            if b.shape[0] != self.m:
+                raise ValueError("b_new has incompatible dimension with A")
+            bc = np.array(b, dtype=np.float64, order="C", copy=True)
+        with self._lock:
+            if not self._work:
+                raise ValueError("Workspace not initialized!")
+            _lib.scs_update(self._work, _pd(bc) if bc is not None else None, _pd(cc) if cc is not None else None)
+        return None
+
+    def __del__(self):
+        lock = getattr(self, "_lock", None)
+        work = getattr(self, "_work", None)
+        if work and lock is not None:
+            with lock:
+                _lib.scs_finish(self._work)
+                self._work = None
+
+
+# ---------------------------------------------------------------- kernel-level entry points (tests, bench)
+def _matrix(A):
+    """scipy CSC -> (_ScsMatrix, keepalive)"""
+    x = np.ascontiguousarray(A.data, dtype=np.float64)
+    i = np.ascontiguousarray(A.indices, dtype=np.int32)
+    p = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    return _ScsMatrix(_pd(x), _pi(i), _pi(p), A.shape[0], A.shape[1]), (x, i, p)
+
+
+def _cone_struct(cone):
+    z = _cone_pos_int(cone, "z") + _cone_pos_int(cone, "f")
+    bu, bl = _cone_float_list(cone, "bu"), _cone_float_list(cone, "bl")
+    q, s, cs = _cone_int_list(cone, "q"), _cone_int_list(cone, "s"), _cone_int_list(cone, "cs")
+    p = _cone_float_list(cone, "p")
+    k = _ScsCone(z, _cone_pos_int(cone, "l"), _pd(bu), _pd(bl), (bu.size + 1) if bu.size else 0,
+                 _pi(q), q.size, _pi(s), s.size, _pi(cs), cs.size,
+                 _cone_pos_int(cone, "ep"), _cone_pos_int(cone, "ed"), _pd(p), p.size)
+    return k, (bu, bl, q, s, cs, p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("libscs_hip: " + last_error())
+
+
+def spmv(A, x, transpose=False):
+    """y = A x (or A' x) through the hot-path SpMV kernel; A scipy CSC."""
+    M, keep = _matrix(A)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(A.shape[1] if transpose else A.shape[0])
+    _check(_lib.scs_hip_spmv(C.byref(M), _pd(xx), _pd(y), 1 if transpose else 0))
+    return y
+
+
+def spmv_bench(A, transpose=False, reps=20):
+    M, keep = _matrix(A)
+    ms = _lib.scs_hip_spmv_bench(C.byref(M), 1 if transpose else 0, int(reps))
+    if ms < 0:
+        raise RuntimeError("libscs_hip: " + last_error())
+    return ms
+
+
+def proj_cone(z, cone, dual=False):
+    x = np.array(z, dtype=np.float64, copy=True)
+    k, keep = _cone_struct(cone)
+    _check(_lib.scs_hip_proj_cone(_pd(x), C.byref(k), x.size, 1 if dual else 0))
+    return x
+
+
+def kkt_solve(A, P, diag_r, rhs, tol=1e-12):
+    M, keep = _matrix(A)
+    Pm = None
+    if P is not None:
+        Pm, keep2 = _matrix(P)
+    r = np.array(rhs, dtype=np.float64, copy=True)
+    dr = np.ascontiguousarray(diag_r, dtype=np.float64)
+    its = c_int(0)
+    _check(_lib.scs_hip_kkt_solve(C.byref(M), C.byref(Pm) if Pm is not None else None, _pd(dr), _pd(r),
+                                  float(tol), C.byref(its)))
+    return r, its.value
+
+
+def normalize(A, P, b, c, cone):
+    """Returns (A_data_hat, P_data_hat, b_hat, c_hat, D, E, sigma) as scs_init computes them."""
+    M, keepA = _matrix(A.copy())
+    Pm, keepP = (None, None)
+    if P is not None:
+        Pm, keepP = _matrix(P.copy())
+    bb = np.array(b, dtype=np.float64, copy=True)
+    cc = np.array(c, dtype=np.float64, copy=True)
+    k, keep = _cone_struct(cone)
+    D, E, sig = np.zeros(A.shape[0]), np.zeros(A.shape[1]), np.zeros(1)
+    _check(_lib.scs_hip_normalize(C.byref(M), C.byref(Pm) if Pm is not None else None, _pd(bb), _pd(cc),
+                                  C.byref(k), _pd(D), _pd(E), _pd(sig)))
+    return keepA[0], (keepP[0] if keepP else None), bb, cc, D, E, float(sig[0])
+
+
+def copy_bandwidth(nbytes=1 << 30, reps=10):
+    return float(_lib.scs_hip_copy_bandwidth(int(nbytes), int(reps)))

@@ -1,0 +1,56 @@
+"""Shared helpers for the test-suite: golden loaders and certificate checks."""
+import os
+
+import numpy as np
+from scipy import sparse
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cone_from_npz(d, prefix=""):
+    return {"z": int(d[prefix + "K_z"]), "l": int(d[prefix + "K_l"]), "q": d[prefix + "K_q"].tolist(),
+            "s": d[prefix + "K_s"].tolist(), "ep": int(d[prefix + "K_ep"]), "ed": int(d[prefix + "K_ed"]),
+            "p": d[prefix + "K_p"].tolist()}
+
+
+def load_problem(fname, prefix):
+    d = np.load(os.path.join(GOLDEN, fname))
+    K = cone_from_npz(d)
+    A = sparse.csc_matrix((d[prefix + "A_data"], d[prefix + "A_indices"], d[prefix + "A_indptr"]),
+                          shape=tuple(int(t) for t in d[prefix + "shape"]))
+    p_star = float(d[prefix + "p_star"]) if (prefix + "p_star") in d else None
+    return {"A": A, "b": d[prefix + "b"].copy(), "c": d[prefix + "c"].copy()}, K, p_star
+
+
+def load_projection_cases():
+    d = np.load(os.path.join(GOLDEN, "cone_projections.npz"))
+    out = []
+    for tag in d["names"]:
+        tag = str(tag)
+        out.append((tag, cone_from_npz(d, tag), d[tag + "z"], d[tag + "proj"], d[tag + "dual"]))
+    return out
+
+
+def raw_args(data, cone):
+    """(shape, Ax, Ai, Ap, Px, Pi, Pp, b, c, cone) — the raw backend call surface."""
+    A = sparse.csc_matrix(data["A"])
+    A.sort_indices()
+    P = data.get("P")
+    Px = Pi = Pp = None
+    if P is not None:
+        P = sparse.triu(sparse.csc_matrix(P), format="csc")
+        P.sort_indices()
+        Px, Pi, Pp = P.data, P.indices, P.indptr
+    return (A.shape, A.data, A.indices, A.indptr, Px, Pi, Pp,
+            np.asarray(data["b"], dtype=np.float64), np.asarray(data["c"], dtype=np.float64), cone)
+
+
+def kkt_certificate(data, sol, P=None):
+    """max-norm primal / dual residuals and gap of a 'solved' answer in original units"""
+    A, b, c = data["A"], data["b"], data["c"]
+    x, y, s = sol["x"], sol["y"], sol["s"]
+    pri = np.abs(A @ x + s - b).max()
+    px = P @ x if P is not None else 0.0
+    dual = np.abs(px + A.T @ y + c).max()
+    gap = abs((x @ px if P is not None else 0.0) + c @ x + b @ y)
+    return pri, dual, gap

@@ -1,0 +1,179 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every hot-path kernel and the
+whole ADMM loop against the CPU oracle, through the C-ABI (ctypes -> libscs_hip.so).
+
+Tolerances: SpMV bit-exact (same per-row summation order as the oracle);
+SOC / PSD / box / power / exp projections 1e-9 .. 1e-7 absolute; KKT solve 1e-8
+relative; full solves: x, y, s within rtol 1e-4 of the oracle's direct-LDL answer
+at eps = 1e-9 (the notion of cross-backend agreement the reference itself tests,
+R:test/test_scs_coverage.py:2060-2080), objective within 1e-6 of p*.
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import helpers
+import problem_gen as pg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from scs import _scs_hip
+    assert _scs_hip.device_count() > 0, "GPU tests need a HIP device (no CPU fallback exists)"
+    return _scs_hip
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import scs_oracle
+    return scs_oracle
+
+
+def _rand_csc(m, n, density, seed, long_rows=False):
+    rng = np.random.RandomState(seed)
+    A = sparse.rand(m, n, density, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    if long_rows:  # a few dense rows / columns exercise the long-row path (> 2048 nnz)
+        A = A.tolil()
+        A[3, :] = rng.randn(n)
+        A[:, 5] = rng.randn(m).reshape(-1, 1)
+        A = A.tocsc()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("m,n,density,long_rows", [
+    (50, 30, 0.2, False), (1000, 700, 0.01, False), (5000, 4000, 0.002, True),
+    (300, 1, 0.5, False), (1, 300, 0.5, False), (4000, 3000, 0.0, False),
+])
+def test_spmv_bit_exact(hip, oracle, m, n, density, long_rows):
+    A = _rand_csc(m, n, density, 11, long_rows)
+    rng = np.random.RandomState(5)
+    x, y = rng.randn(n), rng.randn(m)
+    np.testing.assert_array_equal(hip.spmv(A, x), oracle.spmv(A, x))
+    np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), oracle.spmv(A, y, trans=True))
+
+
+@pytest.mark.parametrize("case", helpers.load_projection_cases(), ids=lambda c: c[0])
+def test_cone_projection_vs_oracle_and_golden(hip, oracle, case):
+    tag, K, z, gproj, gdual = case
+    if z.size == 0:
+        return
+    for dual, gold in ((False, gproj), (True, gdual)):
+        got = hip.proj_cone(z, K, dual=dual)
+        ref = oracle.proj_cone(z, K, dual=dual)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-8 * max(1.0, np.abs(z).max()))
+        # goldens: the reference's Python exp bisection stops at 1e-9 on rho with an inner
+        # Newton tolerance of 1e-6 (R:test/gen_random_cone_prob.py:259-313) => 1e-4 there
+        np.testing.assert_allclose(got, gold, rtol=0, atol=1e-4 * max(1.0, np.abs(z).max()))
+
+
+def test_cone_projection_large_mixed(hip, oracle):
+    rng = np.random.RandomState(3)
+    K = {"z": 100, "l": 300, "bu": (rng.rand(99) + 0.1).tolist(), "bl": (-rng.rand(99) - 0.1).tolist(),
+         "q": [20] * 50 + [5000, 1, 0, 2], "s": [1, 2, 7, 16, 33], "ep": 500, "ed": 500,
+         "p": (rng.uniform(0.1, 0.9, 400) * rng.choice([-1, 1], 400)).tolist()}
+    m = pg.cone_dims(K)
+    for scl in (1.0, 25.0):
+        z = scl * rng.randn(m)
+        for dual in (False, True):
+            got = hip.proj_cone(z, K, dual=dual)
+            ref = oracle.proj_cone(z, K, dual=dual)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-8 * scl)
+
+
+@pytest.mark.parametrize("with_P", [False, True])
+def test_kkt_solve_vs_direct_ldl(hip, oracle, with_P):
+    m, n = 600, 250
+    A = _rand_csc(m, n, 0.03, 21)
+    rng = np.random.RandomState(8)
+    P = None
+    if with_P:
+        B = sparse.rand(n, n, 0.02, format="csc", random_state=rng)
+        P = sparse.triu(B.T @ B + sparse.eye(n) * 0.1, format="csc")
+        P.sort_indices()
+    diag_r = np.concatenate([np.full(n, 1e-3), np.full(50, 0.01), np.full(m - 50, 10.0)])
+    rhs = rng.randn(n + m)
+    ref, _ = oracle.kkt_solve(A, P, diag_r, rhs, indirect=False)
+    got, its = hip.kkt_solve(A, P, diag_r, rhs, tol=1e-13)
+    assert its > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
+
+
+STG = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False)
+
+
+def _solve_both(hip, oracle, data, K, **kw):
+    stg = dict(STG)
+    stg.update(kw)
+    args = helpers.raw_args(data, K)
+    got = hip.SCS(*args, **stg).solve(False, None, None, None)
+    ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
+    return got, ref
+
+
+def _assert_xys(got, ref, rtol=1e-4):
+    for key in ("x", "y", "s"):
+        scale = np.abs(ref[key]).max()
+        np.testing.assert_allclose(got[key], ref[key], rtol=rtol, atol=rtol * scale, err_msg=key)
+
+
+@pytest.mark.parametrize("fname,prefix", [
+    ("problems_std.npz", "std_feas_"), ("problems_rand.npz", "feas0_"), ("problems_rand.npz", "feas1_"),
+    ("problems_sdp.npz", "feas0_"), ("problems_sdp.npz", "feas2_"),
+])
+def test_solve_feasible_golden(hip, oracle, fname, prefix):
+    data, K, p_star = helpers.load_problem(fname, prefix)
+    got, ref = _solve_both(hip, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    assert abs(got["info"]["pobj"] - p_star) < 1e-5 * max(1, abs(p_star))
+    assert abs(-data["b"] @ got["y"] - p_star) < 1e-5 * max(1, abs(p_star))
+    _assert_xys(got, ref)
+    pri, dual, gap = helpers.kkt_certificate(data, got)
+    assert pri < 1e-6 and dual < 1e-6 and gap < 1e-6
+    # cone membership through the oracle's projections (R:test/test_solve_random_cone_prob.py:63-65)
+    np.testing.assert_allclose(got["s"], oracle.proj_cone(got["s"], K), atol=1e-6)
+    np.testing.assert_allclose(got["y"], oracle.proj_cone(got["y"], K, dual=True), atol=1e-6)
+
+
+@pytest.mark.parametrize("fname,prefix", [("problems_std.npz", "std_infeas_"), ("problems_rand.npz", "infeas0_"),
+                                          ("problems_sdp.npz", "infeas1_")])
+def test_solve_infeasible_golden(hip, oracle, fname, prefix):
+    data, K, _ = helpers.load_problem(fname, prefix)
+    got, ref = _solve_both(hip, oracle, data, K, eps_infeas=1e-7)
+    assert got["info"]["status"] == "infeasible" and ref["info"]["status"] == "infeasible"
+    y = got["y"]
+    assert np.linalg.norm(data["A"].T @ y) < 1e-3 and data["b"] @ y < -0.1
+    np.testing.assert_allclose(y, oracle.proj_cone(y, K, dual=True), atol=1e-4)
+    assert np.isnan(got["x"]).all() and np.isnan(got["s"]).all()
+
+
+def test_lp_soc_generated_parity(hip, oracle):
+    K, n, k, seed = pg.workload("small_lp_soc")
+    data, p_star, (x0, y0, s0) = pg.gen_feasible(K, n, k, seed, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    got, ref = _solve_both(hip, oracle, data, K)
+    assert got["info"]["status"] == "solved"
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+    _assert_xys(got, ref)
+
+
+def test_qp_with_P_parity(hip, oracle):
+    d = np.load(helpers.GOLDEN + "/warm_start_qp.npz")
+    P = sparse.csc_matrix((d["P_data"], d["P_indices"], d["P_indptr"]), shape=(15, 15))
+    G = sparse.csc_matrix((d["G_data"], d["G_indices"], d["G_indptr"]), shape=(60, 15))
+    data = {"P": P, "A": G, "b": d["h"].copy(), "c": d["q"].copy()}
+    got, ref = _solve_both(hip, oracle, data, {"l": 60})
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _assert_xys(got, ref)
+
+
+def test_determinism_bit_exact(hip):
+    # R:test/test_scs_coverage.py:2283-2301 — two fresh instances give identical bits
+    data, K, _ = helpers.load_problem("problems_std.npz", "std_feas_")
+    args = helpers.raw_args(data, K)
+    a = hip.SCS(*args, verbose=False).solve(False, None, None, None)
+    b = hip.SCS(*args, verbose=False).solve(False, None, None, None)
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert a["info"]["iter"] == b["info"]["iter"]

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — ADMM iterations/sec of the MI355X-native SCS hot path + SpMV roofline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  * workload (N=1): the configuration BASELINE.json's metric is quoted on — random LP+SOC cone
+    program m=2e6, n=1e6, nnz~2e7 (problem_gen.workload("target_lp_soc")), synthetic, seeded.
+  * a "step" = one ADMM iteration of the reference's hot path (KKT solve by PCG over A/A' on the
+    device, cone projection, dual update, AA every 10th, convergence check every 25th).  The timed
+    region is ONE scs.SCS(...).solve() call that executes EXACTLY K iterations from a cold start
+    (max_iters=K, eps=0 so the termination test can never fire early); inputs are resident in HBM
+    (scs_init uploaded them) when the timed region starts.  Warm-up = a separate solver instance
+    running W iterations on the same data.
+  * N>1 (torchrun, one rank per GPU): every rank solves its own independent instance of the same
+    size (seed + rank) — the path shards across problems with no data-path collective
+    (SURVEY §8e); value = sum of iterations over ranks / max time; the solutions are then
+    collected with one RCCL gather, outside the timed region.
+  * roofline: dominant kernel = the CG-step SpMV pair.  Its average launch duration is measured
+    live inside the timed solve with HIP events on the solver's own stream (scs_hip_kernel_times).
+  * cpu_baseline (rank 0, N=1): the oracle's CPU-CG variant ("port", 1 thread) on the same
+    instance for the first few iterations.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "scs-python_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="target_lp_soc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    return ap.parse_args()
+
+
+def spmv_bytes(nnz, rows, cols):
+    """algorithmic bytes of one y = M v: fp64 values, int32 indices"""
+    return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch  # first: its bundled HIP runtime must be the one in the process
+    import torch.distributed as dist
+    import numpy as np
+    import scs
+    from scs import _scs_hip
+    import problem_gen as pg
+
+    if _scs_hip.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device; the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    _scs_hip.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- synthetic instance (per rank) ----------------
+    K, n, k, seed = pg.workload(args.workload)
+    t0 = time.perf_counter()
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, lambda z, K: _scs_hip.proj_cone(z, K, dual=True))
+    m = data["A"].shape[0]
+    nnz = int(data["A"].nnz)
+    t_gen = time.perf_counter() - t0
+
+    common = dict(eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False,
+                  acceleration_lookback=10, linear_solver=scs.LinearSolver.HIP_INDIRECT)
+    # ---------------- warm-up ----------------
+    if args.warmup > 0:
+        wsolver = scs.SCS(data, K, max_iters=args.warmup, **common)
+        wsolver.solve()
+        del wsolver
+    solver = scs.SCS(data, K, max_iters=args.steps, **common)
+    solver._solver._set_profiling(True)
+
+    # ---------------- timed region: exactly K ADMM iterations ----------------
+    barrier()
+    t0 = time.perf_counter()
+    sol = solver.solve(warm_start=False)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    info = sol["info"]
+    assert info["iter"] == args.steps, (info["iter"], args.steps, info["status"])
+    kt = solver._solver._kernel_times()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    its = torch.tensor([float(info["iter"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(its, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tmax.item())
+    total_iters = float(its.item())
+
+    # ---------------- single RCCL gather of the solutions (outside the timed region) ----------------
+    gather_ms = None
+    if world > 1:
+        payload = torch.from_numpy(np.concatenate([sol["x"], sol["y"], sol["s"]])).cuda()
+        bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.gather(payload, bufs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- roofline of the dominant kernel ----------------
+    HBM_PEAK = 8000.0  # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+    k1_avg = kt["k1_ms"] / max(kt["k1_n"], 1)
+    k2_avg = kt["k2_ms"] / max(kt["k2_n"], 1)
+    b1 = spmv_bytes(nnz, m, n) + 8 * m      # + R_y read fused in the epilogue
+    b2 = spmv_bytes(nnz, n, m) + 16 * n     # + R_x, p reads fused in the epilogue
+    gb1 = b1 / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
+    gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
+    dom = ("K1 k_spmv_stream<EpiDivR> (z = R_y^-1 A p)", b1, k1_avg, gb1) if k1_avg >= k2_avg else \
+          ("K2 k_spmv_stream<EpiGp> (Gp = A'z + R_x p)", b2, k2_avg, gb2)
+    roofline = {
+        "bound": "hbm", "achieved": round(dom[3], 1), "peak": HBM_PEAK, "unit": "GB/s",
+        "frac": round(dom[3] / HBM_PEAK, 4), "traffic": None,
+        "kernel": dom[0], "algorithmic_bytes_per_launch": int(dom[1]), "avg_launch_ms": round(dom[2], 5),
+        "samples": kt["k1_n"],
+        "k1": {"bytes": int(b1), "avg_ms": round(k1_avg, 5), "GBps": round(gb1, 1), "frac": round(gb1 / HBM_PEAK, 4)},
+        "k2": {"bytes": int(b2), "avg_ms": round(k2_avg, 5), "GBps": round(gb2, 1), "frac": round(gb2 / HBM_PEAK, 4)},
+    }
+
+    # ---------------- CPU baseline (oracle CPU-CG, 1 thread, bounded sample) ----------------
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import scs_oracle  # the checker, timed beside the product; never in the product path
+        ci = max(1, args.cpu_iters)
+        stg = dict(eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False, acceleration_lookback=10, max_iters=ci)
+        ref = scs_oracle.solve(data, K, indirect=True, **stg)
+        cpu_ms = ref["info"]["solve_time"]
+        gsolver = scs.SCS(data, K, max_iters=ci, **common)
+        gsol = gsolver.solve(warm_start=False)
+        gpu_ms = gsol["info"]["solve_time"]
+        cpu_baseline = {
+            "value": round(ci / (cpu_ms * 1e-3), 5), "unit": "ADMM iters/s", "cores": 1, "kind": "port",
+            "sample": "first %d ADMM iterations (cold start, %d CG steps) of the same instance on the "
+                      "oracle's CPU-CG variant: %.1f s; the HIP path runs the same %d iterations "
+                      "(%d CG steps) in %.3f s; host has %d cores" % (
+                          ci, ref["info"]["cg_iters"], cpu_ms * 1e-3, ci, gsol["info"]["cg_iters"],
+                          gpu_ms * 1e-3, os.cpu_count()),
+        }
+
+    out = {
+        "metric": "ADMM iters/sec (random LP+SOC cone program, indirect CG linsys, AA lookback 10)",
+        "value": round(total_iters / elapsed_max, 4),
+        "unit": "ADMM iters/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed_max * 1e3 / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "%s: m=%d n=%d nnz=%d cone=%s seed=%d(+rank); one independent instance per GPU" % (
+                args.workload, m, n, nnz, {kk: (vv if not isinstance(vv, list) else "%dx%s" % (len(vv), vv[0]))
+                                           for kk, vv in K.items()}, seed),
+            "cg_steps_per_admm_iter": round(info["cg_iters"] / max(info["iter"], 1), 2),
+            "admm_iters_timed": int(info["iter"]),
+            "lin_sys_ms": round(info["lin_sys_time"], 1), "cone_ms": round(info["cone_time"], 1),
+            "accel_ms": round(info["accel_time"], 1), "setup_ms": round(info["setup_time"], 1),
+            "gen_s": round(t_gen, 1), "gather_ms": gather_ms,
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

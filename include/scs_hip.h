@@ -85,6 +85,13 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
 /* Measured device-copy bandwidth ceiling in GB/s (float4 copy of `bytes` bytes). */
 double scs_hip_copy_bandwidth(size_t bytes, int reps);
 
+/* Live timing of the two dominant kernels inside scs_solve: when enabled, one CG step per
+ * host sync is bracketed by HIP events on the solver's own stream.  out[8] =
+ * {K1 total ms, K1 samples, K2 total ms, K2 samples, nnz(A), K1 workgroups, K2 workgroups, nnz(P full)}
+ * where K1 = z <- R_y^{-1} A p  and  K2 = Gp <- A' z + R_x p (+ P p). */
+void scs_hip_set_profiling(ScsWork *w, int on);
+void scs_hip_kernel_times(const ScsWork *w, double *out);
+
 /* last error message of the calling thread ("" if none) */
 const char *scs_hip_last_error(void);
 

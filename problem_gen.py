@@ -77,3 +77,24 @@ def workload(name):
     if name == "config5_small":   # one problem of the 512-problem batch
         return {"l": 2000, "q": [50] * 20, "s": [20] * 5}, 1350, 40, 1000
     raise KeyError(name)
+
+
+def gen_feasible_qp(K, n, nnz_per_col, seed, proj_dual, p_diag=1.0):
+    """Strictly convex QP over the cone K: P = p_diag*I + B'B (sparse, PD) makes x — hence s — unique,
+    and with n >= #active rows the dual y is unique too, so x, y, s can all be compared entry-wise.
+    Returns (data with P upper-triangular CSC, p_star, (x, y, s))."""
+    rng = np.random.default_rng(seed)
+    m = cone_dims(K)
+    z = rng.standard_normal(m)
+    y = np.asarray(proj_dual(z, K), dtype=np.float64)
+    s = y - z
+    A = random_sparse(m, n, nnz_per_col, rng)
+    B = random_sparse(max(n // 4, 1), n, 3, rng)
+    P = (B.T @ B + p_diag * sparse.eye(n)).tocsc()
+    P.sort_indices()
+    x = rng.standard_normal(n)
+    c = -(P @ x) - (A.T @ y)
+    b = A @ x + s
+    Pu = sparse.triu(P, format="csc")
+    Pu.sort_indices()
+    return {"P": Pu, "A": A, "b": b, "c": c}, float(0.5 * x @ (P @ x) + c @ x), (x, y, s)

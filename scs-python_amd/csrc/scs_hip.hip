@@ -126,6 +126,10 @@ struct ScsHipWork {
   int n_log_scale_factor = 0, last_scale_update_iter = 0, scale_updates = 0;
   long tot_cg_iters = 0;
   int last_cg_iters = 8;
+  // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
+  bool profile = false;
+  double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
+  long prof_n[2] = {0, 0};
   std::mutex mtx;
 
   ~ScsHipWork() {
@@ -176,14 +180,24 @@ struct ScsHipWork {
     const int nb = vb(n);
     if (warm) matvec(warm, nullptr);
     hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(kVecThreads), 0, stream, cg_b.p, cg_Gp.p, warm, cg_M.p, xout, cg_r.p, cg_p.p,
-                       n, warm ? 1 : 0, part.p);
+                       n, warm ? 1 : 0, fl.p, part.p);
     hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
     int done_iters = 0;
     int chunk = std::max(1, std::min(last_cg_iters + 1, 64));
     while (true) {
+      const int iters_before = done_iters;
       for (int it = 0; it < chunk; ++it) {
-        matvec(cg_p.p, fl.p + F_DONE);
+        if (profile && it == 0) {
+          HIP_CHECK(hipEventRecord(ev[0], stream));
+          launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream);
+          HIP_CHECK(hipEventRecord(ev[1], stream));
+          if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+          launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
+          HIP_CHECK(hipEventRecord(ev[2], stream));
+        } else {
+          matvec(cg_p.p, fl.p + F_DONE);
+        }
         hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nblk, sc.p, fl.p);
         hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, sc.p,
                            fl.p, part.p);
@@ -192,6 +206,13 @@ struct ScsHipWork {
       }
       read_flags();
       done_iters = h_flags[F_ITERS];
+      if (profile && done_iters > iters_before) {  // the sampled step really ran (not an early-exit launch)
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
+          prof_ms[0] += a; prof_n[0]++;
+          prof_ms[1] += b; prof_n[1]++;
+        }
+      }
       if (h_flags[F_DONE] || done_iters >= max_its) break;
       chunk = std::max(2, std::min(std::max(done_iters / 2, 4), 64));
     }
@@ -205,7 +226,7 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_kkt_prep, dim3(vb(m)), dim3(kVecThreads), 0, stream, rhs, diag_r.p, tmp_m.p, n, m);
     launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, rhs}, nullptr, stream);
     HIP_CHECK(hipMemsetAsync(part.p, 0, sizeof(double), stream));
-    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, 1, 0.0, 1.0, tol, sc.p, fl.p);
+    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, 1, 0.0, 1.0, tol, 0, sc.p, fl.p);
     const int its = run_cg(ws.p, nullptr, 10 * n);  // solution in ws
     launch_spmv(Ar.view(), ws.p, EpiStore{tmp_m.p, 0}, nullptr, stream);
     hipLaunchKernelGGL(k_kkt_y, dim3(vb(m)), dim3(kVecThreads), 0, stream, rhs, tmp_m.p, diag_r.p, n, m);
@@ -233,7 +254,7 @@ struct ScsHipWork {
                        n, m, iter >= 1 ? 1 : 0, sc.p, part.p);
     const double res_min = std::min(r.nm_pri_n, r.nm_dual_n);
     hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, res_min, std::pow((double)iter + 1, 1.5),
-                       0.0, sc.p, fl.p);
+                       0.0, 1, sc.p, fl.p);
     // rhs_x + A' R_y^{-1} rhs_y
     launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, ut.p}, nullptr, stream);
     run_cg(ut.p, ws.p, 10 * n);
@@ -660,6 +681,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   w->aa_stats = ScsAaStats{};
   w->r = Residuals{};
   w->tot_cg_iters = 0;
+  w->prof_ms[0] = w->prof_ms[1] = 0;
+  w->prof_n[0] = w->prof_n[1] = 0;
   double t_lin = 0, t_cone = 0, t_acc = 0;
 
   // ---- initial iterate ----
@@ -945,6 +968,17 @@ int scs_hip_set_device(int dev) {
   return 0;
 }
 const char *scs_hip_last_error(void) { return g_last_error.c_str(); }
+
+void scs_hip_set_profiling(ScsWork *w, int on) {
+  if (w) w->profile = on != 0;
+}
+void scs_hip_kernel_times(const ScsWork *w, double *out) {
+  if (!w || !out) return;
+  out[0] = w->prof_ms[0]; out[1] = (double)w->prof_n[0];
+  out[2] = w->prof_ms[1]; out[3] = (double)w->prof_n[1];
+  out[4] = (double)w->At.nnz; out[5] = (double)w->Ar.nblk; out[6] = (double)w->At.nblk;
+  out[7] = w->has_P ? (double)w->Pf.nnz : 0.0;
+}
 
 // ---- kernel-level entry points (tests / bench) ----
 struct TmpStream {

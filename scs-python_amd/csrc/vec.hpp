@@ -23,7 +23,7 @@ enum : int {
 // device flag slots (int)
 enum : int {
   F_DONE = 0, F_ITERS, F_AA_SUCCESS, F_AA_ITER, F_AA_ACCEPT, F_AA_REJ_LAPACK, F_AA_REJ_RANK0, F_AA_REJ_NONFINITE,
-  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_COUNT = 32
+  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_COUNT = 32
 };
 
 inline int vec_blocks(long n) {
@@ -72,29 +72,38 @@ __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev,
   const long l = (long)n + m + 1;
   const double scale = do_scale ? sc[S_VSCALE] : 1.0;
   const double tau = u[l - 1];
-  double mx = 0.;
+  double mx = 0., mr = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
     const double vi = v[i] * scale;
     v[i] = vi;
     v_prev[i] = vi;
     if (i < n) {
-      ut[i] = diag_r[i] * vi;
+      const double rv = diag_r[i] * vi;
+      ut[i] = rv;
       const double w = u[i] + tau * g[i];
       ws[i] = w;
       mx = fmax(mx, abs_nan_inf(w));
+      mr = fmax(mr, abs_nan_inf(rv));
     } else if (i < l - 1) {
       tmp[i - n] = -vi;
+      mr = fmax(mr, abs_nan_inf(diag_r[i] * vi));
     }
   }
   mx = block_max<kVecThreads>(mx, sm);
-  if (threadIdx.x == 0) part[blockIdx.x] = mx;
+  mr = block_max<kVecThreads>(mr, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = mx;
+    part[gridDim.x + blockIdx.x] = mr;  // ||rhs||_inf of the KKT system
+  }
 }
 
 // CG tolerance: tol = max(1e-12, 0.2 * min(res_min, ||ws||_inf / (k+1)^1.5))
+// A right-hand side with ||rhs||_inf <= 1e-12 short-circuits to the zero solution (F_ZERO_RHS).
 __global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int np, double res_min, double ipow,
-                                                         double fixed_tol, double *sc, int *fl) {
+                                                         double fixed_tol, int have_rhs_norm, double *sc, int *fl) {
   __shared__ double sm[kVecThreads / 64];
   const double ws = part_max(part, np, sm);
+  const double rn = have_rhs_norm ? part_max(part + np, np, sm) : 1.0;
   if (threadIdx.x == 0) {
     double tol = fixed_tol;
     if (fixed_tol <= 0.) {
@@ -103,16 +112,27 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int
     }
     sc[S_TOL] = tol;
     sc[S_WSNORM] = ws;
-    fl[F_DONE] = 0;
+    const int zero = (rn <= 1e-12) ? 1 : 0;
+    fl[F_ZERO_RHS] = zero;
+    fl[F_DONE] = zero;
   }
 }
 
 // r = b - G ws; x = ws; p = M r; partial [max|r| , sum r M r]
 __global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restrict__ b, const double *__restrict__ Gws,
                                                          const double *__restrict__ ws, const double *__restrict__ M,
-                                                         double *x, double *r, double *p, int n, int have_ws, double *part) {
+                                                         double *x, double *r, double *p, int n, int have_ws, const int *fl,
+                                                         double *part) {
   __shared__ double sm[kVecThreads / 64];
   double mx = 0., s = 0.;
+  if (fl[F_ZERO_RHS]) {  // zero right-hand side: the solution is zero, no iterations
+    for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) x[i] = 0.;
+    if (threadIdx.x == 0) {
+      part[blockIdx.x] = 0.;
+      part[gridDim.x + blockIdx.x] = 0.;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
     const double ri = have_ws ? b[i] - Gws[i] : b[i];
     const double zi = M[i] * ri;

@@ -151,6 +151,10 @@ def _load():
     lib.scs_hip_normalize.restype = c_int
     lib.scs_hip_normalize.argtypes = [C.POINTER(_ScsMatrix), C.POINTER(_ScsMatrix), _PD, _PD,
                                       C.POINTER(_ScsCone), _PD, _PD, _PD]
+    lib.scs_hip_set_profiling.restype = None
+    lib.scs_hip_set_profiling.argtypes = [C.c_void_p, c_int]
+    lib.scs_hip_kernel_times.restype = None
+    lib.scs_hip_kernel_times.argtypes = [C.c_void_p, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
     lib.scs_hip_copy_bandwidth.argtypes = [C.c_size_t, c_int]
     return lib
@@ -516,6 +520,18 @@ class SCS(object):
                 raise ValueError("Workspace not initialized!")
             _lib.scs_update(self._work, _pd(bc) if bc is not None else None, _pd(cc) if cc is not None else None)
         return None
+
+    # -------------------------------------------------- bench hooks (not part of the reference surface)
+    def _set_profiling(self, on):
+        with self._lock:
+            _lib.scs_hip_set_profiling(self._work, 1 if on else 0)
+
+    def _kernel_times(self):
+        out = np.zeros(8)
+        with self._lock:
+            _lib.scs_hip_kernel_times(self._work, _pd(out))
+        return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
+                "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7])}
 
     def __del__(self):
         lock = getattr(self, "_lock", None)

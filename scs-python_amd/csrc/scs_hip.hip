@@ -43,7 +43,13 @@ struct DeviceCsr {
   DevBuf<double> val;
   int rows = 0, cols = 0, nblk = 0;
   long nnz = 0;
-  void upload(int rows_, int cols_, const int *rp, const int *ci, const double *v, hipStream_t s) {
+  // optional L2-blocked copy (spmv.hpp) used by the mat-vec kernels when the gather vector exceeds L2
+  bool has_slab = false;
+  DevBuf<int> s_segptr, s_col;
+  DevBuf<unsigned short> s_roff;
+  DevBuf<double> s_val;
+  int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
+  void upload(int rows_, int cols_, const int *rp, const int *ci, const double *v, hipStream_t s, bool allow_slab = true) {
     rows = rows_; cols = cols_; nnz = rp[rows_];
     std::vector<int> rb = build_rowblocks(rp, rows);
     nblk = (int)rb.size() - 1;
@@ -51,9 +57,30 @@ struct DeviceCsr {
     col.upload(ci, nnz, s);
     val.upload(v, nnz, s);
     rowblk.upload(rb.data(), rb.size(), s);
+    has_slab = false;
+    const char *env = getenv("SCS_HIP_SLAB");  // "0" forces the plain CSR-stream kernel (A/B measurements)
+    if (allow_slab && slab_wanted(rows, cols) && !(env && env[0] == '0')) {
+      HostSlab hs;
+      if (build_slab(rp, ci, v, rows, cols, hs)) {
+        s_segptr.upload(hs.segptr.data(), hs.segptr.size(), s);
+        s_roff.upload(hs.roff.data(), hs.roff.size(), s);
+        s_col.upload(hs.col.data(), hs.col.size(), s);
+        s_val.upload(hs.val.data(), hs.val.size(), s);
+        s_nchunks = hs.nchunks; s_S = hs.S; s_R = hs.R; s_max_seg = hs.max_seg;
+        has_slab = true;
+        HIP_CHECK(hipStreamSynchronize(s));  // hs is a local
+      }
+    }
     HIP_CHECK(hipStreamSynchronize(s));  // rb is a local
   }
-  CsrView view() const { return CsrView{rowptr.p, col.p, val.p, rowblk.p, rows, cols, nblk, nnz}; }
+  SpmvMat view() const {
+    SpmvMat M;
+    M.csr = CsrView{rowptr.p, col.p, val.p, rowblk.p, rows, cols, nblk, nnz};
+    M.use_slab = has_slab;
+    if (has_slab) M.slab = SlabView{s_segptr.p, s_roff.p, s_col.p, s_val.p, rows, cols, s_nchunks, s_S, s_R, s_max_seg};
+    return M;
+  }
+  int nwg() const { return has_slab ? s_nchunks : nblk; }
 };
 
 struct Residuals {
@@ -187,8 +214,9 @@ struct ScsHipWork {
     int chunk = std::max(1, std::min(last_cg_iters + 1, 64));
     while (true) {
       const int iters_before = done_iters;
+      const int sample_it = chunk / 2;  // a mid-chunk step: not the one right behind the host sync
       for (int it = 0; it < chunk; ++it) {
-        if (profile && it == 0) {
+        if (profile && it == sample_it) {
           HIP_CHECK(hipEventRecord(ev[0], stream));
           launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream);
           HIP_CHECK(hipEventRecord(ev[1], stream));
@@ -198,7 +226,7 @@ struct ScsHipWork {
         } else {
           matvec(cg_p.p, fl.p + F_DONE);
         }
-        hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nblk, sc.p, fl.p);
+        hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
         hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, sc.p,
                            fl.p, part.p);
         hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
@@ -206,7 +234,7 @@ struct ScsHipWork {
       }
       read_flags();
       done_iters = h_flags[F_ITERS];
-      if (profile && done_iters > iters_before) {  // the sampled step really ran (not an early-exit launch)
+      if (profile && done_iters - iters_before > sample_it) {  // the sampled step really ran (not an early-exit launch)
         float a = 0, b = 0;
         if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
           prof_ms[0] += a; prof_n[0]++;
@@ -314,11 +342,11 @@ struct ScsHipWork {
     const double *x = u.p, *y = u.p + n, *s = rsk.p + n, *tau_ptr = u.p + (l - 1);
     // primal: 1 sum + 5 max over Ar blocks
     launch_spmv(Ar.view(), x, EpiResPri{s, h.p + n, normalized ? Dinv.p : nullptr, tau_ptr, y, part.p}, nullptr, stream);
-    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, Ar.nblk, 1, 5, out.p);
+    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, Ar.nwg(), 1, 5, out.p);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{px.p, 0}, nullptr, stream);
     launch_spmv(At.view(), y, EpiResDual{has_P ? px.p : nullptr, h.p, normalized ? Einv.p : nullptr, x, tau_ptr, part.p},
                 nullptr, stream);
-    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nblk, 2, 4, out.p + 8);
+    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), 2, 4, out.p + 8);
     HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(h_pin + 16, u.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(h_pin + 17, rsk.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -614,7 +642,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->solx.alloc_zero(n, s);
   w->soly.alloc_zero(m, s);
   w->sols.alloc_zero(m, s);
-  w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->has_P ? w->Pf.nblk : 0, kMaxVecBlocks}) * 8;
+  w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->At.nwg(), w->Ar.nwg(), w->has_P ? std::max(w->Pf.nblk, w->Pf.nwg()) : 0, kMaxVecBlocks}) * 8;
   w->part_len = std::max(w->part_len, 3 * kAaMaxMem * kMaxVecBlocks);
   w->part.alloc_zero(w->part_len, s);
   w->sc.alloc_zero(S_COUNT, s);
@@ -969,6 +997,35 @@ int scs_hip_set_device(int dev) {
 }
 const char *scs_hip_last_error(void) { return g_last_error.c_str(); }
 
+/* reps back-to-back launches of K1 and of K2 on the solver's own stream and resident data, one HIP event
+ * pair around each batch (event overhead amortised); out = {K1 avg ms, K2 avg ms} */
+int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
+  if (!w || !out || reps <= 0) return -1;
+  try {
+    std::lock_guard<std::mutex> lock(w->mtx);
+    HIP_CHECK(hipSetDevice(g_device));
+    hipStream_t s = w->stream;
+    const int n = w->n;
+    for (int i = 0; i < 2; ++i) w->matvec(w->cg_p.p, nullptr);
+    HIP_CHECK(hipEventRecord(w->ev[0], s));
+    for (int i = 0; i < reps; ++i) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->diag_r.p + n}, nullptr, s);
+    HIP_CHECK(hipEventRecord(w->ev[1], s));
+    for (int i = 0; i < reps; ++i)
+      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->diag_r.p, 0, w->part.p}, nullptr, s);
+    HIP_CHECK(hipEventRecord(w->ev[2], s));
+    HIP_CHECK(hipEventSynchronize(w->ev[2]));
+    float a = 0, b = 0;
+    HIP_CHECK(hipEventElapsedTime(&a, w->ev[0], w->ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&b, w->ev[1], w->ev[2]));
+    out[0] = a / reps;
+    out[1] = b / reps;
+    return 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
 void scs_hip_set_profiling(ScsWork *w, int on) {
   if (w) w->profile = on != 0;
 }
@@ -976,7 +1033,7 @@ void scs_hip_kernel_times(const ScsWork *w, double *out) {
   if (!w || !out) return;
   out[0] = w->prof_ms[0]; out[1] = (double)w->prof_n[0];
   out[2] = w->prof_ms[1]; out[3] = (double)w->prof_n[1];
-  out[4] = (double)w->At.nnz; out[5] = (double)w->Ar.nblk; out[6] = (double)w->At.nblk;
+  out[4] = (double)w->At.nnz; out[5] = (double)w->Ar.nwg(); out[6] = (double)w->At.nwg();
   out[7] = w->has_P ? (double)w->Pf.nnz : 0.0;
 }
 
@@ -1112,7 +1169,7 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
     w.diag_r.upload(dr.data(), w.l, s);
     for (DevBuf<double> *b : {&w.cg_b, &w.cg_p, &w.cg_r, &w.cg_Gp, &w.cg_M, &w.ws}) b->alloc_zero(n, s);
     w.tmp_m.alloc_zero(m, s);
-    w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, kMaxVecBlocks}) * 8, s);
+    w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, w.At.nwg(), w.Ar.nwg(), kMaxVecBlocks}) * 8, s);
     w.sc.alloc_zero(S_COUNT, s);
     w.fl.alloc_zero(F_COUNT, s);
     hipLaunchKernelGGL(k_precond, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w.At.rowptr.p, w.At.col.p, w.At.val.p,

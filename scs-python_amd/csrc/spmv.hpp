@@ -17,6 +17,8 @@
 // the column-ordered CPU scatter/gather of the oracle.
 // Algorithmic bytes per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows.
 #pragma once
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace scship {
@@ -189,10 +191,288 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const d
   }
 }
 
+// ---------------------------------------------------------------------------
+// L2-blocked "slab" variant for matrices whose gather vector does not fit in one
+// XCD's 4 MiB L2 (n ~ 1e6 => 8-16 MB of x).
+//
+// Measurements that shaped it (profiles/, devtools/gather_bench.hip): 2e7 random
+// 8-byte gathers cost 72 us from a 128 KB table, 87 us from 1 MB (L2 hits),
+// 177 us from 8 MB and 257 us from 16 MB (L2 misses served by the fabric, one
+// 128-byte line per gather) — the texture-address path, not HBM, bounds this
+// kernel: ~2 TA cycles per divergent lane, ~0.25 per coalesced lane.
+//
+// Design: column-block the matrix into S slabs of 2^kSlabShift columns (1 MiB of
+// x) and make every workgroup own a fixed chunk of R = 256*RPT rows for the whole
+// launch, walking the slabs in order s = 0..S-1.  The grid is sized to be fully
+// resident (<= 4 workgroups per CU), every workgroup has the same amount of work
+// per slab, so all of them advance through the slabs together and each XCD's L2
+// only has to hold the current slab (+ a neighbour).  Row accumulators stay in
+// REGISTERS across slabs — no partial-sum traffic.  Inside a (chunk, slab) segment:
+// each lane streams 4 consecutive nonzeros with 16-byte loads (segments are padded
+// to a multiple of 4), gathers x, stages the products in LDS, then sums the LDS
+// runs of its RPT rows.  Slabs are ascending column ranges, so every row is still
+// summed in ascending-column order: bit-identical to the CSR-stream kernel and to
+// the oracle.  Extra bytes vs CSR: 2 B * rows * S of uint16 row offsets.
+// ---------------------------------------------------------------------------
+constexpr int kSlabShiftDefault = 17;        // 2^17 columns = 1 MiB of fp64 per slab
+constexpr int kSlabStage = 3072;             // LDS products per pass (24 KiB)
+constexpr int kSlabTargetWgs = 512;          // 2 resident workgroups per CU on 256 CUs
+inline int slab_shift() {
+  const char *e = getenv("SCS_HIP_SLAB_SHIFT");  // experiments only
+  const int v = e ? atoi(e) : kSlabShiftDefault;
+  return (v >= 10 && v <= 24) ? v : kSlabShiftDefault;
+}
+
+struct SlabView {
+  const int *segptr;            // nchunks*S + 1 offsets into val/col (multiples of 4)
+  const unsigned short *roff;   // (nchunks*S) x (R+1) row offsets inside a segment
+  const int *col;
+  const double *val;
+  int rows, cols, nchunks, S, R, max_seg;
+};
+
+struct HostSlab {
+  std::vector<int> segptr, col;
+  std::vector<unsigned short> roff;
+  std::vector<double> val;
+  int rows = 0, cols = 0, nchunks = 0, S = 0, R = 0, max_seg = 0;
+};
+
+inline int slab_pick_rows(int rows) {
+  const char *e = getenv("SCS_HIP_SLAB_RPT");  // experiments only
+  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return 256 * v; }
+  int rpt = 1;
+  while (rpt < 16 && (long)kSlabTargetWgs * 256 * rpt < rows) rpt *= 2;
+  return 256 * rpt;
+}
+inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20) && rows >= 65536; }
+
+// CSR -> slab format; false when a (chunk, slab) segment would overflow the uint16 offsets
+inline bool build_slab(const int *rowptr, const int *col, const double *val, int rows, int cols, HostSlab &out) {
+  const int R = slab_pick_rows(rows);
+  const int shift = slab_shift();
+  const int S = (int)(((long)cols + (1L << shift) - 1) >> shift);
+  const int nchunks = (rows + R - 1) / R;
+  const long nnz = rowptr[rows];
+  out.rows = rows; out.cols = cols; out.R = R; out.S = S; out.nchunks = nchunks; out.max_seg = 0;
+  out.segptr.assign((size_t)nchunks * S + 1, 0);
+  out.roff.assign((size_t)nchunks * S * (R + 1), 0);
+  out.col.clear(); out.val.clear();
+  out.col.reserve(nnz + 4L * nchunks * S);
+  out.val.reserve(nnz + 4L * nchunks * S);
+  std::vector<int> cursor(R);
+  long copied = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int r0 = c * R, r1 = std::min(rows, r0 + R);
+    for (int r = r0; r < r1; ++r) cursor[r - r0] = rowptr[r];
+    for (int s = 0; s < S; ++s) {
+      const size_t seg = (size_t)c * S + s;
+      const long seg0 = (long)out.col.size();
+      if (seg0 > 2000000000L) return false;
+      out.segptr[seg] = (int)seg0;
+      unsigned short *ro = &out.roff[seg * (R + 1)];
+      const long chi = (long)(s + 1) << shift;  // first column beyond this slab
+      for (int r = r0; r < r1; ++r) {
+        const long off = (long)out.col.size() - seg0;
+        if (off > 65535) return false;
+        ro[r - r0] = (unsigned short)off;
+        int p = cursor[r - r0];
+        const int pe = rowptr[r + 1];
+        while (p < pe && col[p] < chi) {
+          out.col.push_back(col[p]);
+          out.val.push_back(val[p]);
+          ++p; ++copied;
+        }
+        cursor[r - r0] = p;
+      }
+      const long endoff = (long)out.col.size() - seg0;
+      if (endoff > 65535) return false;
+      for (int r = r1; r <= r0 + R; ++r) ro[r - r0] = (unsigned short)endoff;
+      // pad to a multiple of 4 with zero-valued entries inside the slab (never summed: beyond every row's run)
+      const int padcol = (int)std::min<long>((long)s << shift, (long)cols - 1);
+      while (out.col.size() % 4 != 0) { out.col.push_back(padcol); out.val.push_back(0.0); }
+      out.max_seg = std::max(out.max_seg, (int)((long)out.col.size() - seg0));
+    }
+  }
+  out.segptr[(size_t)nchunks * S] = (int)out.col.size();
+  return copied == nnz;
+}
+
+// register image of one pass: NQ quads (4 nonzeros each) per lane
+template <int NQ>
+struct SlabRegs {
+  int4 cc[NQ];
+  double2 va[NQ], vb[NQ];
+};
+
+template <int NQ>
+__device__ __forceinline__ void slab_load(SlabRegs<NQ> &r, const int4 *__restrict__ c4, const double2 *__restrict__ v2,
+                                          int cnt4, int tid) {
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * kSpmvThreads;
+    if (q < cnt4) {
+      r.cc[i] = c4[q];
+      r.va[i] = v2[2 * q];
+      r.vb[i] = v2[2 * q + 1];
+    }
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void slab_gather(SlabRegs<NQ> &r, const double *__restrict__ x, int cnt4, int tid) {
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * kSpmvThreads;
+    if (q < cnt4) {
+      r.va[i].x *= x[r.cc[i].x];
+      r.va[i].y *= x[r.cc[i].y];
+      r.vb[i].x *= x[r.cc[i].z];
+      r.vb[i].y *= x[r.cc[i].w];
+    }
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void slab_stage(const SlabRegs<NQ> &r, double *prod, int cnt4, int tid) {
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * kSpmvThreads;
+    if (q < cnt4) {
+      reinterpret_cast<double2 *>(prod)[2 * q] = r.va[i];
+      reinterpret_cast<double2 *>(prod)[2 * q + 1] = r.vb[i];
+    }
+  }
+}
+
+template <class Epi, int RPT, int STAGE>
+__global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const double *__restrict__ x, Epi epi,
+                                                             const int *done_flag) {
+  if (done_flag && *done_flag) return;
+  constexpr int R = kSpmvThreads * RPT;
+  constexpr int NQ = STAGE / 4 / kSpmvThreads;
+  __shared__ __attribute__((aligned(16))) double prod[STAGE];
+  __shared__ double red[kSpmvThreads / 64];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM], acc[RPT];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sums[i] = 0.;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) maxs[i] = 0.;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) acc[j] = 0.;
+
+  if (A.max_seg <= STAGE) {
+    // ---- fast path: every segment fits one LDS pass; software-pipelined over the slabs:
+    // the 16-byte val/col loads (HBM latency) and the row offsets of slab s+1 are issued right
+    // after the gathers of slab s, so the texture-address path never waits on HBM.
+    const size_t seg0 = (size_t)c * A.S;
+    SlabRegs<NQ> cur, nxt;
+    int o_cur[RPT + 1], o_nxt[RPT + 1];
+    int p0 = A.segptr[seg0], p1 = A.segptr[seg0 + 1];
+    int cnt4 = (p1 - p0) >> 2;
+    slab_load<NQ>(cur, reinterpret_cast<const int4 *>(A.col + p0), reinterpret_cast<const double2 *>(A.val + p0), cnt4, tid);
+    {
+      const unsigned short *ro = A.roff + seg0 * (R + 1) + tid * RPT;
+#pragma unroll
+      for (int j = 0; j <= RPT; ++j) o_cur[j] = ro[j];
+    }
+    for (int s = 0; s < A.S; ++s) {
+      slab_gather<NQ>(cur, x, cnt4, tid);
+      int cnt4_n = 0;
+      if (s + 1 < A.S) {
+        const int q0 = p1, q1 = A.segptr[seg0 + s + 2];
+        cnt4_n = (q1 - q0) >> 2;
+        slab_load<NQ>(nxt, reinterpret_cast<const int4 *>(A.col + q0), reinterpret_cast<const double2 *>(A.val + q0), cnt4_n, tid);
+        const unsigned short *ro = A.roff + (seg0 + s + 1) * (R + 1) + tid * RPT;
+#pragma unroll
+        for (int j = 0; j <= RPT; ++j) o_nxt[j] = ro[j];
+        p1 = q1;
+      }
+      slab_stage<NQ>(cur, prod, cnt4, tid);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        double t = acc[j];
+        for (int k = o_cur[j]; k < o_cur[j + 1]; ++k) t += prod[k];
+        acc[j] = t;
+      }
+      __syncthreads();
+      cur = nxt;
+      cnt4 = cnt4_n;
+#pragma unroll
+      for (int j = 0; j <= RPT; ++j) o_cur[j] = o_nxt[j];
+    }
+  } else {
+    // ---- general path: a segment may need several LDS passes
+    for (int s = 0; s < A.S; ++s) {
+      const size_t seg = (size_t)c * A.S + s;
+      const int p0 = A.segptr[seg], n_seg = A.segptr[seg + 1] - p0;  // both multiples of 4
+      const unsigned short *ro = A.roff + seg * (R + 1) + tid * RPT;
+      int o[RPT + 1];
+#pragma unroll
+      for (int j = 0; j <= RPT; ++j) o[j] = ro[j];
+      for (int base = 0; base < n_seg; base += STAGE) {
+        const int cnt4 = min(STAGE, n_seg - base) >> 2;
+        SlabRegs<NQ> cur;
+        slab_load<NQ>(cur, reinterpret_cast<const int4 *>(A.col + p0 + base),
+                      reinterpret_cast<const double2 *>(A.val + p0 + base), cnt4, tid);
+        slab_gather<NQ>(cur, x, cnt4, tid);
+        slab_stage<NQ>(cur, prod, cnt4, tid);
+        __syncthreads();
+        const int cnt = cnt4 << 2;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+          const int a = max(o[j], base) - base, e = min(o[j + 1], base + cnt) - base;
+          double t = acc[j];
+          for (int k = a; k < e; ++k) t += prod[k];
+          acc[j] = t;
+        }
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = c * R + tid * RPT + j;
+    if (r < A.rows) epi(r, acc[j], sums, maxs);
+  }
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+#pragma unroll
+    for (int i = 0; i < Epi::kSums; ++i) {
+      const double t = block_sum<kSpmvThreads>(sums[i], red);
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + c] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < Epi::kMaxs; ++i) {
+      const double t = block_max<kSpmvThreads>(maxs[i], red);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + c] = t;
+    }
+  }
+}
+
+// One matrix, whichever layout init chose for it.  nblk = number of workgroups = number of
+// reduction partials an epilogue writes.
+struct SpmvMat {
+  CsrView csr{};
+  SlabView slab{};
+  bool use_slab = false;
+  int nblk() const { return use_slab ? slab.nchunks : csr.nblk; }
+};
+
 template <class Epi>
-inline void launch_spmv(const CsrView &A, const double *x, const Epi &epi, const int *done_flag, hipStream_t s) {
-  if (A.nblk <= 0) return;
-  hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(A.nblk), dim3(kSpmvThreads), 0, s, A, x, epi, done_flag);
+inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s) {
+  if (M.use_slab) {
+    if (M.slab.nchunks <= 0) return;
+    const dim3 g(M.slab.nchunks), b(kSpmvThreads);
+    if (M.slab.R == 256) hipLaunchKernelGGL((k_spmv_slab<Epi, 1, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    else if (M.slab.R == 512) hipLaunchKernelGGL((k_spmv_slab<Epi, 2, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    else if (M.slab.R == 1024) hipLaunchKernelGGL((k_spmv_slab<Epi, 4, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    else if (M.slab.R == 2048) hipLaunchKernelGGL((k_spmv_slab<Epi, 8, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    else hipLaunchKernelGGL((k_spmv_slab<Epi, 16, 2 * kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    return;
+  }
+  if (M.csr.nblk <= 0) return;
+  hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(M.csr.nblk), dim3(kSpmvThreads), 0, s, M.csr, x, epi, done_flag);
 }
 
 }  // namespace scship

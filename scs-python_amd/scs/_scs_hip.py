@@ -155,6 +155,8 @@ def _load():
     lib.scs_hip_set_profiling.argtypes = [C.c_void_p, c_int]
     lib.scs_hip_kernel_times.restype = None
     lib.scs_hip_kernel_times.argtypes = [C.c_void_p, _PD]
+    lib.scs_hip_time_matvec.restype = c_int
+    lib.scs_hip_time_matvec.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
     lib.scs_hip_copy_bandwidth.argtypes = [C.c_size_t, c_int]
     return lib
@@ -532,6 +534,14 @@ class SCS(object):
             _lib.scs_hip_kernel_times(self._work, _pd(out))
         return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
                 "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7])}
+
+    def _time_matvec(self, reps=20):
+        out = np.zeros(2)
+        with self._lock:
+            rc = _lib.scs_hip_time_matvec(self._work, int(reps), _pd(out))
+        if rc != 0:
+            raise RuntimeError("libscs_hip: " + last_error())
+        return {"k1_ms": float(out[0]), "k2_ms": float(out[1])}
 
     def __del__(self):
         lock = getattr(self, "_lock", None)

@@ -1,0 +1,86 @@
+"""Batch-of-problems sharding across GPUs.
+
+The reference has no parallelism strategy at all (none; the closest is "independent
+SCS instances may run concurrently", R:test/test_thread_safety.py:78-93).  A cone program does
+not shard internally without a per-CG-step all-reduce, but a BATCH of independent programs
+shards perfectly: problem i -> rank i mod world, no data-path collective, and ONE gather of the
+padded [header | x | y | s] blocks to rank 0 at the end (RCCL over xGMI when the process group
+is "nccl"; every rank sends one message straight to rank 0 — point-to-point links, no ring).
+
+    results = solve_sharded(problems)            # under torchrun, one rank per GPU
+    # rank 0: list of dicts (x, y, s, info-subset) in the original order; other ranks: None
+
+`solve_fn` is injectable so that the distributed logic is testable on CPU with gloo
+(tests/test_batch_gloo.py); the default is this package's HIP backend.
+"""
+import numpy as np
+
+_HDR = 8  # n, m, status_val, iter, pobj, dobj, solve_time_ms, cg_iters
+
+
+def shard_indices(n_items, rank, world):
+    """round-robin: problem i runs on rank i % world"""
+    return list(range(rank, n_items, world))
+
+
+def _default_solve(data, cone, settings):
+    import scs
+    return scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings).solve()
+
+
+def pack_result(sol, width):
+    x, y, s, info = sol["x"], sol["y"], sol["s"], sol["info"]
+    n, m = x.size, y.size
+    row = np.zeros(width, dtype=np.float64)
+    row[:_HDR] = (n, m, info["status_val"], info["iter"], info["pobj"], info["dobj"],
+                  info["solve_time"], info.get("cg_iters", 0))
+    row[_HDR:_HDR + n] = x
+    row[_HDR + n:_HDR + n + m] = y
+    row[_HDR + n + m:_HDR + n + 2 * m] = s
+    return row
+
+
+def unpack_result(row):
+    n, m = int(row[0]), int(row[1])
+    return {"x": row[_HDR:_HDR + n].copy(), "y": row[_HDR + n:_HDR + n + m].copy(),
+            "s": row[_HDR + n + m:_HDR + n + 2 * m].copy(),
+            "info": {"status_val": int(row[2]), "iter": int(row[3]), "pobj": float(row[4]),
+                     "dobj": float(row[5]), "solve_time": float(row[6]), "cg_iters": int(row[7])}}
+
+
+def solve_sharded(problems, solve_fn=None, dims=None, device=None):
+    """problems: list of (data, cone, settings) — every rank passes the same list (or at least the
+    same length and `dims` = [(n, m), ...]); only its own shard is touched.  Returns the ordered
+    result list on rank 0 and None elsewhere.  Works without torch.distributed (world = 1)."""
+    import torch
+    import torch.distributed as dist
+
+    solve_fn = solve_fn or _default_solve
+    use_dist = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if use_dist else 0
+    world = dist.get_world_size() if use_dist else 1
+    N = len(problems)
+    if dims is None:
+        dims = [(len(p[0]["c"]), len(p[0]["b"])) for p in problems]
+    width = _HDR + max(n + 2 * m for n, m in dims)
+    per_rank = (N + world - 1) // world
+    mine = shard_indices(N, rank, world)
+    block = np.zeros((per_rank, width), dtype=np.float64)
+    for slot, i in enumerate(mine):
+        data, cone, settings = problems[i]
+        block[slot] = pack_result(solve_fn(data, cone, settings), width)
+    if not use_dist:
+        return [unpack_result(block[slot]) for slot in range(len(mine))]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    payload = torch.from_numpy(block).to(device)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, bufs, dst=0)  # the single collective of the whole batch
+    if rank != 0:
+        return None
+    out = [None] * N
+    for r in range(world):
+        arr = bufs[r].cpu().numpy()
+        for slot, i in enumerate(shard_indices(N, r, world)):
+            out[i] = unpack_result(arr[slot])
+    return out

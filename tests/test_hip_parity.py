@@ -61,6 +61,22 @@ def test_spmv_bit_exact(hip, oracle, m, n, density, long_rows):
         np.testing.assert_allclose(got[~short], ref[~short], rtol=1e-12, atol=1e-12)
 
 
+def test_spmv_slab_layout_bit_exact(hip, oracle):
+    """large gather vector (> 2 MiB) + many rows => the L2-blocked slab kernel is selected; it must
+    reproduce the CSR-stream / oracle summation order bit for bit (incl. a dense-ish row and column)."""
+    rng = np.random.default_rng(17)
+    m, n = 70000, 300000
+    A = pg.random_sparse(m, n, 4, rng).tolil()
+    A[123, :5000] = rng.standard_normal(5000)      # long row: spans one slab densely
+    A = A.tocsc()
+    A.sort_indices()
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    np.testing.assert_array_equal(hip.spmv(A, x), oracle.spmv(A, x))          # CSR(A): rows=m, cols=n  -> slab
+    At = A.T.tocsc()
+    At.sort_indices()
+    np.testing.assert_array_equal(hip.spmv(At, x, transpose=True), oracle.spmv(At, x, trans=True))
+
+
 @pytest.mark.parametrize("case", helpers.load_projection_cases(), ids=lambda c: c[0])
 def test_cone_projection_vs_oracle_and_golden(hip, oracle, case):
     tag, K, z, gproj, gdual = case

@@ -142,9 +142,20 @@ def main():
     gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
     dom = ("K1 k_spmv_slab<EpiDivR> (z = R_y^-1 A p)", b1, k1_avg, gb1) if k1_avg >= k2_avg else \
           ("K2 k_spmv_slab<EpiGp> (Gp = A'z + R_x p)", b2, k2_avg, gb2)
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the
+    # committed rocprofv3 --pmc passes on the same matrix shape are used when the workload matches.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == args.workload:
+            kk = pmc["K1" if k1_avg >= k2_avg else "K2"]
+            traffic = int((2 * kk["FETCH_SIZE_KiB"] + kk["WRITE_SIZE_KiB"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(dom[3], 1), "peak": HBM_PEAK, "unit": "GB/s",
-        "frac": round(dom[3] / HBM_PEAK, 4), "traffic": None,
+        "frac": round(dom[3] / HBM_PEAK, 4), "traffic": traffic,
         "kernel": dom[0], "algorithmic_bytes_per_launch": int(dom[1]), "avg_launch_ms": round(dom[2], 5),
         "samples": kt["k1_n"],
         "k1": {"bytes": int(b1), "avg_ms": round(k1_avg, 5), "GBps": round(gb1, 1), "frac": round(gb1 / HBM_PEAK, 4),

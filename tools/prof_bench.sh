@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/prof_bench.sh <tag> [bench args...]   (GPU box, repo root)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+T=$1; shift
+O=gpurun_out/bench_$T
+mkdir -p $O
+rocprofv3 --kernel-trace --stats -d $O/trace -o run -- python3 bench.py --no-cpu-baseline "$@" > $O/bench_trace.log 2>&1
+tail -1 $O/bench_trace.log | cut -c1-400

@@ -1,33 +1,61 @@
-// psd.hpp — K9: batched projection onto the PSD cone.
+// psd.hpp — K9: batched projection onto the PSD cone on the fp64 matrix cores.
 //
 // Plays the role of the LAPACK syev* path of scs_source/src/cones.c under
 // USE_LAPACK (R:meson.build:145-147,188; absent).  Vector layout per cone:
 // lower triangle, column-major, off-diagonals scaled by sqrt(2)
 // (R:test/gen_random_cone_prob.py:153-173, R:test/test_scs_coverage.py:1387-1393).
-//
-// One workgroup per matrix (all matrices of the cone run concurrently, one CU
-// each).  Eigen-decomposition: two-sided cyclic Jacobi in the round-robin
-// (tournament) parallel ordering.  Each step applies n/2 disjoint rotations
-// J = prod_k J_k:  A <- J' A J is done in ONE pass by giving every (k,k') pair of
-// rotations its own 2x2 block of A (each element belongs to exactly one block, so
-// the update is in place), V <- V J column-wise.  Two barriers per step.
-// Reconstruction X+ = V diag(max(lambda,0)) V' is a dense contraction on the
-// fp64 matrix cores (v_mfma_f64_16x16x4_f64) over 16x16 output tiles.
 // The PSD cone is self-dual, so Pi_{K*} = Pi_K.
+//
+// One 1024-lane workgroup (16 wavefronts) per matrix; all matrices of the cone
+// run concurrently, one CU each.  Eigen-decomposition: two-sided BLOCK Jacobi,
+// block size 8, blocks paired in the round-robin (tournament) parallel ordering.
+// One outer step with NB/2 disjoint block pairs (p,q):
+//   phase 1  each pair's 16x16 pivot [[App,Apq],[Aqp,Aqq]] is diagonalised by ONE wavefront
+//            (scalar parallel-order Jacobi held in LDS, 8 rotations per inner step, each
+//            (k,k') rotation pair owning one 2x2 block) -> 16x16 orthogonal W_k;
+//   phase 2  A <- W' A W and V <- V W as 16x16x16 products on v_mfma_f64_16x16x4_f64:
+//            every (k <= k') pair of block pairs owns the 16x16 block rows{p,q} x cols{p',q'},
+//            computes W_k' (B W_k') with 8 MFMAs and writes it and its mirror (A stays exactly
+//            symmetric, the update is in place); V row tiles likewise.
+// The C/D register layout of the f64 MFMA (row = (lane>>4) + 4*reg, col = lane&15) is exactly
+// its B-operand layout for k-step `reg`, so the intermediate product feeds the second MFMA
+// chain straight from registers.  A and V live in an L2-resident scratch; finally
+// X+ = (V sqrt(L+)) (V sqrt(L+))' over lower-triangular 16x16 tiles, again on MFMA.
 #pragma once
 #include "common.hpp"
+
+#ifndef PSD_INNER
+#define PSD_INNER 1
+#endif
 
 namespace scship {
 
 constexpr int kPsdThreads = 1024;
-constexpr int kPsdMaxSweeps = 40;
+constexpr int kPsdWaves = kPsdThreads / 64;
+constexpr int kPsdMaxSweeps = 30;
+constexpr int kPsdB = 8;  // block size; pivots are 2*kPsdB = 16 = one MFMA tile
+constexpr int kPsdWaveLds = 272 + 256 + 16;  // per wave: S / 16x17 transpose scratch, W, (c,s)
+constexpr int kPsdDepth = 4;  // block tasks whose global loads are in flight per wave
+constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
+constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int) + 256;
 
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (in doubles) of this matrix's scratch: A (npad*npad) then V (npad*npad) then lam (npad)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A (NP*NP), V (NP*NP), W (NB/2*256), lam (NP)
   int count;
 };
+
+__host__ __device__ inline long psd_np(long n) {  // padded order: even number of 8-blocks
+  long nb = (n + kPsdB - 1) / kPsdB;
+  nb = (nb + 1) & ~1L;
+  if (nb < 2) nb = 2;
+  return nb * kPsdB;
+}
+inline long psd_scratch_doubles(long n) {
+  const long np = psd_np(n);
+  return 2 * np * np + (np / 16) * 256 + np;
+}
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -38,38 +66,133 @@ __device__ __forceinline__ void rr_pair(int r, int k, int N, int &p, int &q) {
   if (p > q) { const int t = p; p = q; q = t; }
 }
 
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Jacobi rotation (c, s) annihilating a_pq.  The ANGLE may be approximate (hardware rcp / rsq / sqrt
+// estimates, ~1e-7 relative: the rotation then leaves 1e-7 |a_pq| behind, which the next sweep removes),
+// but (c, s) must be orthonormal to full precision: c = rsqrt(1 + t^2) is refined by two Newton steps.
+__device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
+  const double theta = (aqq - app) * 0.5 * __builtin_amdgcn_rcp(apq);
+  const double at = fabs(theta);
+  double t;
+  if (at > 1e150) {
+    t = 0.5 * __builtin_amdgcn_rcp(theta);
+  } else {
+    t = __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(theta * theta + 1.));
+    t = theta >= 0 ? t : -t;
+  }
+  const double z = t * t + 1.;
+  double y = __builtin_amdgcn_rsq(z);
+  y = y * (1.5 - 0.5 * z * y * y);
+  y = y * (1.5 - 0.5 * z * y * y);
+  c = y;
+  s = t * y;
+}
+
+// One wavefront improves the symmetric 16x16 pivot S (LDS, column-major) by up to kPsdInnerSweeps
+// cyclic Jacobi sweeps, W <- accumulated rotations (LDS).  cs: 16 doubles of wave-private LDS.
+// sch: the N=16 round-robin schedule, sch[2*(8*r + k)] = p, +1 = q (built once per kernel).
+constexpr int kPsdInnerSweeps = PSD_INNER;
+__device__ inline void wave_jacobi16(double *S, double *W, double *cs, const unsigned char *sch, int lane) {
+  for (int e = lane; e < 256; e += 64) W[e] = ((e & 15) == (e >> 4)) ? 1. : 0.;
+  wave_sync();
+  for (int sweep = 0; sweep < kPsdInnerSweeps; ++sweep) {
+    double off = 0., tot = 0.;
+    for (int e = lane; e < 256; e += 64) {
+      const double a = S[e];
+      tot += a * a;
+      if ((e & 15) != (e >> 4)) off += a * a;
+    }
+    off = wave_sum(off);
+    tot = wave_sum(tot);
+    off = __shfl(off, 0, 64);
+    tot = __shfl(tot, 0, 64);
+    if (off <= 1e-26 * tot || off == 0.) break;  // (16 eps)^2 ~ 1e-29 is the rounding floor
+    for (int r = 0; r < 15; ++r) {
+      const unsigned char *sr = sch + 16 * r;
+      if (lane < 8) {
+        const int p = sr[2 * lane], q = sr[2 * lane + 1];
+        double c = 1., s = 0.;
+        const double apq = S[p + 16 * q];
+        if (fabs(apq) > 1e-300) jacobi_rot(S[p + 16 * p], S[q + 16 * q], apq, c, s);
+        cs[lane] = c;
+        cs[8 + lane] = s;
+      }
+      wave_sync();
+      {  // the 64 (k,k') rotation pairs: one 2x2 block per lane, blk <- J_k' blk J_k'
+        const int k = lane & 7, k2 = lane >> 3;
+        const int p = sr[2 * k], q = sr[2 * k + 1], p2 = sr[2 * k2], q2 = sr[2 * k2 + 1];
+        const double c = cs[k], s = cs[8 + k], c2 = cs[k2], s2 = cs[8 + k2];
+        const double app = S[p + 16 * p2], apq = S[p + 16 * q2], aqp = S[q + 16 * p2], aqq = S[q + 16 * q2];
+        const double t1 = c2 * app - s2 * apq, t2 = s2 * app + c2 * apq;
+        const double t3 = c2 * aqp - s2 * aqq, t4 = s2 * aqp + c2 * aqq;
+        S[p + 16 * p2] = c * t1 - s * t3;
+        S[p + 16 * q2] = c * t2 - s * t4;
+        S[q + 16 * p2] = s * t1 + c * t3;
+        S[q + 16 * q2] = s * t2 + c * t4;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // W <- W J : 8 pairs x 16 rows
+        const int e = lane + 64 * h, i = e & 15, k = e >> 4;
+        const int p = sr[2 * k], q = sr[2 * k + 1];
+        const double c = cs[k], s = cs[8 + k];
+        const double wp = W[i + 16 * p], wq = W[i + 16 * q];
+        W[i + 16 * p] = c * wp - s * wq;
+        W[i + 16 * q] = s * wp + c * wq;
+      }
+      wave_sync();
+    }
+  }
+}
+
+// index of local row/col i (0..15) of the pivot (p,q): block p for i<8, block q otherwise
+__device__ __forceinline__ int pq_index(int i, int p, int q) { return (i < 8 ? p * kPsdB : q * kPsdB - 8) + i; }
+
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *cs = reinterpret_cast<double *>(smem_raw);  // [N/2] cos
-  double *sn = cs + 512;                              // [N/2] sin
-  double *red = sn + 512;                             // [16]
-  double *bc = red + 16;                              // [2] broadcast
+  // LDS: per wave S/transpose scratch (272) + W (256) + cs (16) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
+  //      inner N=16 schedule (15*16 bytes)
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  double *red = lds + kPsdWaves * kPsdWaveLds;
+  double *bc = red + 16;
+  int *osch = reinterpret_cast<int *>(bc + 2);
+  unsigned char *isch = reinterpret_cast<unsigned char *>(osch + 2 * kPsdMaxH);
   const int cidx = blockIdx.x;
   const int n = B.order[cidx];
   double *X = x + B.off[cidx];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (n == 0) return;
   if (n == 1) {
     if (tid == 0) X[0] = fmax(X[0], 0.);
     return;
   }
-  const int N = (n + 1) & ~1;       // even number of players
-  const int ld = (n + 15) & ~15;    // padded leading dimension (MFMA tiles)
+  const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP;
   double *A = scratch + B.woff[cidx];
-  double *V = A + (size_t)ld * ld;
-  double *lam = V + (size_t)ld * ld;
+  double *V = A + (size_t)NP * NP;
+  double *Wg = V + (size_t)NP * NP;  // H pivots' rotation blocks, 256 doubles each (used when H > 16)
+  double *lam = Wg + (size_t)H * 256;
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
+  const bool w_in_lds = H <= kPsdWaves;  // pivot k is solved by wave k and its W stays in that wave's LDS
 
-  // ---- unpack (lower tri, col-major, off-diag / sqrt2), V = I, zero padding ----
-  for (int e = tid; e < ld * ld; e += kPsdThreads) {
-    const int i = e % ld, j = e / ld;
+  // ---- unpack (lower tri, col-major, off-diag / sqrt2), V = I, zero padding; inner schedule ----
+  for (int e = tid; e < NP * NP; e += kPsdThreads) {
+    const int i = e % NP, j = e / NP;
     A[e] = 0.;
-    V[e] = (i == j && i < n) ? 1. : 0.;
+    V[e] = (i == j) ? 1. : 0.;
+  }
+  if (tid < 15 * 8) {
+    int p, q;
+    rr_pair(tid >> 3, tid & 7, 16, p, q);
+    isch[2 * tid] = (unsigned char)p;
+    isch[2 * tid + 1] = (unsigned char)q;
   }
   __syncthreads();
   for (int j = 0; j < n; ++j) {
-    // column j of the packed vector starts at j*n - j(j-1)/2
-    const long base = (long)j * n - (long)j * (j - 1) / 2;
+    const long base = (long)j * n - (long)j * (j - 1) / 2;  // start of packed column j
     for (int i = j + tid; i < n; i += kPsdThreads) {
       double v = X[base + (i - j)];
       if (i != j) v *= isq2;
@@ -79,9 +202,11 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   }
   __syncthreads();
 
-  // ---- Jacobi sweeps ----
+  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + 272, *csw = Ww + 256;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nblk = H * (H + 1) / 2, ntile = NP / 16;
+
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
-    // convergence: off-diagonal mass vs total
     double off = 0., tot = 0.;
     for (int e = tid; e < n * n; e += kPsdThreads) {
       const int i = e % n, j = e / n;
@@ -91,95 +216,143 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     }
     off = block_sum<kPsdThreads>(off, red);
     tot = block_sum<kPsdThreads>(tot, red);
-    if (tid == 0) bc[0] = (off <= 1e-30 * tot || off == 0.) ? 1. : 0.;
+    // relative off-norm 1e-12; the rounding floor of the MFMA updates is ~(n eps)^2 = 2e-27 at n = 200
+    if (tid == 0) bc[0] = (off <= 1e-24 * tot || off == 0.) ? 1. : 0.;
     __syncthreads();
     const bool done = bc[0] != 0.;
     __syncthreads();
     if (done) break;
 
-    for (int r = 0; r < N - 1; ++r) {
-      // phase A: rotation angles of the N/2 disjoint pairs
-      for (int k = tid; k < N / 2; k += kPsdThreads) {
+    for (int r = 0; r < NB - 1; ++r) {
+      // outer schedule of this step -> LDS (block pairs p < q)
+      for (int k = tid; k < H; k += kPsdThreads) {
         int p, q;
-        rr_pair(r, k, N, p, q);
-        double c = 1., s = 0.;
-        if (q < n) {
-          const double apq = A[p + (size_t)ld * q];
-          if (fabs(apq) > 1e-300) {
-            const double theta = (A[q + (size_t)ld * q] - A[p + (size_t)ld * p]) / (2. * apq);
-            const double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-            c = 1. / sqrt(t * t + 1.);
-            s = t * c;
-          }
-        }
-        cs[k] = c;
-        sn[k] = s;
+        rr_pair(r, k, NB, p, q);
+        if (k < kPsdMaxH) { osch[2 * k] = p; osch[2 * k + 1] = q; }
       }
       __syncthreads();
-      // phase B: every (k,k') owns the 2x2 block rows {p,q} x cols {p',q'}:  blk <- J_k' blk J_k'
-      const int H = N / 2;
-      for (int e = tid; e < H * H; e += kPsdThreads) {
-        const int k = e % H, k2 = e / H;
-        int p, q, p2, q2;
-        rr_pair(r, k, N, p, q);
-        rr_pair(r, k2, N, p2, q2);
-        const double c = cs[k], s = sn[k], c2 = cs[k2], s2 = sn[k2];
-        const bool vq = q < n, vq2 = q2 < n;
-        double app = A[p + (size_t)ld * p2];
-        double apq = vq2 ? A[p + (size_t)ld * q2] : 0.;
-        double aqp = vq ? A[q + (size_t)ld * p2] : 0.;
-        double aqq = (vq && vq2) ? A[q + (size_t)ld * q2] : 0.;
-        // columns: [a_p' a_q'] <- [c2 a_p' - s2 a_q', s2 a_p' + c2 a_q']
-        const double t1 = c2 * app - s2 * apq, t2 = s2 * app + c2 * apq;
-        const double t3 = c2 * aqp - s2 * aqq, t4 = s2 * aqp + c2 * aqq;
-        // rows: [r_p; r_q] <- [c r_p - s r_q; s r_p + c r_q]
-        A[p + (size_t)ld * p2] = c * t1 - s * t3;
-        if (vq2) A[p + (size_t)ld * q2] = c * t2 - s * t4;
-        if (vq) A[q + (size_t)ld * p2] = s * t1 + c * t3;
-        if (vq && vq2) A[q + (size_t)ld * q2] = s * t2 + c * t4;
+      // ---------------- phase 1: one wavefront per pivot ----------------
+      for (int k = wave; k < H; k += kPsdWaves) {
+        const int p = osch[2 * k], q = osch[2 * k + 1];
+        for (int e = lane; e < 256; e += 64) {
+          const int i = e & 15, j = e >> 4;
+          Sw[e] = A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)];
+        }
+        wave_sync();
+        wave_jacobi16(Sw, Ww, csw, isch, lane);
+        if (!w_in_lds)
+          for (int e = lane; e < 256; e += 64) Wg[(size_t)k * 256 + e] = Ww[e];
       }
-      // V <- V J (columns p,q of V), rows i coalesced
-      for (int e = tid; e < H * n; e += kPsdThreads) {
-        const int i = e % n, k = e / n;
-        int p, q;
-        rr_pair(r, k, N, p, q);
-        if (q >= n) continue;
-        const double c = cs[k], s = sn[k];
-        const double vp = V[i + (size_t)ld * p], vq = V[i + (size_t)ld * q];
-        V[i + (size_t)ld * p] = c * vp - s * vq;
-        V[i + (size_t)ld * q] = s * vp + c * vq;
+      __syncthreads();
+      // ---------------- phase 2a: A <- W' A W over blocks k <= k', 4 tasks in flight per wave ----------------
+      for (int base = wave; base < nblk; base += kPsdDepth * kPsdWaves) {
+        int tk[kPsdDepth], tk2[kPsdDepth];
+        double av[kPsdDepth][4];
+#pragma unroll
+        for (int j = 0; j < kPsdDepth; ++j) {
+          const int task = base + j * kPsdWaves;
+          tk[j] = -1;
+          if (task < nblk) {
+            int k = 0, rem = task;  // unrank task -> (k, k2), k <= k2
+            while (rem >= H - k) { rem -= H - k; ++k; }
+            tk[j] = k;
+            tk2[j] = k + rem;
+            const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * tk2[j]], q2 = osch[2 * tk2[j] + 1];
+            const int row = pq_index(li, p, q);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) av[j][kk] = A[row + (size_t)ld * pq_index(4 * kk + lk, p2, q2)];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kPsdDepth; ++j) {
+          if (tk[j] < 0) continue;
+          const int k = tk[j], k2 = tk2[j];
+          const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
+          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + 272 : Wg + (size_t)k * 256;
+          const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + 272 : Wg + (size_t)k2 * 256;
+          f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][kk], W2[(4 * kk + lk) + 16 * li], T, 0, 0, 0);
+          f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T  (B operand of k-step t is T[t])
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + 16 * li], T[t], Rr, 0, 0, 0);
+          // Stores.  Lane holds R[row = lk + 4t][col = li].  The mirror block (k2,k) = R' is written straight
+          // from this layout (li runs down a column: full 128-byte lines).  The direct block goes through a
+          // 16x17 LDS transpose in the wave's private scratch so that li runs down its columns as well.
+          const int gi = pq_index(li, p2, q2);
+          if (k != k2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) A[gi + (size_t)ld * pq_index(lk + 4 * t, p, q)] = Rr[t];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
+          wave_sync();
+          const int gr = pq_index(li, p, q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) A[gr + (size_t)ld * pq_index(lk + 4 * t, p2, q2)] = Sw[li + 17 * (lk + 4 * t)];
+          wave_sync();
+        }
+      }
+      // ---------------- phase 2b: V <- V W (16-row tiles x pivots), 4 tasks in flight per wave ----------------
+      for (int base = wave; base < H * ntile; base += kPsdDepth * kPsdWaves) {
+        int tk[kPsdDepth], trt[kPsdDepth];
+        double av[kPsdDepth][4];
+#pragma unroll
+        for (int j = 0; j < kPsdDepth; ++j) {
+          const int task = base + j * kPsdWaves;
+          tk[j] = -1;
+          if (task < H * ntile) {
+            tk[j] = task % H;
+            trt[j] = task / H;
+            const int p = osch[2 * tk[j]], q = osch[2 * tk[j] + 1];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) av[j][kk] = V[(trt[j] * 16 + li) + (size_t)ld * pq_index(4 * kk + lk, p, q)];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kPsdDepth; ++j) {
+          if (tk[j] < 0) continue;
+          const int k = tk[j];
+          const int p = osch[2 * k], q = osch[2 * k + 1];
+          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + 272 : Wg + (size_t)k * 256;
+          f64x4 T = {0., 0., 0., 0.};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + 16 * li], av[j][kk], T, 0, 0, 0);  // (V_blk W)'
+          // lane holds (V_blk W)[row = li][col = lk + 4t]: li runs down a column -> full-line stores
+#pragma unroll
+          for (int t = 0; t < 4; ++t) V[(trt[j] * 16 + li) + (size_t)ld * pq_index(lk + 4 * t, p, q)] = T[t];
+        }
       }
       __syncthreads();
     }
   }
 
-  // ---- scale eigenvector columns: W = V diag(sqrt(lambda+)) so X+ = W W' ----
-  for (int j = tid; j < ld; j += kPsdThreads) lam[j] = (j < n) ? fmax(A[j + (size_t)ld * j], 0.) : 0.;
+  // ---- scale eigenvector columns: Wc = V diag(sqrt(lambda+)) so X+ = Wc Wc' ----
+  for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? fmax(A[j + (size_t)ld * j], 0.) : 0.;
   __syncthreads();
-  for (int e = tid; e < ld * ld; e += kPsdThreads) {
-    const int j = e / ld;
+  for (int e = tid; e < NP * NP; e += kPsdThreads) {
+    const int j = e / NP;
     V[e] *= sqrt(lam[j]);
   }
   __syncthreads();
 
-  // ---- X+ = W W' on the fp64 matrix cores: one wave per 16x16 output tile ----
-  // v_mfma_f64_16x16x4_f64: A operand lane l holds A[i=l&15][k=l>>4], B operand holds B[k=l>>4][j=l&15];
-  // result reg t of lane l is C[row=(l>>4)+4t][col=l&15].
-  const int wave = tid >> 6, lane = tid & 63, nwaves = kPsdThreads / 64;
-  const int T = ld / 16;
-  for (int tile = wave; tile < T * T; tile += nwaves) {
-    const int ti = tile % T, tj = tile / T;
-    if (tj > ti) continue;  // lower triangle only
+  // ---- X+ = Wc Wc' : one wave per lower-triangular 16x16 output tile ----
+  const int Tn = NP / 16;
+  for (int tile = wave; tile < Tn * Tn; tile += kPsdWaves) {
+    const int ti = tile % Tn, tj = tile / Tn;
+    if (tj > ti) continue;
     f64x4 acc = {0., 0., 0., 0.};
-    const int li = lane & 15, lk = lane >> 4;
-    for (int k0 = 0; k0 < ld; k0 += 4) {
-      const double a = V[(ti * 16 + li) + (size_t)ld * (k0 + lk)];  // W[i][k]
-      const double b = V[(tj * 16 + li) + (size_t)ld * (k0 + lk)];  // W'[k][j] = W[j][k]
+    for (int k0 = 0; k0 < NP; k0 += 4) {
+      const double a = V[(ti * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc[i][k]
+      const double b = V[(tj * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc'[k][j] = Wc[j][k]
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int i = ti * 16 + (lane >> 4) + 4 * t, j = tj * 16 + (lane & 15);
+      const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
       if (i < n && j <= i) {
         const long base = (long)j * n - (long)j * (j - 1) / 2;
         X[base + (i - j)] = (i == j) ? acc[t] : acc[t] * sq2;

@@ -309,8 +309,7 @@ struct ScsHipWork {
     }
     if (n_psd > 0) {  // self-dual
       PsdBatch B{psd_off.p, psd_order.p, psd_woff.p, n_psd};
-      hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), (512 + 512 + 16 + 2) * sizeof(double), stream, y, B,
-                         psd_scratch.p);
+      hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), kPsdLdsBytes, stream, y, B, psd_scratch.p);
     }
     if (cone.ep > 0)  // K = K_exp: dual -> project onto K_exp^*
       hipLaunchKernelGGL(k_proj_exp, dim3(ceil_div(cone.ep, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_ep,
@@ -555,8 +554,7 @@ static void upload_cone_meta(ScsHipWork *w) {
     poff.push_back(o);
     pord.push_back(sdim);
     woff.push_back(wtot);
-    const long ld = (sdim + 15) & ~15;
-    wtot += 2 * ld * ld + ld;
+    wtot += psd_scratch_doubles(sdim);
     o += (int)sd_size(sdim);
   }
   w->n_psd = (int)poff.size();

@@ -1,0 +1,83 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the oracle would take
+hours here): adjointness and linearity of the SpMV pair, projection idempotence / Moreau identities,
+and an end-to-end solve of the metric workload (m=2e6, n=1e6, nnz~2e7) checked by its KKT certificate
+and by the optimum p* the instance was constructed with."""
+import numpy as np
+import pytest
+
+import problem_gen as pg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from scs import _scs_hip
+    assert _scs_hip.device_count() > 0
+    return _scs_hip
+
+
+@pytest.fixture(scope="module")
+def big(hip):
+    K, n, k, seed = pg.workload("target_lp_soc")
+    data, p_star, xys = pg.gen_feasible(K, n, k, seed, lambda z, K: hip.proj_cone(z, K, dual=True))
+    return K, data, p_star, xys
+
+
+def test_spmv_adjoint_and_linear_full_size(hip, big):
+    K, data, _, _ = big
+    A = data["A"]
+    m, n = A.shape
+    rng = np.random.default_rng(0)
+    x1, x2, y = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(m)
+    Ax1, Ax2 = hip.spmv(A, x1), hip.spmv(A, x2)
+    Aty = hip.spmv(A, y, transpose=True)
+    # <A x, y> = <x, A' y>
+    lhs, rhs = Ax1 @ y, x1 @ Aty
+    assert abs(lhs - rhs) <= 1e-10 * (np.linalg.norm(Ax1) * np.linalg.norm(y))
+    # linearity
+    np.testing.assert_allclose(hip.spmv(A, 2.0 * x1 - 3.0 * x2), 2.0 * Ax1 - 3.0 * Ax2, rtol=0, atol=1e-9 * np.abs(Ax1).max())
+    # against scipy on a sample of rows (different summation order => tolerance, not bits)
+    ref = A @ x1
+    np.testing.assert_allclose(Ax1, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    # run-to-run determinism
+    np.testing.assert_array_equal(hip.spmv(A, x1), Ax1)
+
+
+def test_projection_properties_full_size(hip):
+    rng = np.random.default_rng(1)
+    K = {"z": 100000, "l": 300000, "q": [20] * 5000, "ep": 50000, "ed": 50000,
+         "p": (rng.uniform(0.1, 0.9, 33333) * rng.choice([-1.0, 1.0], 33333)).tolist()}
+    m = pg.cone_dims(K)
+    z = rng.standard_normal(m)
+    p = hip.proj_cone(z, K)
+    d = hip.proj_cone(-z, K, dual=True)
+    # idempotence and Moreau: z = Pi_K(z) - Pi_K*(-z),  <Pi_K(z), Pi_K*(-z)> = 0
+    np.testing.assert_allclose(hip.proj_cone(p, K), p, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(p - d, z, rtol=0, atol=1e-7)
+    assert abs(p @ d) <= 1e-6 * max(1.0, np.linalg.norm(p) * np.linalg.norm(d))
+
+
+def test_metric_workload_solves_to_certificate(hip, big):
+    import scs
+    K, data, p_star, (x0, y0, s0) = big
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-5, eps_rel=1e-5, verbose=False).solve()
+    info = sol["info"]
+    assert info["status"] == "solved", info
+    A, b, c = data["A"], data["b"], data["c"]
+    x, y, s = sol["x"], sol["y"], sol["s"]
+    # certificate in original units, max norm, relative as SCS's own stopping rule
+    pri = np.abs(A @ x + s - b).max()
+    dua = np.abs(A.T @ y + c).max()
+    gap = abs(c @ x + b @ y)
+    assert pri <= 1e-5 + 1e-5 * max(np.abs(A @ x).max(), np.abs(s).max(), np.abs(b).max()) * 1.01
+    assert dua <= 1e-5 + 1e-5 * max(np.abs(A.T @ y).max(), np.abs(c).max()) * 1.01
+    assert gap <= 1e-5 + 1e-5 * max(abs(c @ x), abs(b @ y)) * 1.01
+    assert abs(info["pobj"] - p_star) <= 1e-4 * abs(p_star)
+    # cone membership: s in K, y in K* (self-dual cones here)
+    assert s[: K["l"]].min() >= -1e-9 and y[: K["l"]].min() >= -1e-9
+    q = 10
+    S = s[K["l"]:].reshape(-1, q)
+    Y = y[K["l"]:].reshape(-1, q)
+    assert (np.linalg.norm(S[:, 1:], axis=1) <= S[:, 0] + 1e-7).all()
+    assert (np.linalg.norm(Y[:, 1:], axis=1) <= Y[:, 0] + 1e-7).all()

@@ -205,17 +205,19 @@ def test_mixed_cones_generated_parity(hip, oracle, K, n, k, seed):
 
 
 def test_iteration_counts_track_oracle_cg(hip, oracle):
-    """Same algorithm => with Anderson acceleration off (AA trajectories amplify rounding
-    differences) the ADMM iteration count follows the oracle's CPU-CG variant closely."""
+    """Same algorithm => the ADMM iteration count follows the oracle's CPU-CG variant closely once the
+    two chaotic amplifiers are off: Anderson acceleration and the adaptive-scale branch (a scale update
+    fires when a running geometric mean crosses sqrt(10); a 1e-13 difference in a projection can flip
+    that decision and send the two runs down different, equally valid, paths)."""
     data, K, _ = helpers.load_problem("problems_std.npz", "std_feas_")
     args = helpers.raw_args(data, K)
-    stg = dict(STG, acceleration_lookback=0)
+    stg = dict(STG, acceleration_lookback=0, adaptive_scale=False, eps_abs=1e-6, eps_rel=1e-6)
     got = hip.SCS(*args, **stg).solve(False, None, None, None)
     ref = oracle.OracleSCS(*args, indirect=True, **stg).solve(False)
     assert got["info"]["status"] == ref["info"]["status"] == "solved"
     gi, ri = got["info"], ref["info"]
-    assert abs(gi["iter"] - ri["iter"]) <= 0.15 * ri["iter"] + 25, (gi["iter"], ri["iter"])
-    assert abs(gi["cg_iters"] - ri["cg_iters"]) <= 0.25 * ri["cg_iters"] + 50, (gi["cg_iters"], ri["cg_iters"])
+    assert abs(gi["iter"] - ri["iter"]) <= 0.05 * ri["iter"] + 25, (gi["iter"], ri["iter"])
+    assert abs(gi["cg_iters"] - ri["cg_iters"]) <= 0.05 * ri["cg_iters"] + 50, (gi["cg_iters"], ri["cg_iters"])
 
 
 def test_qp_with_P_parity(hip, oracle):

@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--workload", default="target_lp_soc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
+    # testing aids (the driver never passes these): run the N>1 flow on a 1-GPU box
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--force-device", type=int, default=None)
     return ap.parse_args()
 
 
@@ -62,10 +65,15 @@ def main():
 
     if _scs_hip.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device; the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    _scs_hip.set_device(local_rank)
+    dev = local_rank if args.force_device is None else args.force_device
+    torch.cuda.set_device(dev)
+    _scs_hip.set_device(dev)
+    coll_dev = torch.device("cuda", dev) if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     def barrier():
         if world > 1:
@@ -102,8 +110,8 @@ def main():
     kt = solver._solver._kernel_times()          # in-situ samples (one CG step per host sync)
     kb = solver._solver._time_matvec(reps=30)    # back-to-back batch, event overhead amortised
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    its = torch.tensor([float(info["iter"])], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    its = torch.tensor([float(info["iter"])], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(its, op=dist.ReduceOp.SUM)
@@ -113,7 +121,7 @@ def main():
     # ---------------- single RCCL gather of the solutions (outside the timed region) ----------------
     gather_ms = None
     if world > 1:
-        payload = torch.from_numpy(np.concatenate([sol["x"], sol["y"], sol["s"]])).cuda()
+        payload = torch.from_numpy(np.concatenate([sol["x"], sol["y"], sol["s"]])).to(coll_dev)
         bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         tg = time.perf_counter()

@@ -15,6 +15,7 @@
 //   rsk = R (v + u - 2 u_t)   (only when residuals are needed)
 //   v  += alpha (u - u_t)
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <mutex>
 
@@ -116,6 +117,16 @@ struct ScsHipWork {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   double *h_pin = nullptr;  // pinned scalars
   int *h_flags = nullptr;   // pinned flags
+  double *h_params = nullptr, *d_params = nullptr;  // mapped pinned per-iteration scalars (P_*)
+
+  // hipGraphs of the launch-bound inner loop (built lazily at the first solve):
+  //   g_pre[i] : iterate normalisation, rhs, CG start + kGraphSteps[i] CG steps + flag read-back
+  //   g_cg[i]  : kGraphSteps[i] further CG steps + flag read-back
+  //   g_post   : y recovery, tau, cone projections, dual update (iterations without a convergence check)
+  static constexpr int kNumGraphs = 5;
+  const int kGraphSteps[kNumGraphs] = {1, 2, 4, 8, 16};
+  hipGraphExec_t g_pre[kNumGraphs] = {}, g_cg[kNumGraphs] = {}, g_post = nullptr;
+  bool graphs_ready = false, graphs_enabled = true;
 
   DeviceCsr At;  // CSR(A') == caller's CSC(A): rows n, cols m   (x-space outputs)
   DeviceCsr Ar;  // CSR(A): rows m, cols n                        (y-space outputs)
@@ -160,8 +171,12 @@ struct ScsHipWork {
   std::mutex mtx;
 
   ~ScsHipWork() {
+    for (auto &g : g_pre) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &g : g_cg) if (g) (void)hipGraphExecDestroy(g);
+    if (g_post) (void)hipGraphExecDestroy(g_post);
     if (h_pin) (void)hipHostFree(h_pin);
     if (h_flags) (void)hipHostFree(h_flags);
+    if (h_params) (void)hipHostFree(h_params);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
@@ -201,46 +216,89 @@ struct ScsHipWork {
     }
   }
 
-  // PCG on cg_b (rhs, length n); solution accumulates in xout.  S_TOL / F_DONE must be set on device.
-  // Returns CG iterations taken.
-  int run_cg(double *xout, const double *warm, int max_its) {
+  // ---- enqueue helpers (used both eagerly and under stream capture) ----
+  void enqueue_cg_start(double *xout, const double *warm) {
     const int nb = vb(n);
     if (warm) matvec(warm, nullptr);
     hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(kVecThreads), 0, stream, cg_b.p, cg_Gp.p, warm, cg_M.p, xout, cg_r.p, cg_p.p,
                        n, warm ? 1 : 0, fl.p, part.p);
     hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
+  }
+  void enqueue_cg_step(double *xout) {
+    const int nb = vb(n);
+    matvec(cg_p.p, fl.p + F_DONE);
+    hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
+    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, sc.p,
+                       fl.p, part.p);
+    hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
+    hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+  }
+  void enqueue_flag_readback() {
+    HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
+  }
+  void sync_flags() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    process_pending_flags();
+  }
+
+  // PCG on cg_b (rhs, length n); solution accumulates in xout.  S_TOL / F_DONE must be set on device.
+  // Returns CG iterations taken.  `started` = the CG start (and `done_iters` steps) were already enqueued
+  // and synced by a captured graph.
+  // mode 0: enqueue the CG start here; 1: the start is already enqueued (not synced);
+  // 2: start + some steps were enqueued by a captured graph and the flags are synced.
+  int run_cg(double *xout, const double *warm, int max_its, int mode = 0) {
     int done_iters = 0;
-    int chunk = std::max(1, std::min(last_cg_iters + 1, 64));
+    const bool started = mode == 2;
+    if (mode == 0) {
+      enqueue_cg_start(xout, warm);
+    } else if (mode == 2) {
+      done_iters = h_flags[F_ITERS];
+      if (h_flags[F_DONE] || done_iters >= max_its) {
+        last_cg_iters = done_iters;
+        tot_cg_iters += done_iters;
+        return done_iters;
+      }
+    }
+    const bool use_graph = started && xout == ut.p;  // graphs are captured for the ADMM buffers only
+    int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 1, 64));
     while (true) {
       const int iters_before = done_iters;
-      const int sample_it = chunk / 2;  // a mid-chunk step: not the one right behind the host sync
-      for (int it = 0; it < chunk; ++it) {
-        if (profile && it == sample_it) {
-          HIP_CHECK(hipEventRecord(ev[0], stream));
-          launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream);
-          HIP_CHECK(hipEventRecord(ev[1], stream));
-          if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-          launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
-          HIP_CHECK(hipEventRecord(ev[2], stream));
-        } else {
-          matvec(cg_p.p, fl.p + F_DONE);
+      if (use_graph) {
+        int gi = 0;
+        while (gi + 1 < kNumGraphs && kGraphSteps[gi + 1] <= chunk) ++gi;
+        HIP_CHECK(hipGraphLaunch(g_cg[gi], stream));
+        sync_flags();
+      } else {
+        const int sample_it = chunk / 2;  // a mid-chunk step: not the one right behind the host sync
+        for (int it = 0; it < chunk; ++it) {
+          if (profile && it == sample_it) {
+            HIP_CHECK(hipEventRecord(ev[0], stream));
+            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream);
+            HIP_CHECK(hipEventRecord(ev[1], stream));
+            if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
+            HIP_CHECK(hipEventRecord(ev[2], stream));
+            const int nb = vb(n);
+            hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
+            hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
+                               sc.p, fl.p, part.p);
+            hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
+            hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+          } else {
+            enqueue_cg_step(xout);
+          }
         }
-        hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
-        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, sc.p,
-                           fl.p, part.p);
-        hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
-        hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+        read_flags();
+        if (profile && h_flags[F_ITERS] - iters_before > sample_it) {  // the sampled step really ran
+          float a = 0, b = 0;
+          if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
+            prof_ms[0] += a; prof_n[0]++;
+            prof_ms[1] += b; prof_n[1]++;
+          }
+        }
       }
-      read_flags();
       done_iters = h_flags[F_ITERS];
-      if (profile && done_iters - iters_before > sample_it) {  // the sampled step really ran (not an early-exit launch)
-        float a = 0, b = 0;
-        if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
-          prof_ms[0] += a; prof_n[0]++;
-          prof_ms[1] += b; prof_n[1]++;
-        }
-      }
       if (h_flags[F_DONE] || done_iters >= max_its) break;
       chunk = std::max(2, std::min(std::max(done_iters / 2, 4), 64));
     }
@@ -254,7 +312,8 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_kkt_prep, dim3(vb(m)), dim3(kVecThreads), 0, stream, rhs, diag_r.p, tmp_m.p, n, m);
     launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, rhs}, nullptr, stream);
     HIP_CHECK(hipMemsetAsync(part.p, 0, sizeof(double), stream));
-    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, 1, 0.0, 1.0, tol, 0, sc.p, fl.p);
+    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, 1, 0.0, 1.0, tol, 0, (const double *)nullptr, sc.p,
+                       fl.p);
     const int its = run_cg(ws.p, nullptr, 10 * n);  // solution in ws
     launch_spmv(Ar.view(), ws.p, EpiStore{tmp_m.p, 0}, nullptr, stream);
     hipLaunchKernelGGL(k_kkt_y, dim3(vb(m)), dim3(kVecThreads), 0, stream, rhs, tmp_m.p, diag_r.p, n, m);
@@ -272,26 +331,90 @@ struct ScsHipWork {
   }
 
   // ------------------------------------------------------------ ADMM steps
-  void project_lin_sys(int iter) {
+  void set_iter_params(int iter) {
+    h_params[P_DO_SCALE] = iter >= 1 ? 1.0 : 0.0;
+    h_params[P_RES_MIN] = std::min(r.nm_pri_n, r.nm_dual_n);
+    h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
+    h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
+  }
+  // everything of project_lin_sys up to (and including) the CG start
+  void enqueue_lin_sys_head() {
     const int nbl = vb(l);
-    if (iter >= 1) {
-      hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
-      hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
-    }
+    hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
+    hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, tmp_m.p, ws.p, u.p, g.p, diag_r.p,
-                       n, m, iter >= 1 ? 1 : 0, sc.p, part.p);
-    const double res_min = std::min(r.nm_pri_n, r.nm_dual_n);
-    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, res_min, std::pow((double)iter + 1, 1.5),
-                       0.0, 1, sc.p, fl.p);
-    // rhs_x + A' R_y^{-1} rhs_y
-    launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, ut.p}, nullptr, stream);
-    run_cg(ut.p, ws.p, 10 * n);
-    // y = R_y^{-1}(A x - rhs_y) = (A x)/r_y + v_y
-    launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);
-    // tau
+                       n, m, d_params, sc.p, part.p);
+    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 0.0, 1.0, 0.0, 1, d_params, sc.p, fl.p);
+    launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, ut.p}, nullptr, stream);  // rhs_x + A' R_y^{-1} rhs_y
+    enqueue_cg_start(ut.p, ws.p);
+  }
+  // y recovery and tau
+  void enqueue_lin_sys_tail() {
+    launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);  // y = (A x)/r_y + v_y
     const int nb1 = vb(l - 1);
     hipLaunchKernelGGL(k_tau_dots, dim3(nb1), dim3(kVecThreads), 0, stream, ut.p, v.p, g.p, diag_r.p, l - 1, part.p);
-    hipLaunchKernelGGL(k_fin_tau, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb1, v.p, diag_r.p, l, iter < 1 ? 1 : 0, sc.p);
+    hipLaunchKernelGGL(k_fin_tau, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb1, v.p, diag_r.p, l, d_params, sc.p);
+  }
+  void enqueue_cones() {
+    hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
+                       d_params, sc.p);
+    project_nonlinear_cones(u.p + n, 1);
+  }
+  void enqueue_v_update() {
+    hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l);
+  }
+
+  hipGraphExec_t capture(const std::function<void()> &body) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      body();
+    } catch (...) {
+      (void)hipStreamEndCapture(stream, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(graph));
+    return exec;
+  }
+  void build_graphs() {
+    if (graphs_ready || !graphs_enabled) return;
+    for (int i = 0; i < kNumGraphs; ++i) {
+      const int c = kGraphSteps[i];
+      g_pre[i] = capture([&] {
+        enqueue_lin_sys_head();
+        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p);
+        enqueue_flag_readback();
+      });
+      g_cg[i] = capture([&] {
+        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p);
+        enqueue_flag_readback();
+      });
+    }
+    g_post = capture([&] {
+      enqueue_lin_sys_tail();
+      enqueue_cones();
+      enqueue_v_update();
+    });
+    graphs_ready = true;
+  }
+
+  void project_lin_sys(int iter, bool graph) {
+    set_iter_params(iter);
+    if (graph) {
+      int gi = 0;
+      const int want = std::max(1, std::min(last_cg_iters + 1, kGraphSteps[kNumGraphs - 1]));
+      while (gi + 1 < kNumGraphs && kGraphSteps[gi + 1] <= want) ++gi;
+      HIP_CHECK(hipGraphLaunch(g_pre[gi], stream));
+      sync_flags();
+      run_cg(ut.p, ws.p, 10 * n, 2);
+    } else {
+      enqueue_lin_sys_head();
+      run_cg(ut.p, ws.p, 10 * n, 1);  // the CG start is already enqueued: continue eagerly
+    }
   }
 
   // in-place projection of the m-slice y onto K (dual=0) or K* (dual=1), rows z/l excluded (handled by caller)
@@ -326,12 +449,6 @@ struct ScsHipWork {
         hipLaunchKernelGGL(k_proj_pow_primal, dim3(ceil_div(np, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_p,
                            pow_a.p, np);
     }
-  }
-
-  void project_cones(int iter) {
-    hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
-                       iter < 1 ? 1 : 0, sc.p);
-    project_nonlinear_cones(u.p + n, 1);
   }
 
   // --------------------------------------------------------------- residuals
@@ -602,6 +719,13 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   for (auto &e : w->ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc((void **)&w->h_pin, sizeof(double) * 256));
   HIP_CHECK(hipHostMalloc((void **)&w->h_flags, sizeof(int) * F_COUNT));
+  HIP_CHECK(hipHostMalloc((void **)&w->h_params, sizeof(double) * P_COUNT, hipHostMallocMapped));
+  HIP_CHECK(hipHostGetDevicePointer((void **)&w->d_params, w->h_params, 0));
+  std::memset(w->h_params, 0, sizeof(double) * P_COUNT);
+  {
+    const char *env = getenv("SCS_HIP_GRAPH");  // "0" keeps every launch eager (A/B measurements)
+    w->graphs_enabled = !(env && env[0] == '0');
+  }
   hipStream_t s = w->stream;
 
   // ---- copy + equilibrate on the host (one-off, O(nnz)) ----
@@ -756,37 +880,52 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
 
   int i;
   const int max_iters = w->stgs.max_iters;
+  // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
+  // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
+  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= 1000000;
+  bool use_graphs = graphs_wanted && w->graphs_ready;
   for (i = 0; i < max_iters; ++i) {
+    if (graphs_wanted && !use_graphs && i == 64) {
+      w->build_graphs();
+      use_graphs = w->graphs_ready;
+    }
     const bool aa_now = w->aa_mem > 0 && i > 0 && (i % w->stgs.acceleration_interval == 0);
     double t = now_ms();
     if (aa_now) {
       w->aa_apply();
       t_acc += now_ms() - t;
     }
-    t = now_ms();
-    w->project_lin_sys(i);  // ends with a stream sync inside run_cg (+ async tail)
-    t_lin += now_ms() - t;
-    t = now_ms();
-    w->project_cones(i);
     const bool check = (i % 25 == 0);
     const bool print_now = verbose && (i % 250 == 0);
     const bool last = (i == max_iters - 1);
-    if (check || print_now || last)
-      hipLaunchKernelGGL(k_rsk, dim3(w->vb(l)), dim3(kVecThreads), 0, s, w->rsk.p, w->v.p, w->u.p, w->ut.p, w->diag_r.p, l);
-    t_cone += now_ms() - t;
-    if (check) {
-      w->populate_residuals(i);
-      if ((info->status_val = w->has_converged(i)) != 0) break;
-      if (w->stgs.time_limit_secs > 0 && (now_ms() - t_start) > 1e3 * w->stgs.time_limit_secs) break;
+    const bool plain_iter = !(check || print_now || last);
+    t = now_ms();
+    w->project_lin_sys(i, use_graphs);  // ends with a stream sync (CG convergence flags)
+    t_lin += now_ms() - t;
+    t = now_ms();
+    if (use_graphs && plain_iter) {
+      HIP_CHECK(hipGraphLaunch(w->g_post, s));  // y, tau, cones, v += alpha (u - u_t)
+      t_cone += now_ms() - t;
+    } else {
+      w->enqueue_lin_sys_tail();
+      w->enqueue_cones();
+      if (!plain_iter)
+        hipLaunchKernelGGL(k_rsk, dim3(w->vb(l)), dim3(kVecThreads), 0, s, w->rsk.p, w->v.p, w->u.p, w->ut.p, w->diag_r.p, l);
+      t_cone += now_ms() - t;
+      if (check) {
+        w->populate_residuals(i);
+        if ((info->status_val = w->has_converged(i)) != 0) break;
+        if (w->stgs.time_limit_secs > 0 && (now_ms() - t_start) > 1e3 * w->stgs.time_limit_secs) break;
+      }
+      if (print_now) {
+        w->populate_residuals(i);
+        std::printf("%6d|%9.2e|%9.2e|%9.2e|%9.2e|%9.2e|%9.2e\n", i, w->r.res_pri, w->r.res_dual, w->r.gap,
+                    0.5 * (w->r.pobj + w->r.dobj), w->scale, (now_ms() - t_start) / 1e3);
+        std::fflush(stdout);
+      }
+      if (w->stgs.adaptive_scale && i == w->r.last_iter) w->update_scale(i);
+      w->enqueue_v_update();
     }
-    if (print_now) {
-      w->populate_residuals(i);
-      std::printf("%6d|%9.2e|%9.2e|%9.2e|%9.2e|%9.2e|%9.2e\n", i, w->r.res_pri, w->r.res_dual, w->r.gap,
-                  0.5 * (w->r.pobj + w->r.dobj), w->scale, (now_ms() - t_start) / 1e3);
-      std::fflush(stdout);
-    }
-    if (w->stgs.adaptive_scale && i == w->r.last_iter) w->update_scale(i);
-    hipLaunchKernelGGL(k_v_update, dim3(w->vb(l)), dim3(kVecThreads), 0, s, w->v.p, w->u.p, w->ut.p, w->stgs.alpha, l);
     if (aa_now) {
       t = now_ms();
       w->aa_safeguard();

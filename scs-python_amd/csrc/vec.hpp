@@ -26,6 +26,9 @@ enum : int {
   F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_COUNT = 32
 };
 
+// per-iteration host scalars, kept in mapped pinned memory so that captured hipGraphs stay static
+enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_COUNT = 8 };
+
 inline int vec_blocks(long n) {
   long nb = (n + 4L * kVecThreads - 1) / (4L * kVecThreads);
   if (nb < 1) nb = 1;
@@ -66,11 +69,11 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_vscale(const double *part, 
 // and the CG warm start ws = u_x + tau g_x; partial max |ws|.
 __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *tmp, double *ws,
                                                       const double *__restrict__ u, const double *__restrict__ g,
-                                                      const double *__restrict__ diag_r, int n, int m, int do_scale,
+                                                      const double *__restrict__ diag_r, int n, int m, const double *params,
                                                       const double *sc, double *part) {
   __shared__ double sm[kVecThreads / 64];
   const long l = (long)n + m + 1;
-  const double scale = do_scale ? sc[S_VSCALE] : 1.0;
+  const double scale = params[P_DO_SCALE] != 0. ? sc[S_VSCALE] : 1.0;
   const double tau = u[l - 1];
   double mx = 0., mr = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
@@ -100,8 +103,13 @@ __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev,
 // CG tolerance: tol = max(1e-12, 0.2 * min(res_min, ||ws||_inf / (k+1)^1.5))
 // A right-hand side with ||rhs||_inf <= 1e-12 short-circuits to the zero solution (F_ZERO_RHS).
 __global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int np, double res_min, double ipow,
-                                                         double fixed_tol, int have_rhs_norm, double *sc, int *fl) {
+                                                         double fixed_tol, int have_rhs_norm, const double *params,
+                                                         double *sc, int *fl) {
   __shared__ double sm[kVecThreads / 64];
+  if (params) {
+    res_min = params[P_RES_MIN];
+    ipow = params[P_IPOW];
+  }
   const double ws = part_max(part, np, sm);
   const double rn = have_rhs_norm ? part_max(part + np, np, sm) : 1.0;
   if (threadIdx.x == 0) {
@@ -259,7 +267,8 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_store_sum(const double *par
 
 // tau_tilde = positive root of the scalar quadratic
 __global__ __launch_bounds__(kVecThreads) void k_fin_tau(const double *part, int np, const double *v, const double *diag_r,
-                                                         long l, int first_iter, double *sc) {
+                                                         long l, const double *params, double *sc) {
+  const int first_iter = params[P_FIRST] != 0.;
   __shared__ double sm[kVecThreads / 64];
   const double pg = part_sum(part, np, sm);
   const double pp = part_sum(part + np, np, sm);
@@ -282,8 +291,9 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_tau(const double *part, int
 //   x rows: identity.  zero-cone rows: dual cone is free -> identity.  l rows: max(.,0).
 __global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
                                                           const double *__restrict__ g, int n, int m, int nz, int nl,
-                                                          int first_iter, const double *sc) {
+                                                          const double *params, const double *sc) {
   const long l = (long)n + m + 1;
+  const int first_iter = params[P_FIRST] != 0.;
   const double taut = sc[S_TAUT];
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
     if (i < l - 1) {

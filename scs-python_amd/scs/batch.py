@@ -48,10 +48,15 @@ def unpack_result(row):
                      "dobj": float(row[5]), "solve_time": float(row[6]), "cg_iters": int(row[7])}}
 
 
-def solve_sharded(problems, solve_fn=None, dims=None, device=None):
+def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
     """problems: list of (data, cone, settings) — every rank passes the same list (or at least the
     same length and `dims` = [(n, m), ...]); only its own shard is touched.  Returns the ordered
-    result list on rank 0 and None elsewhere.  Works without torch.distributed (world = 1)."""
+    result list on rank 0 and None elsewhere.  Works without torch.distributed (world = 1).
+
+    threads > 1 solves that many problems of the local shard concurrently: every SCS instance owns
+    its HIP stream and lock and the backend releases the GIL for the whole solve (the reference's
+    contract for independent instances, R:test/test_thread_safety.py:78-93), so small problems —
+    whose kernels cannot fill 256 CUs — overlap on the device: "one problem per stream"."""
     import torch
     import torch.distributed as dist
 
@@ -66,9 +71,16 @@ def solve_sharded(problems, solve_fn=None, dims=None, device=None):
     per_rank = (N + world - 1) // world
     mine = shard_indices(N, rank, world)
     block = np.zeros((per_rank, width), dtype=np.float64)
-    for slot, i in enumerate(mine):
-        data, cone, settings = problems[i]
-        block[slot] = pack_result(solve_fn(data, cone, settings), width)
+    if threads > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            futs = [pool.submit(solve_fn, *problems[i]) for i in mine]
+            for slot, f in enumerate(futs):
+                block[slot] = pack_result(f.result(), width)
+    else:
+        for slot, i in enumerate(mine):
+            data, cone, settings = problems[i]
+            block[slot] = pack_result(solve_fn(data, cone, settings), width)
     if not use_dist:
         return [unpack_result(block[slot]) for slot in range(len(mine))]
     if device is None:

@@ -1,0 +1,244 @@
+"""GPU tests written the way the reference's own tests are (they read like R:test/test_scs_basic.py,
+R:test/test_scs_coverage.py, R:test/test_scs_object.py, R:test/test_thread_safety.py), driving the
+public `scs` package with linear_solver=HIP_INDIRECT (and AUTO, which resolves to it)."""
+import threading
+
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal
+from scipy import sparse as sp
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scs():
+    import scs as _scs
+    assert _scs._scs_hip.device_count() > 0
+    return _scs
+
+
+SOLVERS = ["hip_indirect", "auto"]
+
+c = np.array([-1.0])
+b = np.array([1.0, 0.0])
+A = sp.csc_matrix([1.0, -1.0]).T.tocsc()
+data = {"A": A, "b": b, "c": c}
+
+
+@pytest.mark.parametrize("cone,expected", [({"q": [], "l": 2}, 1), ({"q": [2], "l": 0}, 0.5)])
+@pytest.mark.parametrize("ls", SOLVERS)
+def test_problems(scs, cone, ls, expected):
+    # R:test/test_scs_basic.py:57-72
+    sol = scs.SCS(data, cone=cone, linear_solver=ls, verbose=False).solve()
+    assert_almost_equal(sol["x"][0], expected, decimal=2)
+
+
+def test_failures(scs):
+    # R:test/test_scs_basic.py:95-114
+    with pytest.raises(TypeError):
+        scs.solve()
+    with pytest.raises(ValueError):
+        scs.solve(data, {"q": [4], "l": -2})
+    with pytest.raises(TypeError):
+        scs.solve(data, {"q": [], "l": 2}, max_iters=1.1)
+    with pytest.raises(ValueError):
+        scs.solve(data, {"q": [1], "l": 0}, verbose=False)
+
+
+def test_legacy_solve_with_warm_start_in_data(scs):
+    sol = scs.solve(dict(data), {"l": 2}, verbose=False)
+    d2 = dict(data, x=sol["x"], y=sol["y"], s=sol["s"])
+    sol2 = scs.solve(d2, {"l": 2}, verbose=False)
+    assert sol2["info"]["status"] == "solved" and sol2["info"]["iter"] <= sol["info"]["iter"]
+
+
+def test_qp_known_answer(scs):
+    # min 0.5 x^2 - x  st  0 <= x <= 0.5  -> x* = 0.5        (R:test/test_scs_coverage.py:761-779)
+    P = sp.csc_matrix([[1.0]])
+    d = {"P": P, "A": sp.csc_matrix([[1.0], [-1.0]]), "b": np.array([0.5, 0.0]), "c": np.array([-1.0])}
+    sol = scs.SCS(d, {"l": 2}, verbose=False).solve()
+    assert sol["info"]["status"] == "solved"
+    assert_almost_equal(sol["x"][0], 0.5, decimal=3)
+
+
+def test_full_P_is_reduced_to_upper_triangle(scs):
+    rng = np.random.RandomState(0)
+    n, m = 8, 12
+    B = rng.randn(n, n)
+    P = sp.csc_matrix(B @ B.T + np.eye(n))              # full symmetric
+    Am = sp.csc_matrix(rng.randn(m, n))
+    d_full = {"P": P, "A": Am, "b": rng.rand(m) + 1.0, "c": rng.randn(n)}
+    d_triu = dict(d_full, P=sp.triu(P, format="csc"))
+    kw = dict(verbose=False, eps_abs=1e-8, eps_rel=1e-8)
+    a = scs.SCS(d_full, {"l": m}, **kw).solve()
+    t = scs.SCS(d_triu, {"l": m}, **kw).solve()
+    np.testing.assert_array_equal(a["x"], t["x"])
+
+
+@pytest.mark.parametrize("cone,Adense,bvec,cvec,idx,expected", [
+    ({"z": 1}, [[1.0]], [0.7], [1.0], 0, 0.7),                                         # zero cone
+    ({"ep": 1}, [[0.0], [0.0], [-1.0]], [1.0, 1.0, 0.0], [1.0], 0, np.e),               # exp: t* = e
+    ({"p": [0.5]}, [[0.0], [0.0], [-1.0]], [1.0, 1.0, 0.0], [-1.0], 0, 1.0),             # power: z* = 1
+    ({"s": [2]}, [[0.0], [-np.sqrt(2.0)], [0.0]], [1.0, 0.0, 1.0], [1.0], 0, -1.0),      # SDP 2x2: x* = -1
+    ({"bu": [0.5], "bl": [-0.5]}, [[0.0], [1.0]], [1.0, 0.5], [-1.0], 0, 1.0),           # box: x* = 1
+    ({"bu": [0.35], "bl": [-0.35]}, [[0.0], [1.0]], [1.0, 0.65], [1.0], 0, 0.3),          # box: x* = 0.3
+])
+def test_closed_forms_per_cone(scs, cone, Adense, bvec, cvec, idx, expected):
+    # R:test/test_scs_coverage.py:563-632,805-820,912-1021,1380-1410
+    d = {"A": sp.csc_matrix(np.array(Adense)), "b": np.array(bvec), "c": np.array(cvec)}
+    sol = scs.SCS(d, cone, verbose=False, eps_abs=1e-7, eps_rel=1e-7).solve()
+    assert sol["info"]["status"] == "solved"
+    assert_almost_equal(sol["x"][idx], expected, decimal=4)
+
+
+def test_statuses_infeasible_and_unbounded(scs):
+    # R:test/test_scs_coverage.py:862-904
+    # x >= 1 and x <= 0
+    d = {"A": sp.csc_matrix([[-1.0], [1.0]]), "b": np.array([-1.0, 0.0]), "c": np.array([1.0])}
+    sol = scs.SCS(d, {"l": 2}, verbose=False).solve()
+    assert sol["info"]["status"] == "infeasible" and sol["info"]["status_val"] == scs.INFEASIBLE
+    assert np.isnan(sol["x"]).all()
+    # min -x st x >= 0
+    d = {"A": sp.csc_matrix([[-1.0]]), "b": np.array([0.0]), "c": np.array([-1.0])}
+    sol = scs.SCS(d, {"l": 1}, verbose=False).solve()
+    assert sol["info"]["status"] == "unbounded" and sol["info"]["status_val"] == scs.UNBOUNDED
+    assert np.isnan(sol["y"]).all()
+
+
+def test_info_dict_and_copies(scs):
+    # R:test/test_scs_coverage.py:328-365,1259-1285,2865-2877,2909-2917
+    solver = scs.SCS(data, {"l": 2}, verbose=False)
+    sol = solver.solve()
+    info = sol["info"]
+    for key in ("status", "status_val", "iter", "pobj", "dobj", "gap", "res_pri", "res_dual", "res_infeas",
+                "res_unbdd_a", "res_unbdd_p", "setup_time", "solve_time", "lin_sys_time", "cone_time", "accel_time",
+                "scale", "comp_slack", "accepted_accel_steps", "rejected_accel_steps", "aa_stats", "scale_updates"):
+        assert key in info, key
+    for key in ("iter", "n_accept", "n_reject_lapack", "n_reject_rank0", "n_reject_nonfinite", "n_reject_weight_cap",
+                "n_safeguard_reject", "last_rank", "last_aa_norm", "last_regularization"):
+        assert key in info["aa_stats"], key
+    assert isinstance(info["iter"], int) and isinstance(info["pobj"], float) and isinstance(info["status"], str)
+    assert info["status_val"] == scs.SOLVED
+    for k in ("setup_time", "solve_time", "lin_sys_time", "cone_time", "accel_time"):
+        assert info[k] >= 0.0
+    sol2 = solver.solve()
+    assert sol["x"] is not sol2["x"]
+    keep = sol["x"].copy()
+    sol2["x"][:] = 123.0
+    np.testing.assert_array_equal(sol["x"], keep)
+    assert sol["x"].flags.owndata and sol["x"].shape == (1,) and sol["y"].shape == (2,)
+
+
+def test_warm_start_validation_and_reuse(scs):
+    # R:test/test_scs_coverage.py:2576-2598, R:test/test_scs_object.py:68-110
+    dat, K, _ = helpers.load_problem("problems_rand.npz", "feas1_")
+    solver = scs.SCS(dat, K, verbose=False, eps_abs=1e-7, eps_rel=1e-7)
+    cold = solver.solve(warm_start=False)
+    warm = solver.solve()                       # previous solution is the warm start
+    assert warm["info"]["status"] == "solved" and warm["info"]["iter"] <= cold["info"]["iter"]
+    again = solver.solve(warm_start=True, x=cold["x"], y=cold["y"], s=cold["s"])
+    assert again["info"]["iter"] <= cold["info"]["iter"]
+    with pytest.raises(ValueError):
+        solver.solve(warm_start=True, x=np.zeros(3))
+    with pytest.raises(ValueError):
+        solver.solve(warm_start=True, y=np.zeros((len(dat["b"]), 1)))
+    with pytest.raises(TypeError):
+        solver.solve(warm_start=1)
+
+
+def test_update_b_c(scs):
+    # R:test/test_scs_object.py:68-88, R:test/test_scs_coverage.py:663-697,1141-1178,1543-1553
+    dat, K, _ = helpers.load_problem("problems_rand.npz", "feas0_")
+    kw = dict(verbose=False, eps_abs=1e-7, eps_rel=1e-7)
+    solver = scs.SCS(dat, K, **kw)
+    solver.update(b=dat["b"] * 1.0)             # allowed before the first solve
+    solver.solve()
+    b2, c2 = dat["b"] * 1.02, dat["c"] * 0.97
+    solver.update(b=b2, c=c2)
+    upd = solver.solve()
+    fresh = scs.SCS(dict(dat, b=b2, c=c2), K, **kw).solve()
+    assert upd["info"]["status"] == fresh["info"]["status"] == "solved"
+    assert abs(upd["info"]["pobj"] - fresh["info"]["pobj"]) < 1e-5 * max(1, abs(fresh["info"]["pobj"]))
+    with pytest.raises(ValueError):
+        solver.update(b=np.zeros(3))
+    with pytest.raises(TypeError):
+        solver.update(c=[1.0, 2.0])
+    with pytest.raises(TypeError):
+        solver.update(b=np.arange(len(b2)))
+
+
+def test_aa_off_counters_zero_and_type2(scs):
+    # R:test/test_scs_coverage.py:1320-1330 and the README's type-II example (R:README.md:106-111)
+    dat, K, p_star = helpers.load_problem("problems_rand.npz", "feas0_")
+    info = scs.SCS(dat, K, acceleration_lookback=0, verbose=False).solve()["info"]
+    assert all(v == 0 for v in info["aa_stats"].values())
+    assert info["accepted_accel_steps"] == 0 and info["rejected_accel_steps"] == 0
+    sol = scs.SCS(dat, K, acceleration_type_1=False, acceleration_regularization=1e-12, verbose=False,
+                  eps_abs=1e-7, eps_rel=1e-7).solve()
+    assert sol["info"]["status"] == "solved" and abs(sol["info"]["pobj"] - p_star) < 1e-4
+    assert sol["info"]["aa_stats"]["iter"] > 0
+
+
+def test_normalize_and_max_iters_and_time_limit(scs):
+    dat, K, p_star = helpers.load_problem("problems_rand.npz", "feas2_")
+    a = scs.SCS(dat, K, normalize=False, verbose=False, eps_abs=1e-7, eps_rel=1e-7).solve()
+    assert a["info"]["status"] == "solved" and abs(a["info"]["pobj"] - p_star) < 1e-4
+    few = scs.SCS(dat, K, max_iters=7, verbose=False).solve()
+    assert few["info"]["iter"] == 7 and "inaccurate" in few["info"]["status"]
+    tl = scs.SCS(dat, K, time_limit_secs=1e-4, eps_abs=1e-12, eps_rel=1e-12, verbose=False).solve()
+    assert tl["info"]["iter"] < 10000
+
+
+def test_verbose_false_prints_nothing(scs, capfd):
+    # R:test/test_scs_coverage.py:2925-2929
+    scs.SCS(data, {"l": 2}, verbose=False).solve()
+    out = capfd.readouterr()
+    assert out.out == "" and out.err == ""
+    scs.SCS(data, {"l": 2}, verbose=True).solve()
+    assert "status" in capfd.readouterr().out
+
+
+def test_independent_instances_run_concurrently(scs):
+    # R:test/test_thread_safety.py:78-93 — one stream + lock per instance, GIL released in solve
+    dat, K, p_star = helpers.load_problem("problems_std.npz", "std_feas_")
+    ref = scs.SCS(dat, K, verbose=False).solve()
+    results, errors = [None] * 6, []
+
+    def work(i):
+        try:
+            results[i] = scs.SCS(dat, K, verbose=False).solve()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors
+    for r in results:
+        np.testing.assert_array_equal(r["x"], ref["x"])   # deterministic, also under concurrency
+
+
+def test_shared_instance_is_serialised_by_its_lock(scs):
+    # R:test/test_free_threading.py (shared-instance concurrent solve/update must not corrupt state)
+    dat, K, _ = helpers.load_problem("problems_rand.npz", "feas0_")
+    solver = scs.SCS(dat, K, verbose=False)
+    base = solver.solve(warm_start=False)
+    outs, errors = [], []
+
+    def work():
+        try:
+            outs.append(solver.solve(warm_start=False))
+            solver.update(b=dat["b"])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors and len(outs) == 4
+    for o in outs:  # (the adaptive scale persists between solves, so later trajectories differ: compare optima)
+        assert o["info"]["status"] == "solved"
+        assert abs(o["info"]["pobj"] - base["info"]["pobj"]) < 1e-3 * max(1.0, abs(base["info"]["pobj"]))

@@ -222,17 +222,18 @@ struct ScsHipWork {
     if (warm) matvec(warm, nullptr);
     hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(kVecThreads), 0, stream, cg_b.p, cg_Gp.p, warm, cg_M.p, xout, cg_r.p, cg_p.p,
                        n, warm ? 1 : 0, fl.p, part.p);
-    hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
+    hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, 0, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
   }
-  void enqueue_cg_step(double *xout) {
-    const int nb = vb(n);
+  // yacc != nullptr: carry y += alpha R_y^{-1} A p along (ADMM path, see k_prep)
+  void enqueue_cg_step(double *xout, double *yacc) {
+    const int nb = vb(std::max(n, yacc ? m : 0));
     matvec(cg_p.p, fl.p + F_DONE);
     hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
-    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, sc.p,
-                       fl.p, part.p);
+    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, yacc,
+                       tmp_m.p, m, sc.p, fl.p, part.p);
     hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
-    hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+    hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
   }
   void enqueue_flag_readback() {
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
@@ -261,6 +262,7 @@ struct ScsHipWork {
       }
     }
     const bool use_graph = started && xout == ut.p;  // graphs are captured for the ADMM buffers only
+    double *yacc = (xout == ut.p) ? ut.p + n : nullptr;  // ADMM path carries the y block along the recurrence
     int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 1, 64));
     while (true) {
       const int iters_before = done_iters;
@@ -279,14 +281,14 @@ struct ScsHipWork {
             if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
             launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
             HIP_CHECK(hipEventRecord(ev[2], stream));
-            const int nb = vb(n);
+            const int nb = vb(std::max(n, yacc ? m : 0));
             hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
-                               sc.p, fl.p, part.p);
+                               yacc, tmp_m.p, m, sc.p, fl.p, part.p);
             hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
             hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
           } else {
-            enqueue_cg_step(xout);
+            enqueue_cg_step(xout, yacc);
           }
         }
         read_flags();
@@ -337,20 +339,26 @@ struct ScsHipWork {
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
   }
-  // everything of project_lin_sys up to (and including) the CG start
+  // everything of project_lin_sys up to (and including) the fused, warm-started CG start
   void enqueue_lin_sys_head() {
     const int nbl = vb(l);
     hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
     hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
-    hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, tmp_m.p, ws.p, u.p, g.p, diag_r.p,
-                       n, m, d_params, sc.p, part.p);
+    hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
+                       d_params, sc.p, part.p);
     hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 0.0, 1.0, 0.0, 1, d_params, sc.p, fl.p);
-    launch_spmv(At.view(), tmp_m.p, EpiRhs{cg_b.p, ut.p}, nullptr, stream);  // rhs_x + A' R_y^{-1} rhs_y
-    enqueue_cg_start(ut.p, ws.p);
+    // y0 = v_y + R_y^{-1} A ws   (start of the y recurrence, lives in ut_y)
+    launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);
+    // r0 = R_x (v_x - ws) - P ws - A' y0 ; p0 = M r0 ; partials for ||r0||_inf and r0'M r0
+    if (has_P) launch_spmv(Pf.view(), ws.p, EpiStore{cg_Gp.p, 0}, nullptr, stream);
+    launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, diag_r.p, v.p, ws.p, has_P ? cg_Gp.p : nullptr, part.p},
+                nullptr, stream);
+    hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), 1, sc.p, fl.p);
+    hipLaunchKernelGGL(k_zero_if_flag, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, ut.p, (long)n + m, fl.p);
+    HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
   }
-  // y recovery and tau
+  // tau (the y block is already in ut_y: it was carried along the CG recurrence)
   void enqueue_lin_sys_tail() {
-    launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);  // y = (A x)/r_y + v_y
     const int nb1 = vb(l - 1);
     hipLaunchKernelGGL(k_tau_dots, dim3(nb1), dim3(kVecThreads), 0, stream, ut.p, v.p, g.p, diag_r.p, l - 1, part.p);
     hipLaunchKernelGGL(k_fin_tau, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb1, v.p, diag_r.p, l, d_params, sc.p);
@@ -386,11 +394,11 @@ struct ScsHipWork {
       const int c = kGraphSteps[i];
       g_pre[i] = capture([&] {
         enqueue_lin_sys_head();
-        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p);
+        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p, ut.p + n);
         enqueue_flag_readback();
       });
       g_cg[i] = capture([&] {
-        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p);
+        for (int k = 0; k < c; ++k) enqueue_cg_step(ut.p, ut.p + n);
         enqueue_flag_readback();
       });
     }

@@ -86,6 +86,24 @@ struct EpiGp {  // Gp[r] = (Pp)[r] + s + rx[r] p[r];  partial sum of p.Gp   (CG 
   }
 };
 
+// warm-started CG start, fused:  r0 = R_x (v_x - ws) - (P ws) - s  with s = A'(v_y + R_y^{-1} A ws);
+// p0 = M r0; partials [sum r0 M r0 | max |r0|]
+struct EpiR0 {
+  double *r, *p;
+  const double *M, *rx, *vx, *ws, *Pws;  // Pws nullable
+  double *partial;
+  static constexpr int kSums = 1, kMaxs = 1;
+  __device__ void operator()(int j, double s, double *sums, double *maxs) const {
+    double r0 = rx[j] * (vx[j] - ws[j]) - s;
+    if (Pws) r0 -= Pws[j];
+    const double z = M[j] * r0;
+    r[j] = r0;
+    p[j] = z;
+    sums[0] += z * r0;
+    maxs[0] = fmax(maxs[0], abs_nan_inf(r0));
+  }
+};
+
 struct EpiRhs {  // b_x[r] = rx_part[r] + s          (rhs: r_x + A' R_y^{-1} r_y)
   double *out;
   const double *add;

@@ -64,10 +64,13 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_vscale(const double *part, 
   if (threadIdx.x == 0) sc[S_VSCALE] = sqrt(l) / fmax(sqrt(s), 1e-300);
 }
 
-// Start of project_lin_sys: normalise v, snapshot v_prev, build the KKT right-hand side
-//   rhs_x = R_x v_x   (into ut_x),   tmp = R_y^{-1} rhs_y = -v_y,
-// and the CG warm start ws = u_x + tau g_x; partial max |ws|.
-__global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *tmp, double *ws,
+// Start of project_lin_sys: normalise v, snapshot v_prev and form the CG warm start
+//   ws = u_x + tau g_x   (also copied into ut_x: the CG iterate x starts there).
+// The KKT right-hand side [R_x v_x; -R_y v_y] is never materialised: the warm-started CG only needs
+//   r0 = rhs_x + A' R_y^{-1} rhs_y - (R_x + P + A' R_y^{-1} A) ws = R_x (v_x - ws) - P ws - A' (v_y + R_y^{-1} A ws)
+// which costs ONE A product and ONE A' product (epilogues EpiY / EpiR0) instead of three.
+// Partials: [max |ws| , max |rhs|] (the latter for the zero-rhs short-circuit).
+__global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *ws,
                                                       const double *__restrict__ u, const double *__restrict__ g,
                                                       const double *__restrict__ diag_r, int n, int m, const double *params,
                                                       const double *sc, double *part) {
@@ -81,14 +84,12 @@ __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev,
     v[i] = vi;
     v_prev[i] = vi;
     if (i < n) {
-      const double rv = diag_r[i] * vi;
-      ut[i] = rv;
       const double w = u[i] + tau * g[i];
       ws[i] = w;
+      ut[i] = w;
       mx = fmax(mx, abs_nan_inf(w));
-      mr = fmax(mr, abs_nan_inf(rv));
+      mr = fmax(mr, abs_nan_inf(diag_r[i] * vi));
     } else if (i < l - 1) {
-      tmp[i - n] = -vi;
       mr = fmax(mr, abs_nan_inf(diag_r[i] * vi));
     }
   }
@@ -158,15 +159,22 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restric
   }
 }
 
-__global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part, int np, double *sc, int *fl) {
+// sum_first: partial layout [sum | max] (SpMV epilogue) instead of [max | sum] (k_cg_init)
+__global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part, int np, int sum_first, double *sc, int *fl) {
   __shared__ double sm[kVecThreads / 64];
-  const double rn = part_max(part, np, sm);
-  const double ztr = part_sum(part + np, np, sm);
+  const double rn = part_max(sum_first ? part + np : part, np, sm);
+  const double ztr = part_sum(sum_first ? part : part + np, np, sm);
   if (threadIdx.x == 0) {
     sc[S_RNORM] = rn;
     sc[S_ZTR] = ztr;
     if (rn < fmax(sc[S_TOL], 1e-12)) fl[F_DONE] = 1;
   }
+}
+
+// zero right-hand side => zero solution (both blocks)
+__global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n, const int *fl) {
+  if (!fl[F_ZERO_RHS]) return;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) x[i] = 0.;
 }
 
 // alpha = z'r / p'Gp
@@ -177,14 +185,20 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_alpha(const double *part, i
   if (threadIdx.x == 0) sc[S_ALPHA] = sc[S_ZTR] / pGp;
 }
 
-// x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r]
+// x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r].
+// With yacc != nullptr also y += alpha z (z = R_y^{-1} A p of this step): the y-block of the KKT solution
+// y = R_y^{-1}(A x - r_y) is carried along the CG recurrence instead of a final A x product.
 __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
                                                            const double *__restrict__ Gp, const double *__restrict__ M,
-                                                           int n, const double *sc, const int *fl, double *part) {
+                                                           int n, double *yacc, const double *__restrict__ z, int m,
+                                                           const double *sc, const int *fl, double *part) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
   const double alpha = sc[S_ALPHA];
   double mx = 0., s = 0.;
+  if (yacc)
+    for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
+      yacc[i] += alpha * z[i];
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * Gp[i];

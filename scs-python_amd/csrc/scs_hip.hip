@@ -93,11 +93,17 @@ struct Residuals {
   double bty_tau = 0, ctx_tau = 0, xt_p_x_tau = 0;
   double bty = 0, ctx = 0, xt_p_x = 0, gap = 0, pobj = 0, dobj = 0;
   double res_pri = 0, res_dual = 0, res_infeas = NAN, res_unbdd_a = NAN, res_unbdd_p = NAN;
+  // extras for the CSV log (normalised space and 2-norms)
+  double sq_pri_n = 0, sq_pri_o = 0, sq_dual_n = 0, sq_dual_o = 0, nm_ax_s_n = 0, nm_px_n = 0, nm_aty_n = 0;
+  double bty_tau_n = 0, ctx_tau_n = 0, xt_p_x_tau_n = 0, kap_n = 0;
 };
 
 }  // namespace scship
 
 using namespace scship;
+
+static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, const double *diffs, double aa_norm,
+                          double time_s);
 
 // ============================================================== workspace
 struct ScsHipWork {
@@ -111,6 +117,7 @@ struct ScsHipWork {
   std::vector<double> b_orig, c_orig;
   double nm_b_orig = 0, nm_c_orig = 0;
   double setup_time = 0;
+  std::string log_csv_filename, write_data_filename;
 
   hipStream_t stream = nullptr;
   bool owns_stream = true;
@@ -164,6 +171,7 @@ struct ScsHipWork {
   int n_log_scale_factor = 0, last_scale_update_iter = 0, scale_updates = 0;
   long tot_cg_iters = 0;
   int last_cg_iters = 8;
+  double cg_res_min = 0;
   // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
   bool profile = false;
   double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
@@ -335,7 +343,7 @@ struct ScsHipWork {
   // ------------------------------------------------------------ ADMM steps
   void set_iter_params(int iter) {
     h_params[P_DO_SCALE] = iter >= 1 ? 1.0 : 0.0;
-    h_params[P_RES_MIN] = std::min(r.nm_pri_n, r.nm_dual_n);
+    h_params[P_RES_MIN] = cg_res_min;  // residuals of the last convergence CHECK (not of a logging-only evaluation)
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
   }
@@ -464,32 +472,44 @@ struct ScsHipWork {
     if (r.last_iter == iter) return;
     r.last_iter = iter;
     const double *x = u.p, *y = u.p + n, *s = rsk.p + n, *tau_ptr = u.p + (l - 1);
-    // primal: 1 sum + 5 max over Ar blocks
+    // primal: 3 sums + 6 max over the A workgroups; dual: 4 sums + 6 max over the A' workgroups
     launch_spmv(Ar.view(), x, EpiResPri{s, h.p + n, normalized ? Dinv.p : nullptr, tau_ptr, y, part.p}, nullptr, stream);
-    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, Ar.nwg(), 1, 5, out.p);
+    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, Ar.nwg(), 3, 6, out.p);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{px.p, 0}, nullptr, stream);
     launch_spmv(At.view(), y, EpiResDual{has_P ? px.p : nullptr, h.p, normalized ? Einv.p : nullptr, x, tau_ptr, part.p},
                 nullptr, stream);
-    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), 2, 4, out.p + 8);
-    HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * 16, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(h_pin + 16, u.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipMemcpyAsync(h_pin + 17, rsk.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), 4, 6, out.p + 16);
+    HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * 32, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(h_pin + 32, u.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(h_pin + 33, rsk.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     const double pd = normalized ? scal.sigma * scal.sigma : 1.0;
-    r.tau = std::fabs(h_pin[16]);
-    r.kap = std::fabs(h_pin[17]) / pd;
-    r.bty_tau = h_pin[0] / pd;
-    r.nm_pri_n = h_pin[1];
-    r.nm_ax_s_btau = h_pin[2];
-    r.nm_ax_s = h_pin[3];
-    r.nm_ax = h_pin[4];
-    r.nm_s = h_pin[5];
-    r.ctx_tau = h_pin[8] / pd;
-    r.xt_p_x_tau = h_pin[9] / pd;
-    r.nm_dual_n = h_pin[10];
-    r.nm_px_aty_ctau = h_pin[11];
-    r.nm_px = h_pin[12];
-    r.nm_aty = h_pin[13];
+    const double *hp = h_pin, *hd = h_pin + 16;
+    r.tau = std::fabs(h_pin[32]);
+    r.kap_n = std::fabs(h_pin[33]);
+    r.kap = r.kap_n / pd;
+    r.bty_tau_n = hp[RES_P_BTY];
+    r.bty_tau = r.bty_tau_n / pd;
+    r.sq_pri_n = hp[RES_P_SQ_N];
+    r.sq_pri_o = hp[RES_P_SQ_O];
+    r.nm_pri_n = hp[RES_P_MAX_N];
+    r.nm_ax_s_btau = hp[RES_P_MAX_O];
+    r.nm_ax_s = hp[RES_P_AXS_O];
+    r.nm_ax = hp[RES_P_AX_O];
+    r.nm_s = hp[RES_P_S_O];
+    r.nm_ax_s_n = hp[RES_P_AXS_N];
+    r.ctx_tau_n = hd[RES_D_CTX];
+    r.ctx_tau = r.ctx_tau_n / pd;
+    r.xt_p_x_tau_n = hd[RES_D_XPX];
+    r.xt_p_x_tau = r.xt_p_x_tau_n / pd;
+    r.sq_dual_n = hd[RES_D_SQ_N];
+    r.sq_dual_o = hd[RES_D_SQ_O];
+    r.nm_dual_n = hd[RES_D_MAX_N];
+    r.nm_px_aty_ctau = hd[RES_D_MAX_O];
+    r.nm_px = hd[RES_D_PX_O];
+    r.nm_aty = hd[RES_D_ATY_O];
+    r.nm_px_n = hd[RES_D_PX_N];
+    r.nm_aty_n = hd[RES_D_ATY_N];
     r.bty = safediv_pos(r.bty_tau, r.tau);
     r.ctx = safediv_pos(r.ctx_tau, r.tau);
     r.xt_p_x = safediv_pos(r.xt_p_x_tau, r.tau * r.tau);
@@ -561,10 +581,10 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_aa_update, dim3(nbl), dim3(kVecThreads), 0, stream, v_prev.p, v.p, aa_x.p, aa_f.p, aa_gprev.p, aa_S.p,
                        aa_Y.p, aa_D.p, l, idx, aa_npart.p);
     hipLaunchKernelGGL(k_aa_dots, dim3(nbl), dim3(kVecThreads), 0, stream, L, aa_Y.p, aa_gprev.p, l, len, idx, part.p);
-    hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, aa_npart.p, nbl, part.p, nbl, len, out.p + 32, sc.p);
-    HIP_CHECK(hipMemcpyAsync(h_pin + 32, out.p + 32, sizeof(double) * (1 + 3 * kAaMaxMem), hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, aa_npart.p, nbl, part.p, nbl, len, out.p + 64, sc.p);
+    HIP_CHECK(hipMemcpyAsync(h_pin + 64, out.p + 64, sizeof(double) * (1 + 3 * kAaMaxMem), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    const double *o = h_pin + 32;
+    const double *o = h_pin + 64;
     for (int j = 0; j < len; ++j) {
       aa_M[idx + aa_mem * j] = o[1 + 0 * kAaMaxMem + j];  // row idx
       aa_M[j + aa_mem * idx] = o[1 + 1 * kAaMaxMem + j];  // col idx
@@ -620,6 +640,16 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_fin_safeguard, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 1.0, sc.p, fl.p);
     hipLaunchKernelGGL(k_aa_restore, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, aa_f.p, aa_x.p, l, fl.p);
     aa_pending_safeguard = true;
+  }
+
+  // one CSV row: residuals of this iteration are already in `r`; diff norms are reduced here
+  void log_csv_row(FILE *f, int iter, double elapsed_ms) {
+    const int nbl = vb(l);
+    hipLaunchKernelGGL(k_diff_norms, dim3(nbl), dim3(kVecThreads), 0, stream, u.p, ut.p, v.p, v_prev.p, l, part.p);
+    hipLaunchKernelGGL(k_fin_multi, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 2, 2, out.p + 40);
+    HIP_CHECK(hipMemcpyAsync(h_pin + 40, out.p + 40, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    write_csv_row(f, iter, r, scale, h_pin + 40, aa_norm, elapsed_ms / 1e3);
   }
 
   static int dense_solve(double *M, double *rhs, int nn) {
@@ -692,6 +722,80 @@ static void upload_cone_meta(ScsHipWork *w) {
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// ---- write_data_filename (kwarg R:scs/scsobject.h:493,550; tests R:test/test_scs_coverage.py:532-537,1728-1738) ----
+// Self-describing little-endian dump of (settings, cone, data) taken BEFORE equilibration, so that an instance
+// can be replayed.  Layout: magic "SCSHIP01", then records  <u32 tag><u64 count><payload>  with tags
+// 1 dims(i32 m,n) 2 settings(f64 x 16, field order of ScsSettings without the file names) 3 cone scalars (i32 z,l,bsize,ep,ed)
+// 4 bu 5 bl 6 q 7 s 8 p 9 b 10 c 11 A.x 12 A.i 13 A.p 14 P.x 15 P.i 16 P.p   (f64 or i32 arrays).
+static void write_record(FILE *f, unsigned tag, const void *ptr, size_t count, size_t elem) {
+  const unsigned long long c = count;
+  std::fwrite(&tag, sizeof(tag), 1, f);
+  std::fwrite(&c, sizeof(c), 1, f);
+  if (count) std::fwrite(ptr, elem, count, f);
+}
+static void write_problem_data(const char *fname, const ScsData *d, const ScsCone *k, const ScsSettings *st) {
+  FILE *f = std::fopen(fname, "wb");
+  if (!f) return;  // like the reference: a diagnostics file that cannot be opened is not fatal
+  std::fwrite("SCSHIP01", 1, 8, f);
+  const int dims[2] = {d->m, d->n};
+  write_record(f, 1, dims, 2, sizeof(int));
+  const double sv[16] = {(double)st->normalize, st->scale, (double)st->adaptive_scale, st->rho_x, (double)st->max_iters,
+                         st->eps_abs, st->eps_rel, st->eps_infeas, st->alpha, st->time_limit_secs, (double)st->verbose,
+                         (double)st->acceleration_lookback, (double)st->acceleration_interval,
+                         (double)st->acceleration_type_1, st->acceleration_regularization, st->acceleration_relaxation};
+  write_record(f, 2, sv, 16, sizeof(double));
+  const int cs[5] = {k->z, k->l, k->bsize, k->ep, k->ed};
+  write_record(f, 3, cs, 5, sizeof(int));
+  const size_t nb = k->bsize > 1 ? (size_t)k->bsize - 1 : 0;
+  write_record(f, 4, k->bu, nb, sizeof(double));
+  write_record(f, 5, k->bl, nb, sizeof(double));
+  write_record(f, 6, k->q, (size_t)k->qsize, sizeof(int));
+  write_record(f, 7, k->s, (size_t)k->ssize, sizeof(int));
+  write_record(f, 8, k->p, (size_t)k->psize, sizeof(double));
+  write_record(f, 9, d->b, (size_t)d->m, sizeof(double));
+  write_record(f, 10, d->c, (size_t)d->n, sizeof(double));
+  write_record(f, 11, d->A->x, (size_t)d->A->p[d->n], sizeof(double));
+  write_record(f, 12, d->A->i, (size_t)d->A->p[d->n], sizeof(int));
+  write_record(f, 13, d->A->p, (size_t)d->n + 1, sizeof(int));
+  if (d->P) {
+    write_record(f, 14, d->P->x, (size_t)d->P->p[d->n], sizeof(double));
+    write_record(f, 15, d->P->i, (size_t)d->P->p[d->n], sizeof(int));
+    write_record(f, 16, d->P->p, (size_t)d->n + 1, sizeof(int));
+  }
+  std::fclose(f);
+}
+
+// ---- log_csv_filename: one row per ADMM iteration, the 36 columns of the reference's logs
+// (R:notebooks/analyze_csv_logs.ipynb cell 3; kwarg R:scs/scsobject.h:494,551; tests R:test/test_scs_coverage.py:540-547,1739-1751)
+static const char *kCsvHeader =
+    "iter,res_pri,res_dual,gap,ax_s_btau_nrm_inf,px_aty_ctau_nrm_inf,ax_s_btau_nrm_2,px_aty_ctau_nrm_2,res_infeas,"
+    "res_unbdd_a,res_unbdd_p,pobj,dobj,tau,kap,res_pri_normalized,res_dual_normalized,gap_normalized,"
+    "ax_s_btau_nrm_inf_normalized,px_aty_ctau_nrm_inf_normalized,ax_s_btau_nrm_2_normalized,"
+    "px_aty_ctau_nrm_2_normalized,res_infeas_normalized,res_unbdd_a_normalized,res_unbdd_p_normalized,"
+    "pobj_normalized,dobj_normalized,tau_normalized,kap_normalized,scale,diff_u_ut_nrm_2,diff_v_v_prev_nrm_2,"
+    "diff_u_ut_nrm_inf,diff_v_v_prev_nrm_inf,aa_norm,time,\n";
+
+static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, const double *diffs, double aa_norm,
+                          double time_s) {
+  const double nan = NAN;
+  // normalised-space counterparts (tau is scale-free)
+  const double res_pri_n = safediv_pos(r.nm_pri_n, r.tau), res_dual_n = safediv_pos(r.nm_dual_n, r.tau);
+  const double bty_n = safediv_pos(r.bty_tau_n, r.tau), ctx_n = safediv_pos(r.ctx_tau_n, r.tau);
+  const double xpx_n = safediv_pos(r.xt_p_x_tau_n, r.tau * r.tau);
+  const double gap_n = std::fabs(xpx_n + ctx_n + bty_n), pobj_n = xpx_n / 2. + ctx_n, dobj_n = -xpx_n / 2. - bty_n;
+  const double infeas_n = r.bty_tau_n < 0 ? safediv_pos(r.nm_aty_n, -r.bty_tau_n) : nan;
+  const double unb_a_n = r.ctx_tau_n < 0 ? safediv_pos(r.nm_ax_s_n, -r.ctx_tau_n) : nan;
+  const double unb_p_n = r.ctx_tau_n < 0 ? safediv_pos(r.nm_px_n, -r.ctx_tau_n) : nan;
+  const double vals[35] = {r.res_pri, r.res_dual, r.gap, r.nm_ax_s_btau, r.nm_px_aty_ctau, std::sqrt(r.sq_pri_o),
+                           std::sqrt(r.sq_dual_o), r.res_infeas, r.res_unbdd_a, r.res_unbdd_p, r.pobj, r.dobj, r.tau, r.kap,
+                           res_pri_n, res_dual_n, gap_n, r.nm_pri_n, r.nm_dual_n, std::sqrt(r.sq_pri_n), std::sqrt(r.sq_dual_n),
+                           infeas_n, unb_a_n, unb_p_n, pobj_n, dobj_n, r.tau, r.kap_n, scale, std::sqrt(diffs[0]),
+                           std::sqrt(diffs[1]), diffs[2], diffs[3], aa_norm, time_s};
+  std::fprintf(f, "%d,", iter);
+  for (double v : vals) std::fprintf(f, "%.16e,", v);
+  std::fprintf(f, "\n");
+}
+
 static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   const double t0 = now_ms();
   if (!d || !k || !stgs) throw std::runtime_error("null argument");
@@ -714,10 +818,13 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   const int n = d->n, m = d->m;
   w->n = n; w->m = m; w->l = (long)n + m + 1;
   w->stgs = *stgs;
+  if (stgs->write_data_filename) w->write_data_filename = stgs->write_data_filename;
+  if (stgs->log_csv_filename) w->log_csv_filename = stgs->log_csv_filename;
   w->stgs.write_data_filename = nullptr;
   w->stgs.log_csv_filename = nullptr;
   w->scale = stgs->scale;
   w->has_P = d->P != nullptr;
+  if (!w->write_data_filename.empty()) write_problem_data(w->write_data_filename.c_str(), d, k, stgs);
   w->b_orig.assign(d->b, d->b + m);
   w->c_orig.assign(d->c, d->c + n);
   for (double x : w->b_orig) w->nm_b_orig = std::max(w->nm_b_orig, std::fabs(x));
@@ -838,6 +945,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   w->rejected_accel = 0; w->accepted_accel = 0; w->aa_iter = 0; w->aa_success = 0; w->aa_pending_safeguard = false;
   w->aa_stats = ScsAaStats{};
   w->r = Residuals{};
+  w->cg_res_min = 0;
   w->tot_cg_iters = 0;
   w->prof_ms[0] = w->prof_ms[1] = 0;
   w->prof_n[0] = w->prof_n[1] = 0;
@@ -867,6 +975,11 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     HIP_CHECK(hipStreamSynchronize(s));
   }
   info->status_val = SCS_UNFINISHED;
+  FILE *csv = nullptr;
+  if (!w->log_csv_filename.empty()) {
+    csv = std::fopen(w->log_csv_filename.c_str(), "w");
+    if (csv) std::fputs(kCsvHeader, csv);
+  }
   const bool verbose = w->stgs.verbose != 0;
   if (verbose) {
     std::printf("------------------------------------------------------------------\n");
@@ -906,7 +1019,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     const bool check = (i % 25 == 0);
     const bool print_now = verbose && (i % 250 == 0);
     const bool last = (i == max_iters - 1);
-    const bool plain_iter = !(check || print_now || last);
+    const bool plain_iter = !(check || print_now || last || csv);
     t = now_ms();
     w->project_lin_sys(i, use_graphs);  // ends with a stream sync (CG convergence flags)
     t_lin += now_ms() - t;
@@ -920,9 +1033,14 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       if (!plain_iter)
         hipLaunchKernelGGL(k_rsk, dim3(w->vb(l)), dim3(kVecThreads), 0, s, w->rsk.p, w->v.p, w->u.p, w->ut.p, w->diag_r.p, l);
       t_cone += now_ms() - t;
+      if (csv) w->populate_residuals(i);
       if (check) {
         w->populate_residuals(i);
-        if ((info->status_val = w->has_converged(i)) != 0) break;
+        w->cg_res_min = std::min(w->r.nm_pri_n, w->r.nm_dual_n);
+        if ((info->status_val = w->has_converged(i)) != 0) {
+          if (csv) w->log_csv_row(csv, i, now_ms() - t_start);
+          break;
+        }
         if (w->stgs.time_limit_secs > 0 && (now_ms() - t_start) > 1e3 * w->stgs.time_limit_secs) break;
       }
       if (print_now) {
@@ -931,8 +1049,9 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
                     0.5 * (w->r.pobj + w->r.dobj), w->scale, (now_ms() - t_start) / 1e3);
         std::fflush(stdout);
       }
-      if (w->stgs.adaptive_scale && i == w->r.last_iter) w->update_scale(i);
+      if (w->stgs.adaptive_scale && check && i == w->r.last_iter) w->update_scale(i);
       w->enqueue_v_update();
+      if (csv) w->log_csv_row(csv, i, now_ms() - t_start);
     }
     if (aa_now) {
       t = now_ms();
@@ -940,6 +1059,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       t_acc += now_ms() - t;
     }
   }
+  if (csv) std::fclose(csv);
   // ---- finalize ----
   if (i == max_iters) i = max_iters;  // loop ran out: rsk of the last iteration was computed
   w->read_flags();

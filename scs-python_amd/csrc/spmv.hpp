@@ -119,44 +119,57 @@ struct EpiY {  // y[r] = s / ry[r] + vy[r]        (y = R_y^{-1}(A x - r_y), r_y 
 };
 
 // primal residual pieces at a convergence check:
-//  s = A x;  ax_s = s + sl;  ax_s_btau = ax_s - b tau.  Norms in normalised and original (/(D sigma)) space.
+//  ax = A x;  ax_s = ax + s;  ax_s_btau = ax_s - b tau.  Norms in normalised and original (/(D sigma)) space.
+// sums: [b'y, ||ax_s_btau||_2^2 normalised, original]; maxs: see RES_P_* below
+enum : int { RES_P_BTY = 0, RES_P_SQ_N, RES_P_SQ_O, RES_P_MAX_N, RES_P_MAX_O, RES_P_AXS_O, RES_P_AX_O, RES_P_S_O, RES_P_AXS_N,
+             RES_P_COUNT };
 struct EpiResPri {
   const double *slack, *b, *Dinv;  // Dinv[r] = 1/(D[r] sigma) or nullptr
   const double *tau_ptr;           // |u[l-1]|
   const double *y;                 // dual iterate, for b'y
   double *partial;
-  static constexpr int kSums = 1, kMaxs = 5;
+  static constexpr int kSums = 3, kMaxs = 6;
   __device__ void operator()(int r, double ax, double *sums, double *maxs) const {
     const double tau = fabs(*tau_ptr);
     const double sl = slack[r];
     const double ax_s = ax + sl, ax_s_btau = ax_s - b[r] * tau;
     const double f = Dinv ? Dinv[r] : 1.0;
+    sums[0] += b[r] * y[r];
+    sums[1] += ax_s_btau * ax_s_btau;
+    sums[2] += (ax_s_btau * f) * (ax_s_btau * f);
     maxs[0] = fmax(maxs[0], abs_nan_inf(ax_s_btau));      // normalised ||Ax+s-b tau||
     maxs[1] = fmax(maxs[1], abs_nan_inf(ax_s_btau * f));  // original
     maxs[2] = fmax(maxs[2], abs_nan_inf(ax_s * f));
     maxs[3] = fmax(maxs[3], abs_nan_inf(ax * f));
     maxs[4] = fmax(maxs[4], abs_nan_inf(sl * f));
-    sums[0] += b[r] * y[r];
+    maxs[5] = fmax(maxs[5], abs_nan_inf(ax_s));
   }
 };
 
 // dual residual pieces: aty = A'y; px_aty_ctau = px + aty + c tau
+// sums: [c'x, x'Px, ||.||_2^2 normalised, original]; maxs: see RES_D_*
+enum : int { RES_D_CTX = 0, RES_D_XPX, RES_D_SQ_N, RES_D_SQ_O, RES_D_MAX_N, RES_D_MAX_O, RES_D_PX_O, RES_D_ATY_O, RES_D_PX_N,
+             RES_D_ATY_N, RES_D_COUNT };
 struct EpiResDual {
   const double *px, *c, *Einv, *x;
   const double *tau_ptr;
   double *partial;
-  static constexpr int kSums = 2, kMaxs = 4;
+  static constexpr int kSums = 4, kMaxs = 6;
   __device__ void operator()(int r, double aty, double *sums, double *maxs) const {
     const double tau = fabs(*tau_ptr);
     const double pxr = px ? px[r] : 0.0;
     const double tot = pxr + aty + c[r] * tau;
     const double f = Einv ? Einv[r] : 1.0;
+    sums[0] += c[r] * x[r];
+    sums[1] += pxr * x[r];
+    sums[2] += tot * tot;
+    sums[3] += (tot * f) * (tot * f);
     maxs[0] = fmax(maxs[0], abs_nan_inf(tot));
     maxs[1] = fmax(maxs[1], abs_nan_inf(tot * f));
     maxs[2] = fmax(maxs[2], abs_nan_inf(pxr * f));
     maxs[3] = fmax(maxs[3], abs_nan_inf(aty * f));
-    sums[0] += c[r] * x[r];
-    sums[1] += pxr * x[r];
+    maxs[4] = fmax(maxs[4], abs_nan_inf(pxr));
+    maxs[5] = fmax(maxs[5], abs_nan_inf(aty));
   }
 };
 

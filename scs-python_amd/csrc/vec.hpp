@@ -412,6 +412,31 @@ __global__ __launch_bounds__(kVecThreads) void k_dot(const double *__restrict__ 
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// per-iteration CSV diagnostics: [||u-u_t||_2^2, ||v-v_prev||_2^2, ||u-u_t||_inf, ||v-v_prev||_inf]
+__global__ __launch_bounds__(kVecThreads) void k_diff_norms(const double *__restrict__ u, const double *__restrict__ ut,
+                                                            const double *__restrict__ v, const double *__restrict__ vp,
+                                                            long l, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double a = 0., b = 0., c = 0., d = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
+    const double du = u[i] - ut[i], dv = v[i] - vp[i];
+    a += du * du;
+    b += dv * dv;
+    c = fmax(c, abs_nan_inf(du));
+    d = fmax(d, abs_nan_inf(dv));
+  }
+  a = block_sum<kVecThreads>(a, sm);
+  b = block_sum<kVecThreads>(b, sm);
+  c = block_max<kVecThreads>(c, sm);
+  d = block_max<kVecThreads>(d, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = a;
+    part[gridDim.x + blockIdx.x] = b;
+    part[2 * gridDim.x + blockIdx.x] = c;
+    part[3 * gridDim.x + blockIdx.x] = d;
+  }
+}
+
 // collapse k groups of np partials into out[0..k): sums for the first `nsum` groups, max for the rest
 __global__ __launch_bounds__(kVecThreads) void k_fin_multi(const double *part, int np, int nsum, int nmax, double *out) {
   __shared__ double sm[kVecThreads / 64];

@@ -242,3 +242,44 @@ def test_shared_instance_is_serialised_by_its_lock(scs):
     for o in outs:  # (the adaptive scale persists between solves, so later trajectories differ: compare optima)
         assert o["info"]["status"] == "solved"
         assert abs(o["info"]["pobj"] - base["info"]["pobj"]) < 1e-3 * max(1.0, abs(base["info"]["pobj"]))
+
+
+def _read_scship_dump(fname):
+    """reader of the write_data_filename format documented in csrc/scs_hip.hip (write_problem_data)"""
+    import struct
+    raw = open(fname, "rb").read()
+    assert raw[:8] == b"SCSHIP01"
+    pos, recs = 8, {}
+    f64_tags = {2, 4, 5, 8, 9, 10, 11, 14}
+    while pos < len(raw):
+        tag, cnt = struct.unpack_from("<IQ", raw, pos)
+        pos += 12
+        dt = np.float64 if tag in f64_tags else np.int32
+        recs[tag] = np.frombuffer(raw, dtype=dt, count=cnt, offset=pos).copy()
+        pos += cnt * np.dtype(dt).itemsize
+    return recs
+
+
+def test_write_data_and_log_csv_files(scs, tmp_path):
+    # R:test/test_scs_coverage.py:532-547,1728-1751,3055-3069
+    dat, K, _ = helpers.load_problem("problems_rand.npz", "feas0_")
+    data_file, log_file = str(tmp_path / "data.bin"), str(tmp_path / "log.csv")
+    sol = scs.SCS(dat, K, verbose=False, write_data_filename=data_file, log_csv_filename=log_file).solve()
+    assert sol["info"]["status"] == "solved"
+    recs = _read_scship_dump(data_file)
+    A = dat["A"]
+    assert tuple(recs[1]) == A.shape
+    np.testing.assert_array_equal(recs[11], A.data)
+    np.testing.assert_array_equal(recs[12], A.indices)
+    np.testing.assert_array_equal(recs[9], dat["b"])
+    np.testing.assert_array_equal(recs[6], K["q"])
+    lines = [ln for ln in open(log_file).read().splitlines() if ln.strip()]
+    header = lines[0].split(",")
+    assert header[0] == "iter" and "res_pri" in header and "diff_u_ut_nrm_2" in header and header[35] == "time"
+    assert len(lines) == sol["info"]["iter"] + 2          # header + one row per iteration 0..iter
+    last = lines[-1].split(",")
+    assert int(last[0]) == sol["info"]["iter"]
+    assert abs(float(last[header.index("res_pri")]) - sol["info"]["res_pri"]) <= 1e-12 + 1e-9 * sol["info"]["res_pri"]
+    # logging must not change the answer
+    plain = scs.SCS(dat, K, verbose=False).solve()
+    np.testing.assert_array_equal(plain["x"], sol["x"])

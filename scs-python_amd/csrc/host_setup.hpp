@@ -1,5 +1,6 @@
 // host_setup.hpp — init-time (one-off, O(nnz)) host work: validation, cone
-// bookkeeping, CSC->CSR, symmetric expansion of P and data equilibration.
+// bookkeeping, CSC->CSR, symmetric expansion of P and the O(m+n) b/c scaling
+// (the matrix equilibration itself runs on the device: normalize_dev.hpp).
 //
 // Plays the role of scs_source/src/normalize.c + the matrix helpers of
 // scs_source/linsys/scs_matrix.c (R:meson.build:192,200; absent).  Algorithm:
@@ -138,74 +139,6 @@ inline double apply_limit(double x) {
   return x > 1e4 ? 1e4 : x;
 }
 inline double safediv_pos(double x, double y) { return y < 1e-18 ? x / 1e-18 : x / y; }
-
-inline void enforce_cone_boundaries(const HostCone &c, std::vector<double> &vec, bool use_mean) {
-  long count = c.boundaries[0];
-  for (size_t i = 1; i < c.boundaries.size(); ++i) {
-    const int len = c.boundaries[i];
-    if (len > 0) {
-      double w = 0.;
-      if (use_mean) {
-        for (int j = 0; j < len; ++j) w += vec[count + j];
-        w /= (double)len;
-      } else {
-        for (int j = 0; j < len; ++j) w = std::max(w, std::fabs(vec[count + j]));
-      }
-      for (int j = 0; j < len; ++j) vec[count + j] = w;
-    }
-    count += len;
-  }
-}
-
-// Equilibrate in place.  A: CSC (m x n); P: upper-tri CSC or null.  Box bounds in `cone` follow D.
-inline void normalize_a_p(int m, int n, const int *Ap, const int *Ai, double *Ax, const int *Pp, const int *Pi, double *Px,
-                          HostCone &cone, HostScaling &sc) {
-  sc.D.assign(m, 1.0);
-  sc.E.assign(n, 1.0);
-  std::vector<double> Dt(m), Et(n);
-  for (int pass = 0; pass < 25 + 1; ++pass) {
-    const bool l2 = pass >= 25;
-    std::fill(Dt.begin(), Dt.end(), 0.0);
-    std::fill(Et.begin(), Et.end(), 0.0);
-    for (int j = 0; j < n; ++j)
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-        const double v = std::fabs(Ax[p]);
-        const int i = Ai[p];
-        if (l2) { Dt[i] += v * v; Et[j] += v * v; }
-        else { Dt[i] = std::max(Dt[i], v); Et[j] = std::max(Et[j], v); }
-      }
-    if (Pp)
-      for (int j = 0; j < n; ++j)
-        for (int p = Pp[j]; p < Pp[j + 1]; ++p) {
-          const double v = std::fabs(Px[p]);
-          const int i = Pi[p];
-          if (i > j) continue;
-          if (l2) { Et[j] += v * v; if (i != j) Et[i] += v * v; }
-          else { Et[j] = std::max(Et[j], v); Et[i] = std::max(Et[i], v); }
-        }
-    if (l2) {
-      for (auto &d : Dt) d = std::sqrt(d);
-      for (auto &e : Et) e = std::sqrt(e);
-    }
-    enforce_cone_boundaries(cone, Dt, l2);
-    for (auto &d : Dt) d = safediv_pos(1.0, std::sqrt(apply_limit(d)));
-    for (auto &e : Et) e = safediv_pos(1.0, std::sqrt(apply_limit(e)));
-    for (int j = 0; j < n; ++j)
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) Ax[p] *= Dt[Ai[p]] * Et[j];
-    if (Pp)
-      for (int j = 0; j < n; ++j)
-        for (int p = Pp[j]; p < Pp[j + 1]; ++p) Px[p] *= Et[Pi[p]] * Et[j];
-    for (int i = 0; i < m; ++i) sc.D[i] *= Dt[i];
-    for (int j = 0; j < n; ++j) sc.E[j] *= Et[j];
-  }
-  if (cone.bsize > 1) {
-    const double *D = &sc.D[cone.off_box];
-    for (int j = 0; j < cone.bsize - 1; ++j) {
-      cone.bu[j] = (cone.bu[j] >= 1e15) ? INFINITY : D[j + 1] * cone.bu[j] / D[0];
-      cone.bl[j] = (cone.bl[j] <= -1e15) ? -INFINITY : D[j + 1] * cone.bl[j] / D[0];
-    }
-  }
-}
 
 inline void normalize_b_c(HostScaling &sc, double *b, int m, double *c, int n) {
   double nb = 0., nc = 0.;

@@ -1,0 +1,130 @@
+// normalize_dev.hpp — K12: data equilibration on the device (init time).
+//
+// Plays the role of scs_source/src/normalize.c + the normalisation helpers of
+// scs_source/linsys/scs_matrix.c (R:meson.build:192,200; absent).  `normalize` defaults to true
+// (R:scs/scsobject.h:797).  Algorithm: 25 Ruiz (inf-norm) passes + 1 l2 pass on
+// [P A'; A 0]; row scalings made constant inside every non-separable cone block (max / mean);
+// factors clamped to [1e-4, 1e4];
+//     A_hat = D A E,  P_hat = E P E,  b_hat = sigma D b,  c_hat = sigma E c.
+//
+// All three resident layouts are scaled in place: CSR(A) gives the row norms, CSR(A') (= the caller's
+// CSC) the column norms, the full symmetric CSR(P) its contribution to E.  One pass = three
+// segmented reductions + three rescale sweeps, each one streaming pass over a matrix (HBM-bound,
+// ~0.1 ms at nnz = 2e7), 26 passes.  Row sums run in CSR order = ascending column, i.e. the same
+// order as the oracle's CSC loops, so D and E agree with the CPU restatement to the last bit
+// (except the l2-pass contribution of P and the mean over large cone blocks: ~1 ulp).
+#pragma once
+#include "common.hpp"
+#include "vec.hpp"
+
+namespace scship {
+
+// out[r] = max |val| (l2 = 0) or sqrt(sum val^2) (l2 = 1) over CSR row r; thread per row
+__global__ __launch_bounds__(kVecThreads) void k_row_norm(const int *__restrict__ rowptr, const double *__restrict__ val,
+                                                          int rows, int l2, double *out) {
+  for (long r = (long)blockIdx.x * kVecThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kVecThreads) {
+    double acc = 0.;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      const double v = fabs(val[p]);
+      acc = l2 ? __dadd_rn(acc, __dmul_rn(v, v)) : fmax(acc, v);  // no FMA contraction: same bits as the CPU restatement
+    }
+    out[r] = acc;
+  }
+}
+
+// Et = combine(Et_A, Et_P): max for the inf passes, sum of squares for the l2 pass (before the sqrt)
+__global__ __launch_bounds__(kVecThreads) void k_combine(double *a, const double *__restrict__ b, int n, int l2) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
+    a[i] = l2 ? a[i] + b[i] : fmax(a[i], b[i]);
+}
+__global__ __launch_bounds__(kVecThreads) void k_sqrt_inplace(double *a, int n) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) a[i] = sqrt(a[i]);
+}
+
+// make Dt constant over each non-separable cone block: max (inf passes) or mean (l2 pass); one wave per block,
+// blocks up to 64 rows are summed sequentially by lane 0 (the oracle's order), larger ones by a fixed tree
+__global__ __launch_bounds__(kVecThreads) void k_enforce_blocks(double *Dt, const int *__restrict__ boff,
+                                                                const int *__restrict__ blen, int nblocks, int use_mean) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kVecThreads / 64) + (threadIdx.x >> 6);
+  if (b >= nblocks) return;
+  const int len = blen[b];
+  if (len <= 0) return;
+  double *d = Dt + boff[b];
+  double w = 0.;
+  if (len <= 64) {
+    if (lane == 0) {
+      for (int j = 0; j < len; ++j) w = use_mean ? w + d[j] : fmax(w, fabs(d[j]));
+      if (use_mean) w /= (double)len;
+    }
+    w = __shfl(w, 0, 64);
+  } else {
+    for (int j = lane; j < len; j += 64) w = use_mean ? w + d[j] : fmax(w, fabs(d[j]));
+    w = use_mean ? wave_sum(w) : wave_max(w);
+    w = __shfl(w, 0, 64);
+    if (use_mean) w /= (double)len;
+  }
+  for (int j = lane; j < len; j += 64) d[j] = w;
+}
+
+// t = 1 / sqrt(limit(t)); acc *= t
+__global__ __launch_bounds__(kVecThreads) void k_invsqrt_acc(double *t, double *acc, int n) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    double x = t[i];
+    x = x < 1e-4 ? 1.0 : x;
+    x = x > 1e4 ? 1e4 : x;
+    const double s = sqrt(x);
+    const double f = s < 1e-18 ? 1.0 / 1e-18 : 1.0 / s;
+    t[i] = f;
+    acc[i] *= f;
+  }
+}
+
+// val[p] *= rs[row] * cs[col[p]]
+__global__ __launch_bounds__(kVecThreads) void k_rescale(const int *__restrict__ rowptr, const int *__restrict__ col, double *val,
+                                                         int rows, const double *__restrict__ rs, const double *__restrict__ cs) {
+  for (long r = (long)blockIdx.x * kVecThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kVecThreads) {
+    const double f = rs[r];
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) val[p] = __dmul_rn(val[p], __dmul_rn(f, cs[col[p]]));
+  }
+}
+
+// diag[r] = sum of the entries (r, r) of a CSR matrix
+__global__ __launch_bounds__(kVecThreads) void k_csr_diag(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                          const double *__restrict__ val, int rows, double *diag) {
+  for (long r = (long)blockIdx.x * kVecThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kVecThreads) {
+    double d = 0.;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p)
+      if (col[p] == r) d += val[p];
+    diag[r] = d;
+  }
+}
+
+// v[i] *= s[i]; partial max |v|
+__global__ __launch_bounds__(kVecThreads) void k_scale_by_vec(double *v, const double *__restrict__ s, int n, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double mx = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    const double x = v[i] * s[i];
+    v[i] = x;
+    mx = fmax(mx, fabs(x));
+  }
+  mx = block_max<kVecThreads>(mx, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = mx;
+}
+__global__ __launch_bounds__(kVecThreads) void k_scale_scalar(double *v, double a, long n) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) v[i] *= a;
+}
+__global__ __launch_bounds__(kVecThreads) void k_fill(double *v, double a, long n) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) v[i] = a;
+}
+// dst[k] = src[perm[k]] (perm < 0: zero padding) — refreshes the slab copy from the scaled CSR values
+__global__ __launch_bounds__(kVecThreads) void k_gather_vals(double *dst, const double *__restrict__ src, const int *__restrict__ perm,
+                                                             long n) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
+    const int p = perm[i];
+    dst[i] = p >= 0 ? src[p] : 0.0;
+  }
+}
+
+}  // namespace scship

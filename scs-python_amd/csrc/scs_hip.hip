@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "cones.hpp"
 #include "host_setup.hpp"
+#include "normalize_dev.hpp"
 #include "psd.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
@@ -46,7 +47,7 @@ struct DeviceCsr {
   long nnz = 0;
   // optional L2-blocked copy (spmv.hpp) used by the mat-vec kernels when the gather vector exceeds L2
   bool has_slab = false;
-  DevBuf<int> s_segptr, s_col;
+  DevBuf<int> s_segptr, s_col, s_perm;  // s_perm: source index of every slab entry in CSR order (-1 = padding)
   DevBuf<unsigned short> s_roff;
   DevBuf<double> s_val;
   int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
@@ -62,7 +63,9 @@ struct DeviceCsr {
     const char *env = getenv("SCS_HIP_SLAB");  // "0" forces the plain CSR-stream kernel (A/B measurements)
     if (allow_slab && slab_wanted(rows, cols) && !(env && env[0] == '0')) {
       HostSlab hs;
-      if (build_slab(rp, ci, v, rows, cols, hs)) {
+      std::vector<int> src;
+      if (build_slab(rp, ci, v, rows, cols, hs, &src)) {
+        s_perm.upload(src.data(), src.size(), s);
         s_segptr.upload(hs.segptr.data(), hs.segptr.size(), s);
         s_roff.upload(hs.roff.data(), hs.roff.size(), s);
         s_col.upload(hs.col.data(), hs.col.size(), s);
@@ -82,7 +85,86 @@ struct DeviceCsr {
     return M;
   }
   int nwg() const { return has_slab ? s_nchunks : nblk; }
+  // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
+  void refresh_slab(hipStream_t s, bool drop_perm) {
+    if (!has_slab) return;
+    const long cnt = (long)s_val.n;
+    hipLaunchKernelGGL(k_gather_vals, dim3(vec_blocks(cnt)), dim3(kVecThreads), 0, s, s_val.p, val.p, s_perm.p, cnt);
+    if (drop_perm) {
+      HIP_CHECK(hipStreamSynchronize(s));
+      s_perm.release();
+    }
+  }
 };
+
+// K12 on the device: equilibrate the three resident layouts in place; D (m) and E (n) accumulate the scalings.
+static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const HostCone &cone, DevBuf<double> &D,
+                             DevBuf<double> &E, hipStream_t s) {
+  const int m = Ar.rows, n = At.rows;
+  DevBuf<double> Dt, Et, Ep;
+  Dt.alloc(m);
+  Et.alloc(n);
+  if (Pf) Ep.alloc(n);
+  D.alloc(m);
+  E.alloc(n);
+  hipLaunchKernelGGL(k_fill, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, D.p, 1.0, (long)m);
+  hipLaunchKernelGGL(k_fill, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, E.p, 1.0, (long)n);
+  // non-separable cone blocks (everything after the z/l/box rows)
+  std::vector<int> boff, blen;
+  long count = cone.boundaries[0];
+  for (size_t i = 1; i < cone.boundaries.size(); ++i) {
+    if (cone.boundaries[i] > 1) { boff.push_back((int)count); blen.push_back(cone.boundaries[i]); }
+    count += cone.boundaries[i];
+  }
+  DevBuf<int> dboff, dblen;
+  const int nblocks = (int)boff.size();
+  if (nblocks) { dboff.upload(boff.data(), boff.size(), s); dblen.upload(blen.data(), blen.size(), s); }
+  for (int pass = 0; pass < 26; ++pass) {
+    const int l2 = pass >= 25 ? 1 : 0;
+    hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Ar.rowptr.p, Ar.val.p, m, l2, Dt.p);
+    hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, At.rowptr.p, At.val.p, n, l2, Et.p);
+    if (Pf) {
+      hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Pf->rowptr.p, Pf->val.p, n, l2, Ep.p);
+      hipLaunchKernelGGL(k_combine, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, Ep.p, n, l2);
+    }
+    if (l2) {
+      hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, m);
+      hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, n);
+    }
+    if (nblocks)
+      hipLaunchKernelGGL(k_enforce_blocks, dim3(ceil_div(nblocks, kVecThreads / 64)), dim3(kVecThreads), 0, s, Dt.p, dboff.p,
+                         dblen.p, nblocks, l2);
+    hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, D.p, m);
+    hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, E.p, n);
+    hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Ar.rowptr.p, Ar.col.p, Ar.val.p, m, Dt.p, Et.p);
+    hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, At.rowptr.p, At.col.p, At.val.p, n, Et.p, Dt.p);
+    if (Pf)
+      hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Pf->rowptr.p, Pf->col.p, Pf->val.p, n, Et.p,
+                         Et.p);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));  // Dt/Et/Ep and the block arrays are locals
+}
+
+// b_hat = sigma D b, c_hat = sigma E c on the device vector h = [c; b]; returns sigma
+static double device_normalize_b_c(DevBuf<double> &h, int n, int m, const DevBuf<double> &D, const DevBuf<double> &E,
+                                   DevBuf<double> &part, double *h_pin, hipStream_t s) {
+  const int nbn = vec_blocks(n), nbm = vec_blocks(m);
+  hipLaunchKernelGGL(k_scale_by_vec, dim3(nbn), dim3(kVecThreads), 0, s, h.p, E.p, n, part.p);
+  hipLaunchKernelGGL(k_scale_by_vec, dim3(nbm), dim3(kVecThreads), 0, s, h.p + n, D.p, m, part.p + kMaxVecBlocks);
+  std::vector<double> pm(2 * kMaxVecBlocks, 0.0);
+  HIP_CHECK(hipMemcpyAsync(pm.data(), part.p, sizeof(double) * 2 * kMaxVecBlocks, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  double nc = 0., nb = 0.;
+  for (int i = 0; i < nbn; ++i) nc = std::max(nc, pm[i]);
+  for (int i = 0; i < nbm; ++i) nb = std::max(nb, pm[kMaxVecBlocks + i]);
+  double sigma = std::max(nc, nb);
+  sigma = sigma < 1e-4 ? 1.0 : sigma;
+  sigma = sigma > 1e4 ? 1e4 : sigma;
+  sigma = safediv_pos(1.0, sigma);
+  hipLaunchKernelGGL(k_scale_scalar, dim3(vec_blocks((long)n + m)), dim3(kVecThreads), 0, s, h.p, sigma, (long)n + m);
+  (void)h_pin;
+  return sigma;
+}
 
 struct Residuals {
   int last_iter = -1;
@@ -843,31 +925,42 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   }
   hipStream_t s = w->stream;
 
-  // ---- copy + equilibrate on the host (one-off, O(nnz)) ----
-  const long nnzA = d->A->p[n];
-  std::vector<double> Ax(d->A->x, d->A->x + nnzA), Px;
-  if (w->has_P) Px.assign(d->P->x, d->P->x + d->P->p[n]);
-  std::vector<double> bn(w->b_orig), cn(w->c_orig);
+  // ---- matrices to HBM (raw): CSC(A) as CSR(A'), explicit CSR(A), full CSR(P) ----
   w->normalized = stgs->normalize != 0;
-  if (w->normalized) {
-    normalize_a_p(m, n, d->A->p, d->A->i, Ax.data(), w->has_P ? d->P->p : nullptr, w->has_P ? d->P->i : nullptr,
-                  w->has_P ? Px.data() : nullptr, w->cone, w->scal);
-    normalize_b_c(w->scal, bn.data(), m, cn.data(), n);
-  }
-  // ---- matrices to HBM: CSC(A) as CSR(A'), explicit CSR(A), full CSR(P) ----
-  w->At.upload(n, m, d->A->p, d->A->i, Ax.data(), s);
+  w->At.upload(n, m, d->A->p, d->A->i, d->A->x, s);
   {
     HostCsr ar;
-    csc_to_csr(m, n, d->A->p, d->A->i, Ax.data(), ar);
+    csc_to_csr(m, n, d->A->p, d->A->i, d->A->x, ar);
     w->Ar.upload(m, n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s);
   }
   if (w->has_P) {
     HostCsr pf;
     std::vector<double> pdiag;
-    sym_expand(n, d->P->p, d->P->i, Px.data(), pf, pdiag);
+    sym_expand(n, d->P->p, d->P->i, d->P->x, pf, pdiag);
     w->Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s);
-    w->Pdiag.upload(pdiag.data(), n, s);
     w->px.alloc_zero(n, s);
+  }
+  // ---- K12: equilibrate on the device, in place in all resident layouts ----
+  if (w->normalized) {
+    device_normalize(w->At, w->Ar, w->has_P ? &w->Pf : nullptr, w->cone, w->D, w->E, s);
+    w->scal.D.resize(m);
+    w->scal.E.resize(n);
+    w->D.download(w->scal.D.data(), m, s);
+    w->E.download(w->scal.E.data(), n, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (w->cone.bsize > 1) {  // box bounds follow the row scaling: bl_j <- bl_j D_{j+1} / D_0
+      const double *Db = &w->scal.D[w->cone.off_box];
+      for (int j = 0; j < w->cone.bsize - 1; ++j) {
+        w->cone.bu[j] = (w->cone.bu[j] >= 1e15) ? INFINITY : Db[j + 1] * w->cone.bu[j] / Db[0];
+        w->cone.bl[j] = (w->cone.bl[j] <= -1e15) ? -INFINITY : Db[j + 1] * w->cone.bl[j] / Db[0];
+      }
+    }
+  }
+  for (DeviceCsr *M : {&w->At, &w->Ar, &w->Pf}) M->refresh_slab(s, true);
+  if (w->has_P) {  // diagonal of the (scaled) P for the Jacobi preconditioner
+    w->Pdiag.alloc_zero(n, s);
+    hipLaunchKernelGGL(k_csr_diag, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w->Pf.rowptr.p, w->Pf.col.p, w->Pf.val.p, n,
+                       w->Pdiag.p);
   }
   // ---- vectors ----
   const long l = w->l;
@@ -887,17 +980,16 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->fl.alloc_zero(F_COUNT, s);
   {
     std::vector<double> hh(l, 0.0);
-    std::copy(cn.begin(), cn.end(), hh.begin());
-    std::copy(bn.begin(), bn.end(), hh.begin() + n);
+    std::copy(w->c_orig.begin(), w->c_orig.end(), hh.begin());
+    std::copy(w->b_orig.begin(), w->b_orig.end(), hh.begin() + n);
     w->h.upload(hh.data(), l, s);
     HIP_CHECK(hipStreamSynchronize(s));
   }
   if (w->normalized) {
+    w->scal.sigma = device_normalize_b_c(w->h, n, m, w->D, w->E, w->part, w->h_pin, s);
     std::vector<double> di(m), ei(n);
     for (int i = 0; i < m; ++i) di[i] = 1.0 / (w->scal.D[i] * w->scal.sigma);
     for (int i = 0; i < n; ++i) ei[i] = 1.0 / (w->scal.E[i] * w->scal.sigma);
-    w->D.upload(w->scal.D.data(), m, s);
-    w->E.upload(w->scal.E.data(), n, s);
     w->Dinv.upload(di.data(), m, s);
     w->Einv.upload(ei.data(), n, s);
     HIP_CHECK(hipStreamSynchronize(s));
@@ -1458,9 +1550,36 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
     set_last_error("");
     HostCone cone;
     if (!build_cone(k, cone) || cone.m != A->m) throw std::runtime_error("invalid cone");
+    if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid A");
+    TmpStream ts;
+    hipStream_t s = ts.s;
+    const int m = A->m, n = A->n;
+    DeviceCsr At, Ar, Pf;
+    At.upload(n, m, A->p, A->i, A->x, s, false);
+    {
+      HostCsr ar;
+      csc_to_csr(m, n, A->p, A->i, A->x, ar);
+      Ar.upload(m, n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, false);
+    }
+    if (P) {
+      HostCsr pf;
+      std::vector<double> pdiag;
+      sym_expand(n, P->p, P->i, P->x, pf, pdiag);
+      Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s, false);
+    }
+    DevBuf<double> dD, dE;
+    device_normalize(At, Ar, P ? &Pf : nullptr, cone, dD, dE, s);
     HostScaling sc;
-    normalize_a_p(A->m, A->n, A->p, A->i, A->x, P ? P->p : nullptr, P ? P->i : nullptr, P ? P->x : nullptr, cone, sc);
-    normalize_b_c(sc, b, A->m, c, A->n);
+    sc.D.resize(m);
+    sc.E.resize(n);
+    dD.download(sc.D.data(), m, s);
+    dE.download(sc.E.data(), n, s);
+    At.val.download(A->x, (size_t)A->p[n], s);  // CSR(A') order == the caller's CSC order
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (P)
+      for (int j = 0; j < n; ++j)
+        for (int q = P->p[j]; q < P->p[j + 1]; ++q) P->x[q] *= sc.E[P->i[q]] * sc.E[j];
+    normalize_b_c(sc, b, m, c, n);
     std::copy(sc.D.begin(), sc.D.end(), D);
     std::copy(sc.E.begin(), sc.E.end(), E);
     *sigma = sc.sigma;

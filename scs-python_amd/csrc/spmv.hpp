@@ -279,7 +279,8 @@ inline int slab_pick_rows(int rows) {
 inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20) && rows >= 65536; }
 
 // CSR -> slab format; false when a (chunk, slab) segment would overflow the uint16 offsets
-inline bool build_slab(const int *rowptr, const int *col, const double *val, int rows, int cols, HostSlab &out) {
+inline bool build_slab(const int *rowptr, const int *col, const double *val, int rows, int cols, HostSlab &out,
+                       std::vector<int> *src = nullptr) {
   const int R = slab_pick_rows(rows);
   const int shift = slab_shift();
   const int S = (int)(((long)cols + (1L << shift) - 1) >> shift);
@@ -289,6 +290,7 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
   out.segptr.assign((size_t)nchunks * S + 1, 0);
   out.roff.assign((size_t)nchunks * S * (R + 1), 0);
   out.col.clear(); out.val.clear();
+  if (src) { src->clear(); src->reserve(nnz + 4L * nchunks * S); }
   out.col.reserve(nnz + 4L * nchunks * S);
   out.val.reserve(nnz + 4L * nchunks * S);
   std::vector<int> cursor(R);
@@ -312,6 +314,7 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
         while (p < pe && col[p] < chi) {
           out.col.push_back(col[p]);
           out.val.push_back(val[p]);
+          if (src) src->push_back(p);
           ++p; ++copied;
         }
         cursor[r - r0] = p;
@@ -321,7 +324,7 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
       for (int r = r1; r <= r0 + R; ++r) ro[r - r0] = (unsigned short)endoff;
       // pad to a multiple of 4 with zero-valued entries inside the slab (never summed: beyond every row's run)
       const int padcol = (int)std::min<long>((long)s << shift, (long)cols - 1);
-      while (out.col.size() % 4 != 0) { out.col.push_back(padcol); out.val.push_back(0.0); }
+      while (out.col.size() % 4 != 0) { out.col.push_back(padcol); out.val.push_back(0.0); if (src) src->push_back(-1); }
       out.max_seg = std::max(out.max_seg, (int)((long)out.col.size() - seg0));
     }
   }

@@ -249,3 +249,27 @@ def test_determinism_bit_exact(hip):
     for key in ("x", "y", "s"):
         np.testing.assert_array_equal(a[key], b[key])
     assert a["info"]["iter"] == b["info"]["iter"]
+
+
+@pytest.mark.parametrize("with_P", [False, True])
+def test_equilibration_matches_oracle(hip, oracle, with_P):
+    """K12 runs on the device; D, E, sigma and the scaled data must match the oracle's restatement to a
+    few ulp (same pass structure and summation order; device sqrt / the l2-pass order of P's
+    contribution may differ in the last bit, compounded over 26 passes)."""
+    data, K, _ = helpers.load_problem("problems_sdp.npz", "feas0_")
+    A = data["A"]
+    n = A.shape[1]
+    P = None
+    if with_P:
+        rng = np.random.RandomState(4)
+        B = sparse.rand(n, n, 0.05, format="csc", random_state=rng)
+        P = sparse.triu(B.T @ B + sparse.eye(n), format="csc")
+        P.sort_indices()
+    got = hip.normalize(A, P, data["b"], data["c"], K)
+    ref = oracle.normalize(A, P, data["b"], data["c"], K)
+    names = ["A", "P", "b", "c", "D", "E"]
+    for name, g, r in zip(names, got[:6], ref[:6]):
+        if g is None:
+            continue
+        np.testing.assert_allclose(g, r, rtol=1e-13, atol=0, err_msg=name)
+    assert abs(got[6] - ref[6]) <= 1e-13 * ref[6]

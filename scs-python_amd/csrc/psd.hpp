@@ -35,6 +35,7 @@ constexpr int kPsdWaves = kPsdThreads / 64;
 constexpr int kPsdMaxSweeps = 30;
 constexpr int kPsdB = 8;  // block size; pivots are 2*kPsdB = 16 = one MFMA tile
 constexpr int kPsdWaveLds = 272 + 256 + 16;  // per wave: S / 16x17 transpose scratch, W, (c,s)
+constexpr int kPsdWarmPeriod = 32;  // calls between two cold (V = I) eigen-solves
 constexpr int kPsdDepth = 4;  // block tasks whose global loads are in flight per wave
 constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
 constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int) + 256;
@@ -42,7 +43,7 @@ constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * siz
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (doubles) of this matrix's scratch: A (NP*NP), V (NP*NP), W (NB/2*256), lam (NP)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T (NP*NP each), W (NB/2*256), lam (NP), state (8)
   int count;
 };
 
@@ -54,7 +55,7 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
 }
 inline long psd_scratch_doubles(long n) {
   const long np = psd_np(n);
-  return 2 * np * np + (np / 16) * 256 + np;
+  return 3 * np * np + (np / 16) * 256 + np + 8;
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -152,7 +153,7 @@ __device__ inline void wave_jacobi16(double *S, double *W, double *cs, const uns
 // index of local row/col i (0..15) of the pivot (p,q): block p for i<8, block q otherwise
 __device__ __forceinline__ int pq_index(int i, int p, int q) { return (i < 8 ? p * kPsdB : q * kPsdB - 8) + i; }
 
-__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch) {
+__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: per wave S/transpose scratch (272) + W (256) + cs (16) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
   //      inner N=16 schedule (15*16 bytes)
@@ -173,16 +174,25 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP;
   double *A = scratch + B.woff[cidx];
   double *V = A + (size_t)NP * NP;
-  double *Wg = V + (size_t)NP * NP;  // H pivots' rotation blocks, 256 doubles each (used when H > 16)
+  double *Tm = V + (size_t)NP * NP;  // scaled eigenvectors for the reconstruction / temp of the warm start
+  double *Wg = Tm + (size_t)NP * NP;  // H pivots' rotation blocks, 256 doubles each (used when H > 16)
   double *lam = Wg + (size_t)H * 256;
+  double *state = lam + NP;           // state[0] = number of consecutive warm-started calls (0 = V invalid)
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
   const bool w_in_lds = H <= kPsdWaves;  // pivot k is solved by wave k and its W stays in that wave's LDS
 
-  // ---- unpack (lower tri, col-major, off-diag / sqrt2), V = I, zero padding; inner schedule ----
+  // Warm start.  Inside ADMM the matrix to project moves little between iterations, so the eigenvectors
+  // of the previous call almost diagonalise it: start from A0 = V' A V (two MFMA GEMMs, ~1/4 sweep) and
+  // the Jacobi iteration converges in 1-3 sweeps instead of ~9.  V is refreshed from the identity every
+  // kPsdWarmPeriod calls to stop rounding drift in its orthogonality (each sweep multiplies ~n^2/2 rotations in).
+  const bool warm = allow_warm && state[0] >= 1. && state[0] < (double)kPsdWarmPeriod;
+  __syncthreads();  // everyone has read state[0]
+
+  // ---- unpack (lower tri, col-major, off-diag / sqrt2), zero padding; V = I when cold; inner schedule ----
   for (int e = tid; e < NP * NP; e += kPsdThreads) {
     const int i = e % NP, j = e / NP;
     A[e] = 0.;
-    V[e] = (i == j) ? 1. : 0.;
+    if (!warm) V[e] = (i == j) ? 1. : 0.;
   }
   if (tid < 15 * 8) {
     int p, q;
@@ -205,6 +215,56 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + 272, *csw = Ww + 256;
   const int li = lane & 15, lk = lane >> 4;
   const int nblk = H * (H + 1) / 2, ntile = NP / 16;
+
+  if (warm) {
+    // T = A V   (NN: li runs down rows of A -> coalesced loads; stored through the 16x17 LDS transpose)
+    for (int tile = wave; tile < ntile * ntile; tile += kPsdWaves) {
+      const int ti = tile % ntile, tj = tile / ntile;
+      f64x4 acc = {0., 0., 0., 0.};
+      for (int k0 = 0; k0 < NP; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(ti * 16 + li) + (size_t)ld * (k0 + lk)],
+                                                   V[(k0 + lk) + (size_t)ld * (tj * 16 + li)], acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[t];
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+      wave_sync();
+    }
+    __syncthreads();
+    // A = V' T   (lower-triangular tiles, mirrored: A stays exactly symmetric)
+    for (int tile = wave; tile < ntile * ntile; tile += kPsdWaves) {
+      const int ti = tile % ntile, tj = tile / ntile;
+      if (tj > ti) continue;
+      f64x4 acc = {0., 0., 0., 0.};
+      for (int k0 = 0; k0 < NP; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V[(k0 + lk) + (size_t)ld * (ti * 16 + li)],
+                                                   Tm[(k0 + lk) + (size_t)ld * (tj * 16 + li)], acc, 0, 0, 0);
+      // lane holds R[row = lk + 4t][col = li] of tile (ti, tj)
+      if (ti != tj) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = acc[t];  // mirror
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[t];
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) A[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+      wave_sync();
+    }
+    __syncthreads();
+    // diagonal tiles were written un-symmetrised: average the two triangles inside them
+    for (int e = tid; e < ntile * 256; e += kPsdThreads) {
+      const int t = e >> 8, i = e & 15, j = (e >> 4) & 15;
+      if (i > j) {
+        const size_t a = (size_t)(t * 16 + i) + (size_t)ld * (t * 16 + j), b = (size_t)(t * 16 + j) + (size_t)ld * (t * 16 + i);
+        const double m = 0.5 * (A[a] + A[b]);
+        A[a] = m;
+        A[b] = m;
+      }
+    }
+    __syncthreads();
+  }
 
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     double off = 0., tot = 0.;
@@ -330,12 +390,13 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     }
   }
 
-  // ---- scale eigenvector columns: Wc = V diag(sqrt(lambda+)) so X+ = Wc Wc' ----
+  // ---- scaled eigenvector columns: Wc = V diag(sqrt(lambda+)) so X+ = Wc Wc' (V itself is kept for the next call) ----
   for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? fmax(A[j + (size_t)ld * j], 0.) : 0.;
+  if (tid == 0) state[0] = warm ? state[0] + 1. : 1.;
   __syncthreads();
   for (int e = tid; e < NP * NP; e += kPsdThreads) {
     const int j = e / NP;
-    V[e] *= sqrt(lam[j]);
+    Tm[e] = V[e] * sqrt(lam[j]);
   }
   __syncthreads();
 
@@ -346,8 +407,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     if (tj > ti) continue;
     f64x4 acc = {0., 0., 0., 0.};
     for (int k0 = 0; k0 < NP; k0 += 4) {
-      const double a = V[(ti * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc[i][k]
-      const double b = V[(tj * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc'[k][j] = Wc[j][k]
+      const double a = Tm[(ti * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc[i][k]
+      const double b = Tm[(tj * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc'[k][j] = Wc[j][k]
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
 #pragma unroll

@@ -237,6 +237,7 @@ struct ScsHipWork {
   DevBuf<long> psd_woff;
   DevBuf<double> psd_scratch;
   int n_psd = 0;
+  int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
   // AA (host mirrors the control state; heavy lifting on device)
   int aa_mem = 0, aa_iter = 0, aa_success = 0;
@@ -530,7 +531,7 @@ struct ScsHipWork {
     }
     if (n_psd > 0) {  // self-dual
       PsdBatch B{psd_off.p, psd_order.p, psd_woff.p, n_psd};
-      hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), kPsdLdsBytes, stream, y, B, psd_scratch.p);
+      hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), kPsdLdsBytes, stream, y, B, psd_scratch.p, psd_warm);
     }
     if (cone.ep > 0)  // K = K_exp: dual -> project onto K_exp^*
       hipLaunchKernelGGL(k_proj_exp, dim3(ceil_div(cone.ep, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_ep,
@@ -799,7 +800,7 @@ static void upload_cone_meta(ScsHipWork *w) {
     w->psd_off.upload(poff.data(), poff.size(), s);
     w->psd_order.upload(pord.data(), pord.size(), s);
     w->psd_woff.upload(woff.data(), woff.size(), s);
-    w->psd_scratch.alloc((size_t)std::max(wtot, 1L));
+    w->psd_scratch.alloc_zero((size_t)std::max(wtot, 1L), s);
   }
   HIP_CHECK(hipStreamSynchronize(s));
 }
@@ -1475,6 +1476,7 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
     w.stream = ts.s;
     w.owns_stream = false;
     w.m = m;
+    w.psd_warm = 0;
     upload_cone_meta(&w);
     w.sc.alloc_zero(S_COUNT, ts.s);
     const double one = 1.0;

@@ -273,3 +273,53 @@ def test_equilibration_matches_oracle(hip, oracle, with_P):
             continue
         np.testing.assert_allclose(g, r, rtol=1e-13, atol=0, err_msg=name)
     assert abs(got[6] - ref[6]) <= 1e-13 * ref[6]
+
+
+def _random_cone(rng):
+    """small random mixed cone (every cone type of the path can appear)"""
+    K = {}
+    if rng.rand() < 0.5:
+        K["z"] = int(rng.randint(1, 6))
+    K["l"] = int(rng.randint(3, 25))
+    if rng.rand() < 0.4:
+        nb = int(rng.randint(1, 6))
+        K["bu"] = (rng.rand(nb) + 0.2).tolist()
+        K["bl"] = (-rng.rand(nb) - 0.2).tolist()
+    if rng.rand() < 0.7:
+        K["q"] = [int(t) for t in rng.randint(1, 9, size=rng.randint(1, 4))]
+    if rng.rand() < 0.5:
+        K["s"] = [int(t) for t in rng.randint(1, 7, size=rng.randint(1, 3))]
+    if rng.rand() < 0.4:
+        K["ep"] = int(rng.randint(1, 4))
+    if rng.rand() < 0.4:
+        K["ed"] = int(rng.randint(1, 4))
+    if rng.rand() < 0.4:
+        K["p"] = (rng.uniform(0.15, 0.85, size=rng.randint(1, 4)) * rng.choice([-1.0, 1.0])).tolist()
+    return K
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_mixed_cone_qp_sweep(hip, oracle, seed):
+    """Randomised parity sweep: strictly convex QPs over random cone mixes; x, y, s against the oracle's
+    direct-LDL solve and against the constructed optimum (rtol 1e-4 of the north star)."""
+    rng = np.random.RandomState(1000 + seed)
+    K = _random_cone(rng)
+    m = pg.cone_dims(K)
+    n = m + 2  # n >= m: the active constraint gradients are independent, so y is unique (P > 0 makes x, s unique)
+    data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, n, min(6, m), 2000 + seed, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    got, ref = _solve_both(hip, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved", (K, got["info"], ref["info"])
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+    _assert_xys(got, ref)
+    _assert_xys(got, {"x": x0, "y": y0, "s": s0})
+
+
+def test_psd_heavy_parity(hip, oracle):
+    """config-4 shaped instance at oracle-friendly size: several PSD cones + l, QP for uniqueness."""
+    K = {"l": 40, "s": [24, 17, 30, 9]}
+    m = pg.cone_dims(K)
+    data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, int(0.6 * m), 8, 77, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    got, ref = _solve_both(hip, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _assert_xys(got, ref)
+    _assert_xys(got, {"x": x0, "y": y0, "s": s0})

@@ -224,7 +224,7 @@ struct ScsHipWork {
 
   DevBuf<double> v, v_prev, u, ut, rsk, g, h, diag_r, D, E, Dinv, Einv;
   DevBuf<double> cg_b, cg_p, cg_r, cg_Gp, cg_M, tmp_m, ws, px;
-  DevBuf<double> part, sc, out;
+  DevBuf<double> part, part2, sc, out;  // part2: partials of k_cg_update (read by k_cg_dir while `part` is reused)
   DevBuf<int> fl;
   DevBuf<double> solx, soly, sols;
   int part_len = 0;
@@ -282,8 +282,9 @@ struct ScsHipWork {
   }
 
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
-  void matvec(const double *x, const int *done) {
-    launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, diag_r.p + n}, done, stream);
+  // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
+  void matvec(const double *x, const int *done, int *step_counter = nullptr) {
+    launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, diag_r.p + n}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
     launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, x, diag_r.p, has_P ? 1 : 0, part.p}, done, stream);
   }
@@ -319,12 +320,10 @@ struct ScsHipWork {
   // yacc != nullptr: carry y += alpha R_y^{-1} A p along (ADMM path, see k_prep)
   void enqueue_cg_step(double *xout, double *yacc) {
     const int nb = vb(std::max(n, yacc ? m : 0));
-    matvec(cg_p.p, fl.p + F_DONE);
-    hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
+    matvec(cg_p.p, fl.p + F_DONE, fl.p + F_STEP);
     hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, yacc,
-                       tmp_m.p, m, sc.p, fl.p, part.p);
-    hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
-    hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+                       tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p);
+    hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
   }
   void enqueue_flag_readback() {
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
@@ -367,17 +366,16 @@ struct ScsHipWork {
         for (int it = 0; it < chunk; ++it) {
           if (profile && it == sample_it) {
             HIP_CHECK(hipEventRecord(ev[0], stream));
-            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream);
+            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream, fl.p + F_STEP);
             HIP_CHECK(hipEventRecord(ev[1], stream));
             if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
             launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
             HIP_CHECK(hipEventRecord(ev[2], stream));
             const int nb = vb(std::max(n, yacc ? m : 0));
-            hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), sc.p, fl.p);
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
-                               yacc, tmp_m.p, m, sc.p, fl.p, part.p);
-            hipLaunchKernelGGL(k_fin_beta, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, sc.p, fl.p);
-            hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, sc.p, fl.p);
+                               yacc, tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p);
+            hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p,
+                               fl.p);
           } else {
             enqueue_cg_step(xout, yacc);
           }
@@ -976,6 +974,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->At.nwg(), w->Ar.nwg(), w->has_P ? std::max(w->Pf.nblk, w->Pf.nwg()) : 0, kMaxVecBlocks}) * 8;
   w->part_len = std::max(w->part_len, 3 * kAaMaxMem * kMaxVecBlocks);
   w->part.alloc_zero(w->part_len, s);
+  w->part2.alloc_zero(2 * kMaxVecBlocks, s);
   w->sc.alloc_zero(S_COUNT, s);
   w->out.alloc_zero(256, s);
   w->fl.alloc_zero(F_COUNT, s);
@@ -1529,6 +1528,7 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
     for (DevBuf<double> *b : {&w.cg_b, &w.cg_p, &w.cg_r, &w.cg_Gp, &w.cg_M, &w.ws}) b->alloc_zero(n, s);
     w.tmp_m.alloc_zero(m, s);
     w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, w.At.nwg(), w.Ar.nwg(), kMaxVecBlocks}) * 8, s);
+    w.part2.alloc_zero(2 * kMaxVecBlocks, s);
     w.sc.alloc_zero(S_COUNT, s);
     w.fl.alloc_zero(F_COUNT, s);
     hipLaunchKernelGGL(k_precond, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w.At.rowptr.p, w.At.col.p, w.At.val.p,

@@ -175,8 +175,9 @@ struct EpiResDual {
 
 template <class Epi>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi,
-                                                               const int *done_flag) {
+                                                               const int *done_flag, int *step_counter) {
   if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
   __shared__ double prod[kNnzPerWg];
   __shared__ double red[kSpmvThreads / 64];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -379,8 +380,9 @@ __device__ __forceinline__ void slab_stage(const SlabRegs<NQ> &r, double *prod, 
 
 template <class Epi, int RPT, int STAGE>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const double *__restrict__ x, Epi epi,
-                                                             const int *done_flag) {
+                                                             const int *done_flag, int *step_counter) {
   if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
   constexpr int R = kSpmvThreads * RPT;
   constexpr int NQ = STAGE / 4 / kSpmvThreads;
   __shared__ __attribute__((aligned(16))) double prod[STAGE];
@@ -494,19 +496,20 @@ struct SpmvMat {
 };
 
 template <class Epi>
-inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s) {
+inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
+                        int *step_counter = nullptr) {
   if (M.use_slab) {
     if (M.slab.nchunks <= 0) return;
     const dim3 g(M.slab.nchunks), b(kSpmvThreads);
-    if (M.slab.R == 256) hipLaunchKernelGGL((k_spmv_slab<Epi, 1, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
-    else if (M.slab.R == 512) hipLaunchKernelGGL((k_spmv_slab<Epi, 2, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
-    else if (M.slab.R == 1024) hipLaunchKernelGGL((k_spmv_slab<Epi, 4, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
-    else if (M.slab.R == 2048) hipLaunchKernelGGL((k_spmv_slab<Epi, 8, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
-    else hipLaunchKernelGGL((k_spmv_slab<Epi, 16, 2 * kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag);
+    if (M.slab.R == 256) hipLaunchKernelGGL((k_spmv_slab<Epi, 1, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag, step_counter);
+    else if (M.slab.R == 512) hipLaunchKernelGGL((k_spmv_slab<Epi, 2, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag, step_counter);
+    else if (M.slab.R == 1024) hipLaunchKernelGGL((k_spmv_slab<Epi, 4, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag, step_counter);
+    else if (M.slab.R == 2048) hipLaunchKernelGGL((k_spmv_slab<Epi, 8, kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag, step_counter);
+    else hipLaunchKernelGGL((k_spmv_slab<Epi, 16, 2 * kSlabStage>), g, b, 0, s, M.slab, x, epi, done_flag, step_counter);
     return;
   }
   if (M.csr.nblk <= 0) return;
-  hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(M.csr.nblk), dim3(kSpmvThreads), 0, s, M.csr, x, epi, done_flag);
+  hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(M.csr.nblk), dim3(kSpmvThreads), 0, s, M.csr, x, epi, done_flag, step_counter);
 }
 
 }  // namespace scship

@@ -17,13 +17,13 @@ constexpr int kMaxVecBlocks = 2048;
 
 // device scalar slots (double)
 enum : int {
-  S_ZTR = 0, S_ALPHA, S_BETA, S_TOL, S_RNORM, S_TAUT, S_VSCALE, S_GG, S_WSNORM, S_AA_NORMG, S_AA_NORMD,
+  S_ZTR = 0, S_ZTR_B, S_ALPHA, S_BETA, S_TOL, S_RNORM, S_TAUT, S_VSCALE, S_GG, S_WSNORM, S_AA_NORMG, S_AA_NORMD,
   S_AA_NORM, S_AA_REG, S_BOX_T, S_TMP0, S_TMP1, S_TMP2, S_TMP3, S_COUNT = 32
 };
 // device flag slots (int)
 enum : int {
   F_DONE = 0, F_ITERS, F_AA_SUCCESS, F_AA_ITER, F_AA_ACCEPT, F_AA_REJ_LAPACK, F_AA_REJ_RANK0, F_AA_REJ_NONFINITE,
-  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_COUNT = 32
+  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_COUNT = 32
 };
 
 // per-iteration host scalars, kept in mapped pinned memory so that captured hipGraphs stay static
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part,
   const double ztr = part_sum(sum_first ? part : part + np, np, sm);
   if (threadIdx.x == 0) {
     sc[S_RNORM] = rn;
-    sc[S_ZTR] = ztr;
+    sc[((fl[F_STEP] + 1) & 1) ? S_ZTR_B : S_ZTR] = ztr;  // the first CG step bumps F_STEP, then reads this slot
     if (rn < fmax(sc[S_TOL], 1e-12)) fl[F_DONE] = 1;
   }
 }
@@ -177,24 +177,30 @@ __global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n,
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) x[i] = 0.;
 }
 
-// alpha = z'r / p'Gp
-__global__ __launch_bounds__(kVecThreads) void k_fin_alpha(const double *part, int np, double *sc, const int *fl) {
-  if (fl[F_DONE]) return;
-  __shared__ double sm[kVecThreads / 64];
-  const double pGp = part_sum(part, np, sm);
-  if (threadIdx.x == 0) sc[S_ALPHA] = sc[S_ZTR] / pGp;
-}
-
 // x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r].
 // With yacc != nullptr also y += alpha z (z = R_y^{-1} A p of this step): the y-block of the KKT solution
 // y = R_y^{-1}(A x - r_y) is carried along the CG recurrence instead of a final A x product.
+// alpha = z'r / p'Gp is formed in the prologue: every workgroup reduces the p'Gp partials of the A' kernel
+// itself (a few hundred L2-resident doubles, fixed order => identical alpha everywhere), so no separate
+// single-workgroup "finalize" launch sits between the SpMV and this kernel.  z'r comes from the slot of the
+// current CG step (two slots, selected by F_STEP, which workgroup 0 of the A kernel bumps once per step).
 __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
                                                            const double *__restrict__ Gp, const double *__restrict__ M,
                                                            int n, double *yacc, const double *__restrict__ z, int m,
-                                                           const double *sc, const int *fl, double *part) {
+                                                           const double *pgp_part, int pgp_np, double *sc, const int *fl,
+                                                           double *part) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
-  const double alpha = sc[S_ALPHA];
+  __shared__ double bc;
+  {
+    const double pGp = part_sum(pgp_part, pgp_np, sm);
+    if (threadIdx.x == 0) {
+      bc = sc[(fl[F_STEP] & 1) ? S_ZTR_B : S_ZTR] / pGp;
+      if (blockIdx.x == 0) sc[S_ALPHA] = bc;
+    }
+    __syncthreads();
+  }
+  const double alpha = bc;
   double mx = 0., s = 0.;
   if (yacc)
     for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
@@ -214,26 +220,33 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r,
   }
 }
 
-// beta = ztr_new / ztr; convergence test on ||r||_inf
-__global__ __launch_bounds__(kVecThreads) void k_fin_beta(const double *part, int np, double *sc, int *fl) {
+// p = M r + beta p.  beta = z'r(new) / z'r(old) and the convergence test are formed in the prologue from the
+// partials of k_cg_update (every workgroup reduces them in the same fixed order); workgroup 0 then does the
+// bookkeeping for the step: new z'r into the OTHER slot (nobody reads that one during this launch),
+// ||r||_inf, the CG step counter and the done flag (p is dead once the flag is set).
+__global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r, const double *__restrict__ M,
+                                                        int n, const double *upd_part, int upd_np, double *sc, int *fl) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
-  const double rn = part_max(part, np, sm);
-  const double ztr = part_sum(part + np, np, sm);
-  if (threadIdx.x == 0) {
-    sc[S_RNORM] = rn;
-    sc[S_BETA] = ztr / sc[S_ZTR];
-    sc[S_ZTR] = ztr;
-    fl[F_ITERS] += 1;
-    if (rn < sc[S_TOL]) fl[F_DONE] = 1;
+  __shared__ double bc[2];
+  const int slot = fl[F_STEP] & 1;
+  {
+    const double rn = part_max(upd_part, upd_np, sm);
+    const double ztr = part_sum(upd_part + upd_np, upd_np, sm);
+    if (threadIdx.x == 0) {
+      bc[0] = ztr / sc[slot ? S_ZTR_B : S_ZTR];
+      bc[1] = ztr;
+      if (blockIdx.x == 0) {
+        sc[S_RNORM] = rn;
+        sc[S_BETA] = bc[0];
+        sc[slot ? S_ZTR : S_ZTR_B] = ztr;
+        fl[F_ITERS] += 1;
+        if (rn < sc[S_TOL]) fl[F_DONE] = 1;
+      }
+    }
+    __syncthreads();
   }
-}
-
-// p = M r + beta p
-__global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r, const double *__restrict__ M,
-                                                        int n, const double *sc, const int *fl) {
-  if (fl[F_DONE]) return;
-  const double beta = sc[S_BETA];
+  const double beta = bc[0];
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
     p[i] = M[i] * r[i] + beta * p[i];
 }

@@ -65,7 +65,7 @@ typedef struct {
   scs_int qsize;
   scs_int *s;    /* PSD matrix orders (vec len k(k+1)/2)     :730     */
   scs_int ssize;
-  scs_int *cs;   /* complex PSD orders (vec len k*k)         :734-737 */
+  scs_int *cs;   /* complex PSD orders (vec len k*k: H_jj, then sqrt2 Re, sqrt2 Im of H_ij, i>j, by column) :734-737 */
   scs_int cssize;
   scs_int ep;    /* primal exponential triples               :742     */
   scs_int ed;    /* dual exponential triples                 :746     */

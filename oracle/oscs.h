@@ -87,6 +87,7 @@ void o_proj_exp_cone(scs_float *v, int primal);
 void o_proj_power_cone(scs_float *v, scs_float a);
 void o_proj_soc(scs_float *x, scs_int q);
 scs_int o_proj_psd(scs_float *X, scs_int n, OConeWork *c);
+scs_int o_proj_cpsd(scs_float *X, scs_int n, OConeWork *c);
 /* symmetric eigen-decomposition (cyclic Jacobi), A n*n col-major in, eigvecs in V, eigvals in e */
 void o_sym_eig(scs_float *A, scs_int n, scs_float *V, scs_float *e);
 

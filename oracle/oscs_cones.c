@@ -3,13 +3,19 @@
  *
  * Restates scs_source/src/cones.c and exp_cone.c (named at R:meson.build:188,190;
  * sources absent).  Behavioural spec that IS in the reference:
- *   - cone order z,l,[box],q,s,ep,ed,p and slice layout: R:test/gen_random_cone_prob.py:90-130
+ *   - cone order z,l,[box],q,s,[cs],ep,ed,p and slice layout: R:test/gen_random_cone_prob.py:90-130
  *   - SOC (t first):                                     R:test/gen_random_cone_prob.py:133-150
  *   - PSD vec = lower-tri col-major, off-diag * sqrt(2): R:test/gen_random_cone_prob.py:153-173
  *   - power cone Newton on r:                            R:test/gen_random_cone_prob.py:176-231
  *   - exp cone (r,s,t), s*exp(r/s) <= t:                 R:test/gen_random_cone_prob.py:234-315
  *   - box cone (t,s), bl*t <= s <= bu*t, dim len(bu)+1:  R:scs/scsobject.h:710-724,
  *                                                        R:test/test_scs_coverage.py:553-560
+ *   - complex PSD cone `cs`, k*k reals per order-k Hermitian matrix, after `s`:
+ *                                                        R:scs/scsobject.h:734-737,
+ *                                                        R:test/test_spectral_and_complex_cones.py:22-24,
+ *                                                        R:test/test_mix_sd_csd_cone.py:34-35
+ *     (element order inside the k*k slice is NOT evidenced in the reference: UPSTREAM-RECALL of the
+ *     SCS docs — lower triangle, column by column: H_jj, then sqrt2*Re H_ij, sqrt2*Im H_ij for i>j)
  * The exp-cone projection uses the univariate root-finding formulation of
  * Friberg (2021, "Projection onto the exponential cone: a univariate
  * root-finding problem"), which is what SCS >= 3.2 documents; the reference's
@@ -38,7 +44,8 @@ scs_int o_cone_dims(const ScsCone *k) {
 scs_int o_validate_cone(const ScsCone *k) {
   scs_int i;
   if (k->z < 0 || k->l < 0 || k->bsize < 0 || k->ep < 0 || k->ed < 0) return -1;
-  if (k->cssize > 0) return -1; /* complex PSD: SURVEY §8f "next" */
+  for (i = 0; i < k->cssize; ++i)
+    if (k->cs[i] < 0) return -1;
   for (i = 0; i < k->bsize - 1; ++i)
     if (k->bl[i] > k->bu[i]) return -1;
   for (i = 0; i < k->qsize; ++i)
@@ -70,21 +77,23 @@ OConeWork *o_init_cone(const ScsCone *k, scs_int m) {
   if (k->ssize) memcpy(c->k.s, k->s, k->ssize * sizeof(scs_int));
   c->k.p = (scs_float *)malloc(OMAX(k->psize, 1) * sizeof(scs_float));
   if (k->psize) memcpy(c->k.p, k->p, k->psize * sizeof(scs_float));
-  c->k.cs = NULL;
-  c->k.cssize = 0;
+  c->k.cs = (scs_int *)malloc(OMAX(k->cssize, 1) * sizeof(scs_int));
+  if (k->cssize) memcpy(c->k.cs, k->cs, k->cssize * sizeof(scs_int));
   /* boundaries: rows that can be scaled independently first, then one block per
    * non-separable cone */
-  c->n_boundaries = 1 + k->qsize + k->ssize + k->ep + k->ed + k->psize;
+  c->n_boundaries = 1 + k->qsize + k->ssize + k->cssize + k->ep + k->ed + k->psize;
   c->boundaries = (scs_int *)calloc(c->n_boundaries, sizeof(scs_int));
   cnt = 0;
   c->boundaries[cnt++] = k->z + k->l + k->bsize;
   for (i = 0; i < k->qsize; ++i) c->boundaries[cnt++] = k->q[i];
   for (i = 0; i < k->ssize; ++i) c->boundaries[cnt++] = sd_size(k->s[i]);
+  for (i = 0; i < k->cssize; ++i) c->boundaries[cnt++] = k->cs[i] * k->cs[i];
   for (i = 0; i < k->ep + k->ed + k->psize; ++i) c->boundaries[cnt++] = 3;
   c->s = (scs_float *)calloc(OMAX(m, 1), sizeof(scs_float));
   c->box_t_warm = 1.;
   c->max_s = 0;
   for (i = 0; i < k->ssize; ++i) c->max_s = OMAX(c->max_s, k->s[i]);
+  for (i = 0; i < k->cssize; ++i) c->max_s = OMAX(c->max_s, 2 * k->cs[i]); /* real embedding is 2k x 2k */
   if (c->max_s > 0) {
     size_t n2 = (size_t)c->max_s * c->max_s;
     c->Xs = (scs_float *)calloc(n2, sizeof(scs_float));
@@ -96,7 +105,7 @@ OConeWork *o_init_cone(const ScsCone *k, scs_int m) {
 
 void o_free_cone(OConeWork *c) {
   if (!c) return;
-  free(c->k.bu); free(c->k.bl); free(c->k.q); free(c->k.s); free(c->k.p);
+  free(c->k.bu); free(c->k.bl); free(c->k.q); free(c->k.s); free(c->k.cs); free(c->k.p);
   free(c->boundaries); free(c->s); free(c->Xs); free(c->Vs); free(c->es);
   free(c);
 }
@@ -209,6 +218,46 @@ scs_int o_proj_psd(scs_float *X, scs_int n, OConeWork *c) {
   k = 0;
   for (j = 0; j < n; ++j)
     for (i = j; i < n; ++i) X[k++] = (i == j) ? Xs[i + n * j] : Xs[i + n * j] * sqrt2;
+  return 0;
+}
+
+/* Hermitian PSD cone.  H = A + iB (A symmetric, B antisymmetric) is PSD iff the real symmetric
+ * M = [[A, -B], [B, A]] is, and Pi(M) = [[A+, -B+], [B+, A+]]: project the 2n x 2n embedding with the
+ * real routine and read H+ back from its first block column. */
+scs_int o_proj_cpsd(scs_float *X, scs_int n, OConeWork *c) {
+  scs_int i, j, k, N = 2 * n;
+  const scs_float sqrt2 = sqrt(2.0), isqrt2 = 1.0 / sqrt(2.0);
+  if (n == 0) return 0;
+  if (n == 1) { X[0] = OMAX(X[0], 0.); return 0; }
+  scs_float *M = c->Xs, *V = c->Vs, *e = c->es;
+  memset(M, 0, (size_t)N * N * sizeof(scs_float));
+  k = 0;
+  for (j = 0; j < n; ++j) {
+    M[j + N * j] = M[(n + j) + N * (n + j)] = X[k++];
+    for (i = j + 1; i < n; ++i) {
+      const scs_float re = X[k++] * isqrt2, im = X[k++] * isqrt2;
+      M[i + N * j] = M[j + N * i] = re;                         /* A */
+      M[(n + i) + N * (n + j)] = M[(n + j) + N * (n + i)] = re; /* A */
+      M[(n + i) + N * j] = M[j + N * (n + i)] = im;             /* B_ij  (lower-left block) */
+      M[(n + j) + N * i] = M[i + N * (n + j)] = -im;            /* B_ji = -B_ij */
+    }
+  }
+  o_sym_eig(M, N, V, e);
+  k = 0;
+  for (j = 0; j < n; ++j) {
+    for (i = j; i < n; ++i) {
+      scs_float re = 0., im = 0.;
+      scs_int q;
+      for (q = 0; q < N; ++q) {
+        if (e[q] <= 0) continue;
+        const scs_float *v = &V[(size_t)N * q];
+        re += e[q] * v[i] * v[j];
+        im += e[q] * v[n + i] * v[j];
+      }
+      if (i == j) X[k++] = re;
+      else { X[k++] = re * sqrt2; X[k++] = im * sqrt2; }
+    }
+  }
   return 0;
 }
 
@@ -508,6 +557,10 @@ scs_int o_proj_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
   for (i = 0; i < k->ssize; ++i) {
     o_proj_psd(&x[count], k->s[i], c);
     count += sd_size(k->s[i]);
+  }
+  for (i = 0; i < k->cssize; ++i) {
+    o_proj_cpsd(&x[count], k->cs[i], c);
+    count += k->cs[i] * k->cs[i];
   }
   for (i = 0; i < k->ep; ++i) { o_proj_exp_cone(&x[count], 1); count += 3; }
   for (i = 0; i < k->ed; ++i) { o_proj_exp_cone(&x[count], 0); count += 3; }

@@ -24,6 +24,7 @@ def cone_dims(K):
     m += nb + 1 if nb else 0
     m += int(sum(K.get("q", [])))
     m += int(sum(int(s) * (int(s) + 1) // 2 for s in K.get("s", [])))
+    m += int(sum(int(s) * int(s) for s in K.get("cs", [])))
     m += 3 * (int(K.get("ep", 0)) + int(K.get("ed", 0)) + len(K.get("p", [])))
     return m
 

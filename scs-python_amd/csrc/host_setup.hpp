@@ -27,10 +27,10 @@ struct HostCsr {
 struct HostCone {
   int z = 0, l = 0, bsize = 0, ep = 0, ed = 0;
   std::vector<double> bu, bl, p;
-  std::vector<int> q, s;
-  std::vector<int> boundaries;  // [z+l+bsize, q..., s(s+1)/2..., 3 x (ep+ed+psize)]
+  std::vector<int> q, s, cs;
+  std::vector<int> boundaries;  // [z+l+bsize, q..., s(s+1)/2..., cs^2..., 3 x (ep+ed+psize)]
   int m = 0;
-  int off_box = 0, off_q = 0, off_s = 0, off_ep = 0, off_ed = 0, off_p = 0;
+  int off_box = 0, off_q = 0, off_s = 0, off_cs = 0, off_ep = 0, off_ed = 0, off_p = 0;
 };
 
 inline long sd_size(long s) { return s * (s + 1) / 2; }
@@ -38,7 +38,6 @@ inline long sd_size(long s) { return s * (s + 1) / 2; }
 inline bool build_cone(const ScsCone *k, HostCone &c) {
   if (k->z < 0 || k->l < 0 || k->bsize < 0 || k->ep < 0 || k->ed < 0) return false;
   if (k->qsize < 0 || k->ssize < 0 || k->psize < 0 || k->cssize < 0) return false;
-  if (k->cssize > 0) return false;  // complex PSD cone: SURVEY §8f "next"
   c.z = k->z; c.l = k->l; c.bsize = k->bsize; c.ep = k->ep; c.ed = k->ed;
   if (k->bsize > 1) {
     c.bu.assign(k->bu, k->bu + k->bsize - 1);
@@ -48,14 +47,17 @@ inline bool build_cone(const ScsCone *k, HostCone &c) {
   }
   if (k->qsize) c.q.assign(k->q, k->q + k->qsize);
   if (k->ssize) c.s.assign(k->s, k->s + k->ssize);
+  if (k->cssize) c.cs.assign(k->cs, k->cs + k->cssize);
   if (k->psize) c.p.assign(k->p, k->p + k->psize);
   for (int q : c.q) if (q < 0) return false;
   for (int s : c.s) if (s < 0 || s > 1024) return false;
+  for (int s : c.cs) if (s < 0 || s > 512) return false;  // projected through its 2k x 2k real embedding
   for (double p : c.p) if (!(p >= -1 && p <= 1)) return false;
   long cnt = (long)c.z + c.l;
   c.off_box = (int)cnt; cnt += c.bsize;
   c.off_q = (int)cnt; for (int q : c.q) cnt += q;
   c.off_s = (int)cnt; for (int s : c.s) cnt += sd_size(s);
+  c.off_cs = (int)cnt; for (int s : c.cs) cnt += (long)s * s;
   c.off_ep = (int)cnt; cnt += 3L * c.ep;
   c.off_ed = (int)cnt; cnt += 3L * c.ed;
   c.off_p = (int)cnt; cnt += 3L * (long)c.p.size();
@@ -65,6 +67,7 @@ inline bool build_cone(const ScsCone *k, HostCone &c) {
   c.boundaries.push_back(c.z + c.l + c.bsize);
   for (int q : c.q) c.boundaries.push_back(q);
   for (int s : c.s) c.boundaries.push_back((int)sd_size(s));
+  for (int s : c.cs) c.boundaries.push_back(s * s);
   for (int i = 0; i < c.ep + c.ed + (int)c.p.size(); ++i) c.boundaries.push_back(3);
   return true;
 }

@@ -422,4 +422,63 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Complex PSD cone `cs` (R:scs/scsobject.h:734-737; k*k reals per order-k Hermitian matrix,
+// R:test/test_spectral_and_complex_cones.py:22-24, R:test/test_mix_sd_csd_cone.py:34-35).
+// Element order inside the slice (UPSTREAM-RECALL, not evidenced in the reference): lower triangle,
+// column by column: H_jj, then (sqrt2 Re H_ij, sqrt2 Im H_ij) for i > j.
+// H = A + iB is PSD iff the real symmetric M = [[A, -B], [B, A]] is, and Pi(M) = [[A+, -B+], [B+, A+]]:
+// the slice is expanded into the packed vector of the 2k x 2k embedding, projected by k_proj_psd
+// (same MFMA kernel, same warm start), and read back (averaging the two copies of every entry).
+// Both layouts carry the sqrt(2) on off-diagonals, so the expansion is a signed copy.
+// ---------------------------------------------------------------------------
+struct CsBatch {
+  const int *off;     // start of each cone's k*k slice inside the m-vector slice
+  const int *order;   // k
+  const long *soff;   // start of the packed 2k x 2k embedding inside the staging buffer
+  int count;
+};
+
+__device__ __forceinline__ long cs_col_start(long j, long k) { return j * (2 * k - j); }
+__device__ __forceinline__ long packed_idx(long I, long J, long N) { return J * N - J * (J - 1) / 2 + (I - J); }  // I >= J
+
+__global__ __launch_bounds__(256) void k_cs_expand(const double *__restrict__ x, CsBatch B, double *stage) {
+  const int c = blockIdx.x;
+  const long k = B.order[c], N = 2 * k;
+  const double *X = x + B.off[c];
+  double *P = stage + B.soff[c];
+  for (long e = threadIdx.x; e < N * N; e += blockDim.x) {
+    const long J = e / N, I = e % N;
+    if (I < J) continue;
+    const long i = I < k ? I : I - k, j = J < k ? J : J - k;
+    double v;
+    if ((I < k) == (J < k)) {  // diagonal blocks: A (i >= j here)
+      v = (i == j) ? X[cs_col_start(j, k)] : X[cs_col_start(j, k) + 1 + 2 * (i - j - 1)];
+    } else {  // lower-left block: B_ij, antisymmetric
+      if (i == j) v = 0.;
+      else if (i > j) v = X[cs_col_start(j, k) + 2 + 2 * (i - j - 1)];
+      else v = -X[cs_col_start(i, k) + 2 + 2 * (j - i - 1)];
+    }
+    P[packed_idx(I, J, N)] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cs_extract(double *x, CsBatch B, const double *__restrict__ stage) {
+  const int c = blockIdx.x;
+  const long k = B.order[c], N = 2 * k;
+  double *X = x + B.off[c];
+  const double *P = stage + B.soff[c];
+  for (long e = threadIdx.x; e < k * k; e += blockDim.x) {
+    const long j = e / k, i = e % k;
+    if (i < j) continue;
+    const long cj = cs_col_start(j, k);
+    if (i == j) {
+      X[cj] = 0.5 * (P[packed_idx(j, j, N)] + P[packed_idx(k + j, k + j, N)]);
+    } else {
+      X[cj + 1 + 2 * (i - j - 1)] = 0.5 * (P[packed_idx(i, j, N)] + P[packed_idx(k + i, k + j, N)]);
+      X[cj + 2 + 2 * (i - j - 1)] = 0.5 * (P[packed_idx(k + i, j, N)] - P[packed_idx(k + j, i, N)]);
+    }
+  }
+}
+
 }  // namespace scship

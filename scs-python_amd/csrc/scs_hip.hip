@@ -237,6 +237,11 @@ struct ScsHipWork {
   DevBuf<long> psd_woff;
   DevBuf<double> psd_scratch;
   int n_psd = 0;
+  // complex PSD cones: projected through the packed 2k x 2k real embedding held in cs_stage (psd.hpp)
+  DevBuf<int> cs_off, cs_order, cs_poff, cs_porder;
+  DevBuf<long> cs_soff, cs_woff;
+  DevBuf<double> cs_stage;
+  int n_cs = 0;
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
   // AA (host mirrors the control state; heavy lifting on device)
@@ -531,6 +536,13 @@ struct ScsHipWork {
       PsdBatch B{psd_off.p, psd_order.p, psd_woff.p, n_psd};
       hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), kPsdLdsBytes, stream, y, B, psd_scratch.p, psd_warm);
     }
+    if (n_cs > 0) {  // Hermitian PSD: self-dual
+      CsBatch C{cs_off.p, cs_order.p, cs_soff.p, n_cs};
+      PsdBatch B{cs_poff.p, cs_porder.p, cs_woff.p, n_cs};
+      hipLaunchKernelGGL(k_cs_expand, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
+      hipLaunchKernelGGL(k_proj_psd, dim3(n_cs), dim3(kPsdThreads), kPsdLdsBytes, stream, cs_stage.p, B, psd_scratch.p, psd_warm);
+      hipLaunchKernelGGL(k_cs_extract, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
+    }
     if (cone.ep > 0)  // K = K_exp: dual -> project onto K_exp^*
       hipLaunchKernelGGL(k_proj_exp, dim3(ceil_div(cone.ep, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_ep,
                          cone.ep, dual ? 0 : 1);
@@ -798,8 +810,33 @@ static void upload_cone_meta(ScsHipWork *w) {
     w->psd_off.upload(poff.data(), poff.size(), s);
     w->psd_order.upload(pord.data(), pord.size(), s);
     w->psd_woff.upload(woff.data(), woff.size(), s);
-    w->psd_scratch.alloc_zero((size_t)std::max(wtot, 1L), s);
   }
+  std::vector<int> coff, cord, cpoff, cpord;
+  std::vector<long> csoff, cwoff;
+  long stot = 0;
+  o = c.off_cs;
+  for (int k : c.cs) {
+    coff.push_back(o);
+    cord.push_back(k);
+    csoff.push_back(stot);
+    cpoff.push_back((int)stot);
+    cpord.push_back(2 * k);
+    cwoff.push_back(wtot);
+    wtot += psd_scratch_doubles(2 * k);
+    stot += sd_size(2 * k);
+    o += k * k;
+  }
+  w->n_cs = (int)coff.size();
+  if (w->n_cs) {
+    w->cs_off.upload(coff.data(), coff.size(), s);
+    w->cs_order.upload(cord.data(), cord.size(), s);
+    w->cs_soff.upload(csoff.data(), csoff.size(), s);
+    w->cs_poff.upload(cpoff.data(), cpoff.size(), s);
+    w->cs_porder.upload(cpord.data(), cpord.size(), s);
+    w->cs_woff.upload(cwoff.data(), cwoff.size(), s);
+    w->cs_stage.alloc_zero((size_t)std::max(stot, 1L), s);
+  }
+  if (w->n_psd || w->n_cs) w->psd_scratch.alloc_zero((size_t)std::max(wtot, 1L), s);
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -807,7 +844,7 @@ static void upload_cone_meta(ScsHipWork *w) {
 // Self-describing little-endian dump of (settings, cone, data) taken BEFORE equilibration, so that an instance
 // can be replayed.  Layout: magic "SCSHIP01", then records  <u32 tag><u64 count><payload>  with tags
 // 1 dims(i32 m,n) 2 settings(f64 x 16, field order of ScsSettings without the file names) 3 cone scalars (i32 z,l,bsize,ep,ed)
-// 4 bu 5 bl 6 q 7 s 8 p 9 b 10 c 11 A.x 12 A.i 13 A.p 14 P.x 15 P.i 16 P.p   (f64 or i32 arrays).
+// 4 bu 5 bl 6 q 7 s 8 p 9 b 10 c 11 A.x 12 A.i 13 A.p 14 P.x 15 P.i 16 P.p 17 cs  (f64 or i32 arrays).
 static void write_record(FILE *f, unsigned tag, const void *ptr, size_t count, size_t elem) {
   const unsigned long long c = count;
   std::fwrite(&tag, sizeof(tag), 1, f);
@@ -833,6 +870,7 @@ static void write_problem_data(const char *fname, const ScsData *d, const ScsCon
   write_record(f, 6, k->q, (size_t)k->qsize, sizeof(int));
   write_record(f, 7, k->s, (size_t)k->ssize, sizeof(int));
   write_record(f, 8, k->p, (size_t)k->psize, sizeof(double));
+  if (k->cssize) write_record(f, 17, k->cs, (size_t)k->cssize, sizeof(int));
   write_record(f, 9, d->b, (size_t)d->m, sizeof(double));
   write_record(f, 10, d->c, (size_t)d->n, sizeof(double));
   write_record(f, 11, d->A->x, (size_t)d->A->p[d->n], sizeof(double));
@@ -1078,8 +1116,9 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     std::printf("\t  scs-hip v%s - MI355X-native Splitting Conic Solver path\n", scs_version());
     std::printf("------------------------------------------------------------------\n");
     std::printf("problem:  variables n: %d, constraints m: %d\n", n, m);
-    std::printf("cones: \t  z: %d, l: %d, box: %d, q: %zu, s: %zu, ep: %d, ed: %d, p: %zu\n", w->cone.z, w->cone.l,
-                w->cone.bsize, w->cone.q.size(), w->cone.s.size(), w->cone.ep, w->cone.ed, w->cone.p.size());
+    std::printf("cones: \t  z: %d, l: %d, box: %d, q: %zu, s: %zu, cs: %zu, ep: %d, ed: %d, p: %zu\n", w->cone.z, w->cone.l,
+                w->cone.bsize, w->cone.q.size(), w->cone.s.size(), w->cone.cs.size(), w->cone.ep, w->cone.ed,
+                w->cone.p.size());
     std::printf("settings: eps_abs: %.1e, eps_rel: %.1e, eps_infeas: %.1e\n\t  alpha: %.2f, scale: %.2e, adaptive_scale: %d\n"
                 "\t  max_iters: %d, normalize: %d, rho_x: %.2e\n\t  acceleration_lookback: %d, acceleration_interval: %d\n",
                 w->stgs.eps_abs, w->stgs.eps_rel, w->stgs.eps_infeas, w->stgs.alpha, w->scale, w->stgs.adaptive_scale,

@@ -54,3 +54,38 @@ def kkt_certificate(data, sol, P=None):
     dual = np.abs(px + A.T @ y + c).max()
     gap = abs((x @ px if P is not None else 0.0) + c @ x + b @ y)
     return pri, dual, gap
+
+
+def cvec_to_herm(v, k):
+    """k*k slice of the complex PSD cone `cs` -> Hermitian matrix (layout: oracle/oscs_cones.c header)."""
+    import numpy as np
+    H = np.zeros((k, k), dtype=complex)
+    p = 0
+    for j in range(k):
+        H[j, j] = v[p]
+        p += 1
+        for i in range(j + 1, k):
+            H[i, j] = (v[p] + 1j * v[p + 1]) / np.sqrt(2.0)
+            H[j, i] = np.conj(H[i, j])
+            p += 2
+    return H
+
+
+def herm_to_cvec(H):
+    import numpy as np
+    k = H.shape[0]
+    out = []
+    for j in range(k):
+        out.append(H[j, j].real)
+        for i in range(j + 1, k):
+            out += [np.sqrt(2.0) * H[i, j].real, np.sqrt(2.0) * H[i, j].imag]
+    return np.array(out, dtype=np.float64)
+
+
+def proj_hermitian_psd(v, k):
+    """independent check of the `cs` projection: numpy's complex Hermitian eigensolver"""
+    import numpy as np
+    if k == 0:
+        return np.zeros(0)
+    w, U = np.linalg.eigh(cvec_to_herm(v, k))
+    return herm_to_cvec((U * np.maximum(w, 0.0)) @ U.conj().T)

@@ -323,3 +323,62 @@ def test_psd_heavy_parity(hip, oracle):
     assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
     _assert_xys(got, ref)
     _assert_xys(got, {"x": x0, "y": y0, "s": s0})
+
+
+# ---- complex PSD cone `cs` ---------------------------------------------------------------------
+@pytest.mark.parametrize("orders", [[1], [2], [3], [5, 4], [8, 1, 0, 13], [40], [100]])
+def test_cs_projection_vs_oracle_and_complex_eigh(hip, oracle, orders):
+    rng = np.random.RandomState(sum(orders))
+    K = {"l": 3, "cs": orders}
+    m = pg.cone_dims(K)
+    for scl in (1.0, 30.0):
+        z = scl * rng.randn(m)
+        for dual in (False, True):
+            got = hip.proj_cone(z, K, dual=dual)
+            if max(orders) <= 40:  # the oracle's cyclic Jacobi on the 2k x 2k embedding is slow beyond that
+                np.testing.assert_allclose(got, oracle.proj_cone(z, K, dual=dual), rtol=0, atol=1e-9 * scl * max(orders))
+            o = 3
+            for k in orders:  # independent check: numpy's complex Hermitian eigensolver
+                np.testing.assert_allclose(got[o:o + k * k], helpers.proj_hermitian_psd(z[o:o + k * k], k), rtol=0,
+                                           atol=1e-9 * scl * max(k, 1))
+                o += k * k
+
+
+def _cs_qp(cone, seed, density, p_scale):
+    """instance construction of the reference's cs tests (R:test/test_spectral_and_complex_cones.py:55-71)"""
+    rng = np.random.RandomState(seed)
+    m = pg.cone_dims(cone)
+    P = p_scale * sparse.eye(m, format="csc")
+    A = sparse.random(m, m, density=density, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    c = rng.randn(m)
+    b = A @ rng.randn(m) + np.abs(rng.randn(m))
+    return dict(P=P, A=A, b=b, c=c)
+
+
+@pytest.mark.parametrize("cone,seed", [({"cs": [3]}, 42), ({"cs": [2, 3]}, 123), (dict(z=1, l=2, s=[3], cs=[3]), 456),
+                                       (dict(z=1, l=2, s=[3, 4], cs=[5, 4]), 1234)])
+def test_cs_solves_reference_cases(hip, oracle, cone, seed):
+    """R:test/test_spectral_and_complex_cones.py:121-152, R:test/test_mix_sd_csd_cone.py:31-40 ask for 'solved';
+    here additionally x, y, s against the oracle's direct solve (P = I and n = m make them unique)."""
+    data = _cs_qp(cone, seed, 0.5, 1.0)
+    got, ref = _solve_both(hip, oracle, data, cone)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _assert_xys(got, ref)
+    pri, dual, gap = helpers.kkt_certificate(data, got, P=data["P"])
+    assert pri < 1e-6 and dual < 1e-6 and gap < 1e-6
+    o = pg.cone_dims({k: v for k, v in cone.items() if k != "cs"})
+    for k in cone["cs"]:
+        for vec in (got["s"], got["y"]):
+            assert np.linalg.eigvalsh(helpers.cvec_to_herm(vec[o:o + k * k], k)).min() > -1e-7
+        o += k * k
+
+
+def test_cs_generated_parity_larger(hip, oracle):
+    K = {"l": 20, "s": [6], "cs": [12, 7]}
+    m = pg.cone_dims(K)
+    data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, m + 2, 6, 91, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    got, ref = _solve_both(hip, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _assert_xys(got, ref)
+    _assert_xys(got, {"x": x0, "y": y0, "s": s0})

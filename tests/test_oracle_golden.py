@@ -11,6 +11,7 @@ import pytest
 from scipy import sparse
 
 import helpers
+import problem_gen as pg
 from oracle import scs_oracle as oracle
 
 TIGHT = dict(eps_abs=1e-7, eps_rel=1e-7, eps_infeas=1e-7, verbose=False)
@@ -217,3 +218,52 @@ def test_embedded_qp_warm_start_regression():
         w2 = s.solve(True, d["x0"].copy(), d["y0"].copy(), d["s0"].copy())
         c = oracle.OracleSCS(*args, acceleration_lookback=lb, **kw).solve(False)
         assert c["info"]["status"] == w1["info"]["status"] == w2["info"]["status"] == "solved"
+
+
+# ---- complex PSD cone `cs` (R:test/test_spectral_and_complex_cones.py:121-152,
+# R:test/test_mix_sd_csd_cone.py:31-40, R:test/test_scs_coverage.py:2028-2034,2822) -----------------------------
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 8, 13])
+def test_cs_projection_vs_complex_eigh(k):
+    rng = np.random.RandomState(40 + k)
+    for scl in (1.0, 30.0):
+        v = scl * rng.randn(k * k)
+        ref = helpers.proj_hermitian_psd(v, k)
+        for dual in (False, True):  # self-dual
+            got = oracle.proj_cone(v, {"cs": [k]}, dual=dual)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * scl * max(k, 1))
+    # idempotent, and the residual v - Pi(v) is in -K and orthogonal to Pi(v) (Moreau)
+    if k:
+        v = rng.randn(k * k)
+        pv = oracle.proj_cone(v, {"cs": [k]})
+        np.testing.assert_allclose(oracle.proj_cone(pv, {"cs": [k]}), pv, atol=1e-12)
+        assert abs(pv @ (v - pv)) < 1e-12 * k * k
+        assert np.linalg.eigvalsh(helpers.cvec_to_herm(pv - v, k)).min() > -1e-12
+
+
+def _cs_qp(cone, seed, density, p_scale):
+    """the reference's own instance construction for the cs tests (R:test/test_spectral_and_complex_cones.py:55-71)"""
+    rng = np.random.RandomState(seed)
+    m = pg.cone_dims(cone)
+    n = m
+    P = p_scale * sparse.eye(n, format="csc")
+    A = sparse.random(m, n, density=density, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    c = rng.randn(n)
+    b = A @ rng.randn(n) + np.abs(rng.randn(m))
+    return dict(P=P, A=A, b=b, c=c)
+
+
+@pytest.mark.parametrize("cone,seed", [({"cs": [3]}, 42), ({"cs": [2, 3]}, 123), (dict(z=1, l=2, s=[3], cs=[3]), 456),
+                                       (dict(z=1, l=2, s=[3, 4], cs=[5, 4]), 1234)])
+def test_cs_solves_reference_cases(cone, seed):
+    data = _cs_qp(cone, seed, 0.5, 1.0)
+    sol = oracle.solve(data, cone, eps_abs=1e-7, eps_rel=1e-7)
+    assert sol["info"]["status"] == "solved"
+    pri, dual, gap = helpers.kkt_certificate(data, sol, P=data["P"])
+    assert pri < 1e-5 and dual < 1e-5 and gap < 1e-5
+    # s in K, y in K* = K: Hermitian blocks PSD
+    o = pg.cone_dims({k: v for k, v in cone.items() if k != "cs"})
+    for k in cone["cs"]:
+        for vec in (sol["s"], sol["y"]):
+            assert np.linalg.eigvalsh(helpers.cvec_to_herm(vec[o:o + k * k], k)).min() > -1e-6
+        o += k * k

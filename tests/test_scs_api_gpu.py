@@ -283,3 +283,24 @@ def test_write_data_and_log_csv_files(scs, tmp_path):
     # logging must not change the answer
     plain = scs.SCS(dat, K, verbose=False).solve()
     np.testing.assert_array_equal(plain["x"], sol["x"])
+
+
+def test_cs_cone_reference_cases(scs):
+    """R:test/test_scs_coverage.py:2020-2055 (mixed z/l/s/cs) and :2813-2825 (standalone, b = c = identity)."""
+    rng = np.random.RandomState(1234)
+    cone = {"z": 1, "l": 2, "s": [3, 4], "cs": [5, 4]}
+    m = 1 + 2 + 6 + 10 + 25 + 16
+    P = 0.1 * sp.eye(m, format="csc")
+    A = sp.random(m, m, density=0.05, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    data = {"P": P, "A": A, "b": rng.randn(m), "c": rng.randn(m)}
+    sol = scs.SCS(data, cone, max_iters=50000, verbose=False).solve()
+    assert sol["info"]["status"] in ("solved", "solved_inaccurate")
+    data = {"P": 0.1 * sp.eye(4, format="csc"), "A": sp.eye(4, 4, format="csc"),
+            "b": np.array([1.0, 0.0, 0.0, 1.0]), "c": np.array([1.0, 0.0, 0.0, 1.0])}
+    sol = scs.solve(data, {"cs": [2]}, verbose=False)
+    assert sol["info"]["status"] in ("solved", "solved_inaccurate")
+    # min 0.05|x|^2 + c'x s.t. s = b - x Hermitian PSD: the unconstrained minimiser x = -10 c keeps s = 11 I > 0
+    np.testing.assert_allclose(sol["x"], [-10.0, 0.0, 0.0, -10.0], atol=1e-3)
+    with pytest.raises(ValueError):  # dims: cs=[2] is 4 rows, not 3
+        scs.SCS({"A": sp.eye(3, 3, format="csc"), "b": np.ones(3), "c": np.ones(3)}, {"cs": [2]})

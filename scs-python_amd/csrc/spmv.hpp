@@ -281,8 +281,8 @@ inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20)
 
 // CSR -> slab format; false when a (chunk, slab) segment would overflow the uint16 offsets
 inline bool build_slab(const int *rowptr, const int *col, const double *val, int rows, int cols, HostSlab &out,
-                       std::vector<int> *src = nullptr) {
-  const int R = slab_pick_rows(rows);
+                       std::vector<int> *src = nullptr, int force_R = 0) {
+  const int R = force_R > 0 ? force_R : slab_pick_rows(rows);
   const int shift = slab_shift();
   const int S = (int)(((long)cols + (1L << shift) - 1) >> shift);
   const int nchunks = (rows + R - 1) / R;

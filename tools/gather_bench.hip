@@ -39,17 +39,33 @@ void run(const char* name, const int* idx, const double* tab, double* out, long 
 
 int main() {
   const long n = 20000000;
-  for (long tsize : {16384L, 131072L, 1000000L, 2000000L}) {
+  // (a) table-size sweep, uniformly random indices
+  for (long tsize : {1024L, 2048L, 4096L, 16384L, 131072L}) {
     std::vector<int> h(n); std::mt19937 g(1);
     for (long i = 0; i < n; ++i) h[i] = (int)(g() % tsize);
     int* idx; double* tab; double* out;
     CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&tab, tsize * 8)); CK(hipMalloc(&out, 64));
     CK(hipMemcpy(idx, h.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemset(tab, 0, tsize * 8));
-    printf("table %ld entries (%.2f MB), %ld gathers\n", tsize, tsize * 8 / 1e6, n);
+    printf("table %ld entries (%.3f MB), %ld gathers\n", tsize, tsize * 8 / 1e6, n);
     run<0, 8>("plain", idx, tab, out, n);
     run<0, 16>("plain", idx, tab, out, n);
-    run<1, 8>("nontemporal", idx, tab, out, n);
-    run<4, 8>("nontemporal f32", idx, tab, out, n);
+    CK(hipFree(idx)); CK(hipFree(tab)); CK(hipFree(out));
+  }
+  // (b) 1 MB table, every group of 64 consecutive gathers (one wave instruction) touches only L distinct 128-byte lines
+  for (int L : {64, 32, 16, 8, 4}) {
+    const long tsize = 131072;
+    std::vector<int> h(n); std::mt19937 g(2);
+    for (long i = 0; i < n; i += 64) {
+      int lines[64];
+      for (int k = 0; k < L; ++k) lines[k] = (int)(g() % (tsize / 16));
+      for (int k = 0; k < 64 && i + k < n; ++k) h[i + k] = lines[k % L] * 16 + (int)(g() % 16);
+    }
+    int* idx; double* tab; double* out;
+    CK(hipMalloc(&idx, n * 4)); CK(hipMalloc(&tab, tsize * 8)); CK(hipMalloc(&out, 64));
+    CK(hipMemcpy(idx, h.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemset(tab, 0, tsize * 8));
+    printf("1 MB table, %d distinct lines per wave instruction\n", L);
+    run<0, 8>("plain", idx, tab, out, n);
+    run<0, 16>("plain", idx, tab, out, n);
     CK(hipFree(idx)); CK(hipFree(tab)); CK(hipFree(out));
   }
   return 0;

@@ -77,34 +77,48 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// result valid in thread 0; `sm` needs NT/64 doubles
-template <int NT>
-__device__ __forceinline__ double block_sum(double v, double *sm) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+struct BlockSync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+// Reductions over a group of NT consecutive lanes (tid = index inside the group); result valid in tid 0;
+// `sm` needs NT/64 doubles private to the group.  sync() must synchronise (at least) the group.
+template <int NT, class Sync>
+__device__ __forceinline__ double group_sum(double v, double *sm, int tid, Sync sync) {
+  const int lane = tid & 63, wid = tid >> 6;
   v = wave_sum(v);
-  __syncthreads();
+  sync();
   if (lane == 0) sm[wid] = v;
-  __syncthreads();
+  sync();
   double r = 0.;
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < NT / 64; ++i) r += sm[i];
   }
   return r;
 }
-template <int NT>
-__device__ __forceinline__ double block_max(double v, double *sm) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+template <int NT, class Sync>
+__device__ __forceinline__ double group_max(double v, double *sm, int tid, Sync sync) {
+  const int lane = tid & 63, wid = tid >> 6;
   v = wave_max(v);
-  __syncthreads();
+  sync();
   if (lane == 0) sm[wid] = v;
-  __syncthreads();
+  sync();
   double r = 0.;
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
 #pragma unroll
     for (int i = 0; i < NT / 64; ++i) r = fmax(r, sm[i]);
   }
   return r;
+}
+// the whole workgroup as one group
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+  return group_sum<NT>(v, sm, (int)threadIdx.x, BlockSync{});
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double *sm) {
+  return group_max<NT>(v, sm, (int)threadIdx.x, BlockSync{});
 }
 
 // abs that propagates NaN into max-reductions as +inf (so a NaN iterate never passes a tolerance test)

@@ -27,6 +27,16 @@
 #ifndef PSD_INNER
 #define PSD_INNER 1
 #endif
+#ifndef PSD_PROFILE
+#define PSD_PROFILE 0  // 1 (tools/psd_lab.hip): thread 0 accumulates 100 MHz wall-clock ticks per phase into state[1..7]
+#endif
+#if PSD_PROFILE
+#define PSD_TICK(var) const long long var = (threadIdx.x == 0) ? wall_clock64() : 0
+#define PSD_ACC(slot, a, b) do { if (threadIdx.x == 0) prof[slot] += (double)((b) - (a)); } while (0)
+#else
+#define PSD_TICK(var) do { } while (0)
+#define PSD_ACC(slot, a, b) do { } while (0)
+#endif
 
 namespace scship {
 
@@ -34,7 +44,17 @@ constexpr int kPsdThreads = 1024;
 constexpr int kPsdWaves = kPsdThreads / 64;
 constexpr int kPsdMaxSweeps = 30;
 constexpr int kPsdB = 8;  // block size; pivots are 2*kPsdB = 16 = one MFMA tile
-constexpr int kPsdWaveLds = 272 + 256 + 16;  // per wave: S / 16x17 transpose scratch, W, (c,s)
+#ifndef PSD_LD
+#define PSD_LD 17
+#endif
+constexpr int kPsdLd = PSD_LD;  // leading dimension of the 16x16 pivot S and rotation W in LDS: stride 16 would put a whole
+                            // row of the 2x2-block accesses (and of the MFMA operand loads of W) on 2 banks
+#ifndef PSD_WLD
+#define PSD_WLD 17
+#endif
+constexpr int kPsdWLd = PSD_WLD;      // leading dimension of W
+constexpr int kPsdWsz = 16 * 17;  // 272 doubles reserved per S / W
+constexpr int kPsdWaveLds = 2 * kPsdWsz;  // per wave: S (also the 16x17 transpose scratch), W
 constexpr int kPsdWarmPeriod = 32;  // calls between two cold (V = I) eigen-solves
 constexpr int kPsdDepth = 4;  // block tasks whose global loads are in flight per wave
 constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
@@ -43,7 +63,7 @@ constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * siz
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T (NP*NP each), W (NB/2*256), lam (NP), state (8)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T (NP*NP each), W (NB/2 * 16x17), lam (NP), state (8)
   int count;
 };
 
@@ -53,9 +73,9 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
   if (nb < 2) nb = 2;
   return nb * kPsdB;
 }
-inline long psd_scratch_doubles(long n) {
+__host__ __device__ inline long psd_scratch_doubles(long n) {
   const long np = psd_np(n);
-  return 3 * np * np + (np / 16) * 256 + np + 8;
+  return 3 * np * np + (np / 16) * kPsdWsz + np + 8;
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -77,17 +97,18 @@ __device__ __forceinline__ void wave_sync() {
 // estimates, ~1e-7 relative: the rotation then leaves 1e-7 |a_pq| behind, which the next sweep removes),
 // but (c, s) must be orthonormal to full precision: c = rsqrt(1 + t^2) is refined by two Newton steps.
 __device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s) {
+  // theta = (aqq - app) / (2 apq) in fp64 (one hardware reciprocal estimate), the tangent
+  // t = sign(theta) / (|theta| + sqrt(theta^2 + 1)) in fp32 (|t| <= 1; an overflowing theta gives t = 0, the right limit),
+  // c = (1 + t^2)^(-1/2) from the fp32 estimate by three fp64 Newton steps (1e-7 -> 1e-14 -> full precision).
   const double theta = (aqq - app) * 0.5 * __builtin_amdgcn_rcp(apq);
-  const double at = fabs(theta);
-  double t;
-  if (at > 1e150) {
-    t = 0.5 * __builtin_amdgcn_rcp(theta);
-  } else {
-    t = __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(theta * theta + 1.));
-    t = theta >= 0 ? t : -t;
-  }
+  const float tf = (float)theta;
+  const float af = fabsf(tf);
+  float t32 = __builtin_amdgcn_rcpf(af + __builtin_amdgcn_sqrtf(af * af + 1.0f));
+  t32 = (af < 1e18f) ? t32 : 0.0f;  // af^2 overflows beyond ~1.8e19; t < 3e-19 there anyway
+  const double t = tf >= 0.0f ? (double)t32 : -(double)t32;
   const double z = t * t + 1.;
-  double y = __builtin_amdgcn_rsq(z);
+  double y = (double)__builtin_amdgcn_rsqf((float)z);
+  y = y * (1.5 - 0.5 * z * y * y);
   y = y * (1.5 - 0.5 * z * y * y);
   y = y * (1.5 - 0.5 * z * y * y);
   c = y;
@@ -95,16 +116,29 @@ __device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, d
 }
 
 // One wavefront improves the symmetric 16x16 pivot S (LDS, column-major) by up to kPsdInnerSweeps
-// cyclic Jacobi sweeps, W <- accumulated rotations (LDS).  cs: 16 doubles of wave-private LDS.
-// sch: the N=16 round-robin schedule, sch[2*(8*r + k)] = p, +1 = q (built once per kernel).
+// cyclic Jacobi sweeps, W <- accumulated rotations (LDS).
+// Lane (k = lane&7, k2 = lane>>3) owns the 2x2 block rows{p,q} x cols{p2,q2} of the round's pairs k and k2; the
+// round-robin schedule is computed arithmetically (no table look-up in front of the dependent LDS reads).
+// A round is ONE LDS round trip: every lane reads the three entries that define the rotations of both its
+// pairs (the 8 lanes sharing a pair compute the same (c,s) redundantly — no exchange, no second barrier),
+// its 2x2 block of S and its two rows of W, rotates, writes back.
 constexpr int kPsdInnerSweeps = PSD_INNER;
-__device__ inline void wave_jacobi16(double *S, double *W, double *cs, const unsigned char *sch, int lane) {
-  for (int e = lane; e < 256; e += 64) W[e] = ((e & 15) == (e >> 4)) ? 1. : 0.;
+__device__ __forceinline__ void rr16(int r, int k, int &p, int &q) {  // rr_pair(r, k, 16) without divisions
+  int a = r + k, b = r - k + 15;
+  a = a >= 15 ? a - 15 : a;
+  b = b >= 15 ? b - 15 : b;
+  if (k == 0) { a = 15; b = r; }
+  p = min(a, b);
+  q = max(a, b);
+}
+__device__ inline void wave_jacobi16(double *S, double *W, int lane) {
+  for (int e = lane; e < 256; e += 64) W[(e & 15) + kPsdWLd * (e >> 4)] = ((e & 15) == (e >> 4)) ? 1. : 0.;
   wave_sync();
+  const int i0 = lane >> 3, i1 = i0 + 8;  // the two rows of W this lane rotates (columns p,q of its pair k)
   for (int sweep = 0; sweep < kPsdInnerSweeps; ++sweep) {
     double off = 0., tot = 0.;
     for (int e = lane; e < 256; e += 64) {
-      const double a = S[e];
+      const double a = S[(e & 15) + kPsdLd * (e >> 4)];
       tot += a * a;
       if ((e & 15) != (e >> 4)) off += a * a;
     }
@@ -114,37 +148,27 @@ __device__ inline void wave_jacobi16(double *S, double *W, double *cs, const uns
     tot = __shfl(tot, 0, 64);
     if (off <= 1e-26 * tot || off == 0.) break;  // (16 eps)^2 ~ 1e-29 is the rounding floor
     for (int r = 0; r < 15; ++r) {
-      const unsigned char *sr = sch + 16 * r;
-      if (lane < 8) {
-        const int p = sr[2 * lane], q = sr[2 * lane + 1];
-        double c = 1., s = 0.;
-        const double apq = S[p + 16 * q];
-        if (fabs(apq) > 1e-300) jacobi_rot(S[p + 16 * p], S[q + 16 * q], apq, c, s);
-        cs[lane] = c;
-        cs[8 + lane] = s;
-      }
-      wave_sync();
-      {  // the 64 (k,k') rotation pairs: one 2x2 block per lane, blk <- J_k' blk J_k'
-        const int k = lane & 7, k2 = lane >> 3;
-        const int p = sr[2 * k], q = sr[2 * k + 1], p2 = sr[2 * k2], q2 = sr[2 * k2 + 1];
-        const double c = cs[k], s = cs[8 + k], c2 = cs[k2], s2 = cs[8 + k2];
-        const double app = S[p + 16 * p2], apq = S[p + 16 * q2], aqp = S[q + 16 * p2], aqq = S[q + 16 * q2];
-        const double t1 = c2 * app - s2 * apq, t2 = s2 * app + c2 * apq;
-        const double t3 = c2 * aqp - s2 * aqq, t4 = s2 * aqp + c2 * aqq;
-        S[p + 16 * p2] = c * t1 - s * t3;
-        S[p + 16 * q2] = c * t2 - s * t4;
-        S[q + 16 * p2] = s * t1 + c * t3;
-        S[q + 16 * q2] = s * t2 + c * t4;
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {  // W <- W J : 8 pairs x 16 rows
-        const int e = lane + 64 * h, i = e & 15, k = e >> 4;
-        const int p = sr[2 * k], q = sr[2 * k + 1];
-        const double c = cs[k], s = cs[8 + k];
-        const double wp = W[i + 16 * p], wq = W[i + 16 * q];
-        W[i + 16 * p] = c * wp - s * wq;
-        W[i + 16 * q] = s * wp + c * wq;
-      }
+      int p, q, p2, q2;
+      rr16(r, lane & 7, p, q);
+      rr16(r, lane >> 3, p2, q2);
+      const double dpp = S[p + kPsdLd * p], dqq = S[q + kPsdLd * q], dpq = S[p + kPsdLd * q];
+      const double epp = S[p2 + kPsdLd * p2], eqq = S[q2 + kPsdLd * q2], epq = S[p2 + kPsdLd * q2];
+      const double app = S[p + kPsdLd * p2], apq = S[p + kPsdLd * q2], aqp = S[q + kPsdLd * p2], aqq = S[q + kPsdLd * q2];
+      const double wp0 = W[i0 + kPsdWLd * p], wq0 = W[i0 + kPsdWLd * q], wp1 = W[i1 + kPsdWLd * p], wq1 = W[i1 + kPsdWLd * q];
+      double c = 1., s = 0., c2 = 1., s2 = 0.;
+      if (fabs(dpq) > 1e-300) jacobi_rot(dpp, dqq, dpq, c, s);
+      if (fabs(epq) > 1e-300) jacobi_rot(epp, eqq, epq, c2, s2);
+      wave_sync();  // every lane has read S and W of the previous round's state
+      const double t1 = c2 * app - s2 * apq, t2 = s2 * app + c2 * apq;
+      const double t3 = c2 * aqp - s2 * aqq, t4 = s2 * aqp + c2 * aqq;
+      S[p + kPsdLd * p2] = c * t1 - s * t3;
+      S[p + kPsdLd * q2] = c * t2 - s * t4;
+      S[q + kPsdLd * p2] = s * t1 + c * t3;
+      S[q + kPsdLd * q2] = s * t2 + c * t4;
+      W[i0 + kPsdWLd * p] = c * wp0 - s * wq0;
+      W[i0 + kPsdWLd * q] = s * wp0 + c * wq0;
+      W[i1 + kPsdWLd * p] = c * wp1 - s * wq1;
+      W[i1 + kPsdWLd * q] = s * wp1 + c * wq1;
       wave_sync();
     }
   }
@@ -155,7 +179,7 @@ __device__ __forceinline__ int pq_index(int i, int p, int q) { return (i < 8 ? p
 
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // LDS: per wave S/transpose scratch (272) + W (256) + cs (16) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
+  // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
   //      inner N=16 schedule (15*16 bytes)
   double *lds = reinterpret_cast<double *>(smem_raw);
   double *red = lds + kPsdWaves * kPsdWaveLds;
@@ -175,10 +199,14 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   double *A = scratch + B.woff[cidx];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;  // scaled eigenvectors for the reconstruction / temp of the warm start
-  double *Wg = Tm + (size_t)NP * NP;  // H pivots' rotation blocks, 256 doubles each (used when H > 16)
-  double *lam = Wg + (size_t)H * 256;
+  double *Wg = Tm + (size_t)NP * NP;  // H pivots' rotation blocks, 16x17 doubles each (used when H > 16)
+  double *lam = Wg + (size_t)H * kPsdWsz;
   double *state = lam + NP;           // state[0] = number of consecutive warm-started calls (0 = V invalid)
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
+#if PSD_PROFILE
+  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};  // [1] unpack [2] warm GEMMs [3] pivots [4] updates [5] norms+schedule [6] reconstruct [7] sweeps
+#endif
+  PSD_TICK(t_begin);
   const bool w_in_lds = H <= kPsdWaves;  // pivot k is solved by wave k and its W stays in that wave's LDS
 
   // Warm start.  Inside ADMM the matrix to project moves little between iterations, so the eigenvectors
@@ -212,7 +240,9 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   }
   __syncthreads();
 
-  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + 272, *csw = Ww + 256;
+  PSD_TICK(t_unpacked);
+  PSD_ACC(1, t_begin, t_unpacked);
+  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int li = lane & 15, lk = lane >> 4;
   const int nblk = H * (H + 1) / 2, ntile = NP / 16;
 
@@ -266,7 +296,10 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     __syncthreads();
   }
 
+  PSD_TICK(t_warmed);
+  PSD_ACC(2, t_unpacked, t_warmed);
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
+    PSD_TICK(t_sw0);
     double off = 0., tot = 0.;
     for (int e = tid; e < n * n; e += kPsdThreads) {
       const int i = e % n, j = e / n;
@@ -277,13 +310,22 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     off = block_sum<kPsdThreads>(off, red);
     tot = block_sum<kPsdThreads>(tot, red);
     // relative off-norm 1e-12; the rounding floor of the MFMA updates is ~(n eps)^2 = 2e-27 at n = 200
+#if PSD_PROFILE >= 2
+    if (tid == 0 && cidx == 0) printf("  block: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
+#endif
     if (tid == 0) bc[0] = (off <= 1e-24 * tot || off == 0.) ? 1. : 0.;
     __syncthreads();
     const bool done = bc[0] != 0.;
     __syncthreads();
+    PSD_TICK(t_sw1);
+    PSD_ACC(5, t_sw0, t_sw1);
     if (done) break;
+#if PSD_PROFILE
+    prof[7] += 1.;
+#endif
 
     for (int r = 0; r < NB - 1; ++r) {
+      PSD_TICK(t_s0);
       // outer schedule of this step -> LDS (block pairs p < q)
       for (int k = tid; k < H; k += kPsdThreads) {
         int p, q;
@@ -291,19 +333,23 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
         if (k < kPsdMaxH) { osch[2 * k] = p; osch[2 * k + 1] = q; }
       }
       __syncthreads();
+      PSD_TICK(t_s1);
+      PSD_ACC(5, t_s0, t_s1);
       // ---------------- phase 1: one wavefront per pivot ----------------
       for (int k = wave; k < H; k += kPsdWaves) {
         const int p = osch[2 * k], q = osch[2 * k + 1];
         for (int e = lane; e < 256; e += 64) {
           const int i = e & 15, j = e >> 4;
-          Sw[e] = A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)];
+          Sw[i + kPsdLd * j] = A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)];
         }
         wave_sync();
-        wave_jacobi16(Sw, Ww, csw, isch, lane);
+        wave_jacobi16(Sw, Ww, lane);
         if (!w_in_lds)
-          for (int e = lane; e < 256; e += 64) Wg[(size_t)k * 256 + e] = Ww[e];
+          for (int e = lane; e < kPsdWsz; e += 64) Wg[(size_t)k * kPsdWsz + e] = Ww[e];
       }
       __syncthreads();
+      PSD_TICK(t_s2);
+      PSD_ACC(3, t_s1, t_s2);
       // ---------------- phase 2a: A <- W' A W over blocks k <= k', 4 tasks in flight per wave ----------------
       for (int base = wave; base < nblk; base += kPsdDepth * kPsdWaves) {
         int tk[kPsdDepth], tk2[kPsdDepth];
@@ -328,16 +374,16 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
           if (tk[j] < 0) continue;
           const int k = tk[j], k2 = tk2[j];
           const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
-          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + 272 : Wg + (size_t)k * 256;
-          const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + 272 : Wg + (size_t)k2 * 256;
+          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + kPsdWsz : Wg + (size_t)k * kPsdWsz;
+          const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + kPsdWsz : Wg + (size_t)k2 * kPsdWsz;
           f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][kk], W2[(4 * kk + lk) + 16 * li], T, 0, 0, 0);
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][kk], W2[(4 * kk + lk) + kPsdWLd * li], T, 0, 0, 0);
           f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T  (B operand of k-step t is T[t])
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + 16 * li], T[t], Rr, 0, 0, 0);
+            Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + kPsdWLd * li], T[t], Rr, 0, 0, 0);
           // Stores.  Lane holds R[row = lk + 4t][col = li].  The mirror block (k2,k) = R' is written straight
           // from this layout (li runs down a column: full 128-byte lines).  The direct block goes through a
           // 16x17 LDS transpose in the wave's private scratch so that li runs down its columns as well.
@@ -376,19 +422,22 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
           if (tk[j] < 0) continue;
           const int k = tk[j];
           const int p = osch[2 * k], q = osch[2 * k + 1];
-          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + 272 : Wg + (size_t)k * 256;
+          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + kPsdWsz : Wg + (size_t)k * kPsdWsz;
           f64x4 T = {0., 0., 0., 0.};
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + 16 * li], av[j][kk], T, 0, 0, 0);  // (V_blk W)'
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + kPsdWLd * li], av[j][kk], T, 0, 0, 0);  // (V_blk W)'
           // lane holds (V_blk W)[row = li][col = lk + 4t]: li runs down a column -> full-line stores
 #pragma unroll
           for (int t = 0; t < 4; ++t) V[(trt[j] * 16 + li) + (size_t)ld * pq_index(lk + 4 * t, p, q)] = T[t];
         }
       }
       __syncthreads();
+      PSD_TICK(t_s3);
+      PSD_ACC(4, t_s2, t_s3);
     }
   }
+  PSD_TICK(t_swept);
 
   // ---- scaled eigenvector columns: Wc = V diag(sqrt(lambda+)) so X+ = Wc Wc' (V itself is kept for the next call) ----
   for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? fmax(A[j + (size_t)ld * j], 0.) : 0.;
@@ -420,6 +469,213 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       }
     }
   }
+#if PSD_PROFILE
+  __syncthreads();
+  PSD_TICK(t_end);
+  PSD_ACC(6, t_swept, t_end);
+  if (tid == 0)
+    for (int i = 1; i < 8; ++i) state[i] = prof[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Small matrices (order <= kPsdSmallMax = 32): ONE wavefront per matrix, everything in LDS.
+// At this size the block algorithm above is all latency (3 outer steps x [16x16 pivot solve + update + 3
+// workgroup barriers] per sweep, ~30 us); a plain parallel-order cyclic Jacobi on the whole matrix has
+// N-1 rounds of N/2 disjoint rotations per sweep and one wavefront covers a round in two LDS round trips:
+// lanes k < N/2 compute (c,s) of pair k; lane (k = lane&15, g = lane>>4) then rotates the 2x2 blocks
+// rows{p,q} x cols{p2,q2} of pairs (k, k2 = g+4h) and rows g+4h' of the eigenvector columns p,q.
+// Same warm start (A0 = V'AV from the previous call's V, cold restart every kPsdWarmPeriod calls), same
+// rotation formula, same packed layout.  Scratch per matrix: V (N x N) at woff, state at the end of the slot.
+// ---------------------------------------------------------------------------
+constexpr int kPsdSmallMax = 32;
+constexpr int kPsdSLd = 33;
+
+__global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm) {
+  __shared__ double S[32 * kPsdSLd], V[32 * kPsdSLd], T[32 * kPsdSLd];
+  __shared__ double csc[16], css[16];
+  const int lane = threadIdx.x, cidx = blockIdx.x;
+  const int n = B.order[cidx];
+  double *X = x + B.off[cidx];
+  if (n == 0) return;
+  if (n == 1) {
+    if (lane == 0) X[0] = fmax(X[0], 0.);
+    return;
+  }
+  const int N = (n + 1) & ~1, H = N / 2, ld = kPsdSLd;
+  double *Vg = scratch + B.woff[cidx];
+  double *state = Vg + psd_scratch_doubles(n) - 8;
+  const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
+  const bool warm = allow_warm && state[0] >= 1. && state[0] < (double)kPsdWarmPeriod;
+#if PSD_PROFILE
+  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+#endif
+  PSD_TICK(t_begin);
+
+  for (int e = lane; e < N * N; e += 64) {
+    const int j = e / N, i = e - j * N;
+    S[i + ld * j] = 0.;
+    V[i + ld * j] = warm ? Vg[e] : (i == j ? 1. : 0.);
+  }
+  wave_sync();
+  for (int j = 0; j < n; ++j) {
+    const long base = (long)j * n - (long)j * (j - 1) / 2;
+    for (int i = j + lane; i < n; i += 64) {
+      double v = X[base + (i - j)];
+      if (i != j) v *= isq2;
+      S[i + ld * j] = v;
+      S[j + ld * i] = v;
+    }
+  }
+  wave_sync();
+  PSD_TICK(t_unpacked);
+  PSD_ACC(1, t_begin, t_unpacked);
+  if (warm) {  // S <- V' S V
+    for (int e = lane; e < N * N; e += 64) {
+      const int j = e / N, i = e - j * N;
+      double acc = 0.;
+      for (int k = 0; k < N; ++k) acc += S[i + ld * k] * V[k + ld * j];
+      T[i + ld * j] = acc;
+    }
+    wave_sync();
+    for (int e = lane; e < N * N; e += 64) {
+      const int j = e / N, i = e - j * N;
+      if (i < j) continue;
+      double acc = 0.;
+      for (int k = 0; k < N; ++k) acc += V[k + ld * i] * T[k + ld * j];
+      S[i + ld * j] = acc;
+      S[j + ld * i] = acc;
+    }
+    wave_sync();
+  }
+
+  PSD_TICK(t_warmed);
+  PSD_ACC(2, t_unpacked, t_warmed);
+  const int k = lane & 15, g = lane >> 4;
+  for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
+    double off = 0., tot = 0.;
+    for (int e = lane; e < N * N; e += 64) {
+      const int j = e / N, i = e - j * N;
+      const double a = S[i + ld * j];
+      tot += a * a;
+      if (i != j) off += a * a;
+    }
+    off = wave_sum(off);
+    tot = wave_sum(tot);
+    off = __shfl(off, 0, 64);
+    tot = __shfl(tot, 0, 64);
+#if PSD_PROFILE >= 2
+    if (lane == 0 && cidx == 0) printf("  small: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
+#endif
+    if (off <= 1e-26 * tot || off == 0.) break;
+#if PSD_PROFILE
+    prof[7] += 1.;
+#endif
+    for (int r = 0; r < N - 1; ++r) {
+      // Round-robin pairing of round r, computed in registers.  The whole round is branch-free up to the
+      // stores (idle lanes read entry 0): all LDS reads leave in one batch, i.e. ONE round trip before the
+      // rotation and one (the published (c,s) of the other pairs) after it.
+      auto pair_of = [&](int kk, int &pp, int &qq) {
+        int x = r + kk, y = r - kk + (N - 1);
+        x = x >= N - 1 ? x - (N - 1) : x;
+        y = y >= N - 1 ? y - (N - 1) : y;
+        x = kk == 0 ? N - 1 : x;
+        y = kk == 0 ? r : y;
+        pp = min(x, y);
+        qq = max(x, y);
+      };
+      const bool kv = k < H;
+      int p, q;
+      pair_of(kv ? k : 0, p, q);
+      const double apq = S[p + ld * q], app = S[p + ld * p], aqq = S[q + ld * q];
+      int p2[4], q2[4];
+      bool bv[4], rv[8];
+      double a[4][4], vp[8], vq[8];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int k2 = g + 4 * h;
+        bv[h] = kv && k2 < H;
+        pair_of(bv[h] ? k2 : 0, p2[h], q2[h]);
+        a[h][0] = S[p + ld * p2[h]]; a[h][1] = S[p + ld * q2[h]];
+        a[h][2] = S[q + ld * p2[h]]; a[h][3] = S[q + ld * q2[h]];
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int i = g + 4 * h;
+        rv[h] = kv && i < N;
+        const int ii = rv[h] ? i : 0;
+        vp[h] = V[ii + ld * p];
+        vq[h] = V[ii + ld * q];
+      }
+      {  // every lane forms the rotation of its own pair (lanes sharing k compute the same bits); lanes < H publish it
+        const bool rot = fabs(apq) > 1e-300;
+        double c, s;
+        jacobi_rot(app, aqq, rot ? apq : 1.0, c, s);
+        c = rot ? c : 1.;
+        s = rot ? s : 0.;
+        if (lane < H) {
+          csc[lane] = c;
+          css[lane] = s;
+        }
+      }
+      wave_sync();  // (c,s) of every pair are in LDS; every lane has read the previous round's S and V
+      const double c = csc[kv ? k : 0], s = css[kv ? k : 0];
+      double c2[4], s2[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        c2[h] = csc[bv[h] ? g + 4 * h : 0];
+        s2[h] = css[bv[h] ? g + 4 * h : 0];
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double t1 = c2[h] * a[h][0] - s2[h] * a[h][1], t2 = s2[h] * a[h][0] + c2[h] * a[h][1];
+        const double t3 = c2[h] * a[h][2] - s2[h] * a[h][3], t4 = s2[h] * a[h][2] + c2[h] * a[h][3];
+        if (bv[h]) {
+          S[p + ld * p2[h]] = c * t1 - s * t3;
+          S[p + ld * q2[h]] = c * t2 - s * t4;
+          S[q + ld * p2[h]] = s * t1 + c * t3;
+          S[q + ld * q2[h]] = s * t2 + c * t4;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        if (rv[h]) {
+          const int i = g + 4 * h;
+          V[i + ld * p] = c * vp[h] - s * vq[h];
+          V[i + ld * q] = s * vp[h] + c * vq[h];
+        }
+      }
+      wave_sync();
+    }
+  }
+
+  PSD_TICK(t_swept);
+  PSD_ACC(3, t_warmed, t_swept);
+  // X+ = (V sqrt(L+)) (V sqrt(L+))'; V itself goes back to the scratch for the next call's warm start
+  for (int e = lane; e < N * N; e += 64) {
+    const int j = e / N, i = e - j * N;
+    const double lam = j < n ? fmax(S[j + ld * j], 0.) : 0.;
+    const double v = V[i + ld * j];
+    Vg[e] = v;
+    T[i + ld * j] = v * sqrt(lam);
+  }
+  if (lane == 0) state[0] = warm ? state[0] + 1. : 1.;
+  wave_sync();
+  for (int e = lane; e < n * n; e += 64) {
+    const int j = e / n, i = e - j * n;
+    if (i < j) continue;
+    double acc = 0.;
+    for (int kk = 0; kk < N; ++kk) acc += T[i + ld * kk] * T[j + ld * kk];
+    const long base = (long)j * n - (long)j * (j - 1) / 2;
+    X[base + (i - j)] = (i == j) ? acc : acc * sq2;
+  }
+#if PSD_PROFILE
+  wave_sync();
+  PSD_TICK(t_end);
+  PSD_ACC(6, t_swept, t_end);
+  if (lane == 0)
+    for (int i = 1; i < 8; ++i) state[i] = prof[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------

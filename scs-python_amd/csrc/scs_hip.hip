@@ -25,6 +25,7 @@
 #include "host_setup.hpp"
 #include "normalize_dev.hpp"
 #include "psd.hpp"
+#include "cg_persist.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
 
@@ -216,6 +217,9 @@ struct ScsHipWork {
   const int kGraphSteps[kNumGraphs] = {1, 2, 4, 8, 16};
   hipGraphExec_t g_pre[kNumGraphs] = {}, g_cg[kNumGraphs] = {}, g_post = nullptr;
   bool graphs_ready = false, graphs_enabled = true;
+  // small problems: the whole PCG solve of an iteration is one persistent launch (cg_persist.hpp)
+  int persist_wgs = 0, persist_ng = 1;  // 0 = launch-per-kernel path
+  DevBuf<unsigned> persist_bar;
 
   DeviceCsr At;  // CSR(A') == caller's CSC(A): rows n, cols m   (x-space outputs)
   DeviceCsr Ar;  // CSR(A): rows m, cols n                        (y-space outputs)
@@ -233,15 +237,27 @@ struct ScsHipWork {
   DevBuf<int> soc_off, soc_dim, soc_big;
   int n_soc = 0, n_soc_big = 0;
   DevBuf<double> pow_a, box_bl, box_bu;
-  DevBuf<int> psd_off, psd_order;
+  DevBuf<int> psd_off, psd_order;    // orders > kPsdSmallMax first (n_psd_big of them), then the small ones
   DevBuf<long> psd_woff;
   DevBuf<double> psd_scratch;
-  int n_psd = 0;
+  int n_psd = 0, n_psd_big = 0;
   // complex PSD cones: projected through the packed 2k x 2k real embedding held in cs_stage (psd.hpp)
-  DevBuf<int> cs_off, cs_order, cs_poff, cs_porder;
+  DevBuf<int> cs_off, cs_order, cs_poff, cs_porder;  // same ordering: embeddings of order > kPsdSmallMax first
   DevBuf<long> cs_soff, cs_woff;
   DevBuf<double> cs_stage;
-  int n_cs = 0;
+  int n_cs = 0, n_cs_big = 0;
+
+  // batched PSD projection of `count` packed matrices (the first `big` of order > kPsdSmallMax): K9 + its one-wave variant
+  void launch_psd(double *base, const int *off, const int *order, const long *woff, int count, int big) {
+    if (big > 0) {
+      PsdBatch B{off, order, woff, big};
+      hipLaunchKernelGGL(k_proj_psd, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm);
+    }
+    if (count > big) {
+      PsdBatch B{off + big, order + big, woff + big, count - big};
+      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm);
+    }
+  }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
   // AA (host mirrors the control state; heavy lifting on device)
@@ -451,6 +467,35 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_zero_if_flag, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, ut.p, (long)n + m, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
   }
+  // small-problem variant: same normalisation / warm start, then ONE launch for tolerance, CG start and CG loop
+  void enqueue_lin_sys_persist() {
+    const int nbl = vb(l);
+    hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
+    hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
+    hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
+                       d_params, sc.p, part2.p);
+    CgPersistArgs a{};
+    a.Ar = Ar.view().csr; a.At = At.view().csr;
+    if (has_P) a.Pf = Pf.view().csr;
+    a.has_P = has_P ? 1 : 0; a.n = n; a.m = m;
+    a.diag_r = diag_r.p; a.v = v.p; a.ws = ws.p; a.ut = ut.p;
+    a.r = cg_r.p; a.p = cg_p.p; a.Gp = cg_Gp.p; a.z = tmp_m.p; a.M = cg_M.p;
+    a.part = part.p; a.part2 = part2.p + 2 * nbl; a.part_p = part2.p; a.np_p = nbl;
+    a.params = d_params; a.sc = sc.p; a.fl = fl.p; a.max_its = 10 * n; a.bar = persist_bar.p;
+    if (persist_ng == 4)
+      hipLaunchKernelGGL(k_cg_persist<4>, dim3(persist_wgs), dim3(4 * kVecThreads), cg_persist_lds<4>(), stream, a);
+    else if (persist_ng == 2)
+      hipLaunchKernelGGL(k_cg_persist<2>, dim3(persist_wgs), dim3(2 * kVecThreads), cg_persist_lds<2>(), stream, a);
+    else
+      hipLaunchKernelGGL(k_cg_persist<1>, dim3(persist_wgs), dim3(kVecThreads), cg_persist_lds<1>(), stream, a);
+    enqueue_flag_readback();
+  }
+  void finish_lin_sys_persist() {
+    sync_flags();
+    if (h_flags[F_PERSIST_ERR]) throw std::runtime_error("persistent CG kernel: grid barrier timed out");
+    last_cg_iters = h_flags[F_ITERS];
+    tot_cg_iters += last_cg_iters;
+  }
   // tau (the y block is already in ut_y: it was carried along the CG recurrence)
   void enqueue_lin_sys_tail() {
     const int nb1 = vb(l - 1);
@@ -484,7 +529,8 @@ struct ScsHipWork {
   }
   void build_graphs() {
     if (graphs_ready || !graphs_enabled) return;
-    for (int i = 0; i < kNumGraphs; ++i) {
+    if (persist_wgs > 0) g_pre[0] = capture([&] { enqueue_lin_sys_persist(); });
+    for (int i = 0; i < kNumGraphs && persist_wgs == 0; ++i) {
       const int c = kGraphSteps[i];
       g_pre[i] = capture([&] {
         enqueue_lin_sys_head();
@@ -506,6 +552,12 @@ struct ScsHipWork {
 
   void project_lin_sys(int iter, bool graph) {
     set_iter_params(iter);
+    if (persist_wgs > 0) {
+      if (graph) HIP_CHECK(hipGraphLaunch(g_pre[0], stream));
+      else enqueue_lin_sys_persist();
+      finish_lin_sys_persist();
+      return;
+    }
     if (graph) {
       int gi = 0;
       const int want = std::max(1, std::min(last_cg_iters + 1, kGraphSteps[kNumGraphs - 1]));
@@ -532,15 +584,11 @@ struct ScsHipWork {
         hipLaunchKernelGGL(k_proj_soc_block, dim3(n_soc_big), dim3(kConeThreads), 0, stream, y, soc_off.p, soc_dim.p,
                            soc_big.p, n_soc_big);
     }
-    if (n_psd > 0) {  // self-dual
-      PsdBatch B{psd_off.p, psd_order.p, psd_woff.p, n_psd};
-      hipLaunchKernelGGL(k_proj_psd, dim3(n_psd), dim3(kPsdThreads), kPsdLdsBytes, stream, y, B, psd_scratch.p, psd_warm);
-    }
+    if (n_psd > 0) launch_psd(y, psd_off.p, psd_order.p, psd_woff.p, n_psd, n_psd_big);  // self-dual
     if (n_cs > 0) {  // Hermitian PSD: self-dual
       CsBatch C{cs_off.p, cs_order.p, cs_soff.p, n_cs};
-      PsdBatch B{cs_poff.p, cs_porder.p, cs_woff.p, n_cs};
       hipLaunchKernelGGL(k_cs_expand, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
-      hipLaunchKernelGGL(k_proj_psd, dim3(n_cs), dim3(kPsdThreads), kPsdLdsBytes, stream, cs_stage.p, B, psd_scratch.p, psd_warm);
+      launch_psd(cs_stage.p, cs_poff.p, cs_porder.p, cs_woff.p, n_cs, n_cs_big);
       hipLaunchKernelGGL(k_cs_extract, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
     }
     if (cone.ep > 0)  // K = K_exp: dual -> project onto K_exp^*
@@ -797,13 +845,18 @@ static void upload_cone_meta(ScsHipWork *w) {
   std::vector<int> poff, pord;
   std::vector<long> woff;
   long wtot = 0;
-  o = c.off_s;
-  for (int sdim : c.s) {
-    poff.push_back(o);
-    pord.push_back(sdim);
-    woff.push_back(wtot);
-    wtot += psd_scratch_doubles(sdim);
-    o += (int)sd_size(sdim);
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: orders > kPsdSmallMax (block kernel), pass 1: the one-wave kernel's
+    o = c.off_s;
+    for (int sdim : c.s) {
+      if ((sdim > kPsdSmallMax) == (pass == 0)) {
+        poff.push_back(o);
+        pord.push_back(sdim);
+        woff.push_back(wtot);
+        wtot += psd_scratch_doubles(sdim);
+      }
+      o += (int)sd_size(sdim);
+    }
+    if (pass == 0) w->n_psd_big = (int)poff.size();
   }
   w->n_psd = (int)poff.size();
   if (w->n_psd) {
@@ -814,17 +867,22 @@ static void upload_cone_meta(ScsHipWork *w) {
   std::vector<int> coff, cord, cpoff, cpord;
   std::vector<long> csoff, cwoff;
   long stot = 0;
-  o = c.off_cs;
-  for (int k : c.cs) {
-    coff.push_back(o);
-    cord.push_back(k);
-    csoff.push_back(stot);
-    cpoff.push_back((int)stot);
-    cpord.push_back(2 * k);
-    cwoff.push_back(wtot);
-    wtot += psd_scratch_doubles(2 * k);
-    stot += sd_size(2 * k);
-    o += k * k;
+  for (int pass = 0; pass < 2; ++pass) {
+    o = c.off_cs;
+    for (int k : c.cs) {
+      if ((2 * k > kPsdSmallMax) == (pass == 0)) {
+        coff.push_back(o);
+        cord.push_back(k);
+        csoff.push_back(stot);
+        cpoff.push_back((int)stot);
+        cpord.push_back(2 * k);
+        cwoff.push_back(wtot);
+        wtot += psd_scratch_doubles(2 * k);
+        stot += sd_size(2 * k);
+      }
+      o += k * k;
+    }
+    if (pass == 0) w->n_cs_big = (int)coff.size();
   }
   w->n_cs = (int)coff.size();
   if (w->n_cs) {
@@ -1013,6 +1071,24 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->part_len = std::max(w->part_len, 3 * kAaMaxMem * kMaxVecBlocks);
   w->part.alloc_zero(w->part_len, s);
   w->part2.alloc_zero(2 * kMaxVecBlocks, s);
+  {
+    // Persistent one-launch CG (cg_persist.hpp): bit-identical to the launch-per-kernel path, but NOT faster on
+    // this GPU (a grid barrier costs what a kernel boundary costs: the L2 invalidate + the dependent-load chain
+    // of the next phase; measured r01: 0.22 ms/iter either way on a config-5 problem with 16 workgroups, 2x slower
+    // with one) => off unless asked for.  SCS_HIP_PERSIST = "W" or "WxG": W workgroups of G (1, 2, 4) 256-lane groups.
+    const bool eligible = !w->At.has_slab && !w->Ar.has_slab && (!w->has_P || !w->Pf.has_slab) &&
+                          2 * vec_blocks(l) + 2 * vec_blocks(std::max(n, m)) <= 2 * kMaxVecBlocks;
+    int wgs = 0, ng = 2;
+    if (const char *env = getenv("SCS_HIP_PERSIST")) {
+      int a = 0, b = 0;
+      const int got = std::sscanf(env, "%dx%d", &a, &b);
+      if (got >= 1) wgs = eligible ? std::max(0, std::min(a, kCgPersistMaxWgs)) : 0;
+      if (got == 2 && (b == 1 || b == 2 || b == 4)) ng = b;
+    }
+    w->persist_wgs = wgs;
+    w->persist_ng = ng;
+    if (wgs > 0) w->persist_bar.alloc_zero(2, s);
+  }
   w->sc.alloc_zero(S_COUNT, s);
   w->out.alloc_zero(256, s);
   w->fl.alloc_zero(F_COUNT, s);
@@ -1069,7 +1145,12 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   hipStream_t s = w->stream;
   std::memset(info, 0, sizeof(*info));
   info->setup_time = w->setup_time;
-  std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (CSR-stream SpMV, PCG)");
+  if (w->persist_wgs > 0)
+    std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (PCG, persistent %dx%d-wave kernel)",
+                  w->persist_wgs, 4 * w->persist_ng);
+  else
+    std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV, PCG)",
+                  w->At.has_slab ? "L2-blocked slab" : "CSR-stream");
   // per-solve state
   w->sum_log_scale_factor = 0; w->n_log_scale_factor = 0; w->last_scale_update_iter = 0; w->scale_updates = 0;
   w->rejected_accel = 0; w->accepted_accel = 0; w->aa_iter = 0; w->aa_success = 0; w->aa_pending_safeguard = false;

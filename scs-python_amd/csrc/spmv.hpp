@@ -173,14 +173,20 @@ struct EpiResDual {
   }
 };
 
-template <class Epi>
-__global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi,
-                                                               const int *done_flag, int *step_counter) {
-  if (done_flag && *done_flag) return;
-  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
-  __shared__ double prod[kNnzPerWg];
-  __shared__ double red[kSpmvThreads / 64];
-  const int tid = threadIdx.x, b = blockIdx.x;
+// One row block of the CSR-stream mat-vec, executed by kSpmvThreads consecutive lanes (tid = 0..255 inside the
+// group).  `nb` = number of row blocks of the whole product = stride of the epilogue's partial arrays.
+// Shared by the one-launch-per-product kernel below and by the persistent CG kernel (cg_persist.hpp), so both
+// paths produce the same bits.  sync() must synchronise the lanes that share `prod` / `red`.
+// UNIFORM: several groups share one hardware barrier (persistent kernel), so every call — short-row block,
+// long-row block or idle (`active` = false) — executes the same number of sync() calls.
+template <class Epi, bool UNIFORM = false, class Sync>
+__device__ __forceinline__ void spmv_stream_block(const CsrView &A, const double *__restrict__ x, const Epi &epi, int b, int nb,
+                                                  double *prod, double *red, int tid, Sync sync, bool active = true) {
+  if (UNIFORM && !active) {
+#pragma unroll
+    for (int i = 0; i < 3 + 2 * (Epi::kSums + Epi::kMaxs); ++i) sync();
+    return;
+  }
   const int r0 = A.rowblk[b], r1 = A.rowblk[b + 1];
   const int p0 = A.rowptr[r0], p1 = A.rowptr[r1];
   const int nnz = p1 - p0;
@@ -196,31 +202,43 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const d
     const int *__restrict__ c = A.col + p0;
 #pragma unroll 8
     for (int k = tid; k < nnz; k += kSpmvThreads) prod[k] = v[k] * x[c[k]];
-    __syncthreads();
+    sync();
     for (int r = r0 + tid; r < r1; r += kSpmvThreads) {
       const int a = A.rowptr[r] - p0, e = A.rowptr[r + 1] - p0;
       double s = 0.;
       for (int k = a; k < e; ++k) s += prod[k];
       epi(r, s, sums, maxs);
     }
-  } else {  // one long row: whole workgroup reduces it (fixed order)
+    if (UNIFORM) { sync(); sync(); }
+  } else {  // one long row: the whole group reduces it (fixed order)
     double s = 0.;
     for (int k = p0 + tid; k < p1; k += kSpmvThreads) s += A.val[k] * x[A.col[k]];
-    s = block_sum<kSpmvThreads>(s, red);
+    if (UNIFORM) sync();
+    s = group_sum<kSpmvThreads>(s, red, tid, sync);
     if (tid == 0) epi(r0, s, sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
-      const double t = block_sum<kSpmvThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + b] = t;
+      const double t = group_sum<kSpmvThreads>(sums[i], red, tid, sync);
+      if (tid == 0) epi.partial[(size_t)i * nb + b] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
-      const double t = block_max<kSpmvThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + b] = t;
+      const double t = group_max<kSpmvThreads>(maxs[i], red, tid, sync);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * nb + b] = t;
     }
   }
+}
+
+template <class Epi>
+__global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi,
+                                                               const int *done_flag, int *step_counter) {
+  if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
+  __shared__ double prod[kNnzPerWg];
+  __shared__ double red[kSpmvThreads / 64];
+  spmv_stream_block(A, x, epi, (int)blockIdx.x, (int)gridDim.x, prod, red, (int)threadIdx.x, BlockSync{});
 }
 
 // ---------------------------------------------------------------------------

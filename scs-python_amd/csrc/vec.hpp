@@ -23,13 +23,13 @@ enum : int {
 // device flag slots (int)
 enum : int {
   F_DONE = 0, F_ITERS, F_AA_SUCCESS, F_AA_ITER, F_AA_ACCEPT, F_AA_REJ_LAPACK, F_AA_REJ_RANK0, F_AA_REJ_NONFINITE,
-  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_COUNT = 32
+  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_PERSIST_ERR, F_COUNT = 32
 };
 
 // per-iteration host scalars, kept in mapped pinned memory so that captured hipGraphs stay static
 enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_COUNT = 8 };
 
-inline int vec_blocks(long n) {
+__host__ __device__ inline int vec_blocks(long n) {
   long nb = (n + 4L * kVecThreads - 1) / (4L * kVecThreads);
   if (nb < 1) nb = 1;
   if (nb > kMaxVecBlocks) nb = kMaxVecBlocks;
@@ -37,15 +37,24 @@ inline int vec_blocks(long n) {
 }
 
 // ---- single-workgroup reduction of a partial array (fixed order) -------------
-__device__ __forceinline__ double part_sum(const double *part, int np, double *sm) {
+// (group form: kVecThreads consecutive lanes, tid = index inside the group — see common.hpp)
+template <class Sync>
+__device__ __forceinline__ double part_sum(const double *part, int np, double *sm, int tid, Sync sync) {
   double s = 0.;
-  for (int i = threadIdx.x; i < np; i += kVecThreads) s += part[i];
-  return block_sum<kVecThreads>(s, sm);
+  for (int i = tid; i < np; i += kVecThreads) s += part[i];
+  return group_sum<kVecThreads>(s, sm, tid, sync);
+}
+template <class Sync>
+__device__ __forceinline__ double part_max(const double *part, int np, double *sm, int tid, Sync sync) {
+  double s = 0.;
+  for (int i = tid; i < np; i += kVecThreads) s = fmax(s, part[i]);
+  return group_max<kVecThreads>(s, sm, tid, sync);
+}
+__device__ __forceinline__ double part_sum(const double *part, int np, double *sm) {
+  return part_sum(part, np, sm, (int)threadIdx.x, BlockSync{});
 }
 __device__ __forceinline__ double part_max(const double *part, int np, double *sm) {
-  double s = 0.;
-  for (int i = threadIdx.x; i < np; i += kVecThreads) s = fmax(s, part[i]);
-  return block_max<kVecThreads>(s, sm);
+  return part_max(part, np, sm, (int)threadIdx.x, BlockSync{});
 }
 
 // ||v||_2 partials
@@ -184,6 +193,31 @@ __global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n,
 // itself (a few hundred L2-resident doubles, fixed order => identical alpha everywhere), so no separate
 // single-workgroup "finalize" launch sits between the SpMV and this kernel.  z'r comes from the slot of the
 // current CG step (two slots, selected by F_STEP, which workgroup 0 of the A kernel bumps once per step).
+// Body of one (virtual) block b of nb: shared with the persistent CG kernel (cg_persist.hpp).
+template <class Sync>
+__device__ __forceinline__ void cg_update_block(double *x, double *r, const double *__restrict__ p, const double *__restrict__ Gp,
+                                                const double *__restrict__ M, int n, double *yacc, const double *__restrict__ z,
+                                                int m, double alpha, double *part, int b, int nb, int tid, double *sm, Sync sync,
+                                                bool active = true) {
+  double mx = 0., s = 0.;
+  if (active) {
+    if (yacc)
+      for (long i = (long)b * kVecThreads + tid; i < m; i += (long)nb * kVecThreads) yacc[i] += alpha * z[i];
+    for (long i = (long)b * kVecThreads + tid; i < n; i += (long)nb * kVecThreads) {
+      x[i] += alpha * p[i];
+      const double ri = r[i] - alpha * Gp[i];
+      r[i] = ri;
+      mx = fmax(mx, abs_nan_inf(ri));
+      s += (M[i] * ri) * ri;
+    }
+  }
+  mx = group_max<kVecThreads>(mx, sm, tid, sync);
+  s = group_sum<kVecThreads>(s, sm, tid, sync);
+  if (active && tid == 0) {
+    part[b] = mx;
+    part[nb + b] = s;
+  }
+}
 __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
                                                            const double *__restrict__ Gp, const double *__restrict__ M,
                                                            int n, double *yacc, const double *__restrict__ z, int m,
@@ -200,24 +234,7 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r,
     }
     __syncthreads();
   }
-  const double alpha = bc;
-  double mx = 0., s = 0.;
-  if (yacc)
-    for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
-      yacc[i] += alpha * z[i];
-  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
-    x[i] += alpha * p[i];
-    const double ri = r[i] - alpha * Gp[i];
-    r[i] = ri;
-    mx = fmax(mx, abs_nan_inf(ri));
-    s += (M[i] * ri) * ri;
-  }
-  mx = block_max<kVecThreads>(mx, sm);
-  s = block_sum<kVecThreads>(s, sm);
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = mx;
-    part[gridDim.x + blockIdx.x] = s;
-  }
+  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{});
 }
 
 // p = M r + beta p.  beta = z'r(new) / z'r(old) and the convergence test are formed in the prologue from the

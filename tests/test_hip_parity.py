@@ -382,3 +382,29 @@ def test_cs_generated_parity_larger(hip, oracle):
     assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
     _assert_xys(got, ref)
     _assert_xys(got, {"x": x0, "y": y0, "s": s0})
+
+
+# ---- persistent one-launch CG (cg_persist.hpp) vs the launch-per-kernel path --------------------------------
+@pytest.mark.parametrize("cfg", ["1x4", "1x1", "1x2", "3x1", "8x2", "16x4"])
+@pytest.mark.parametrize("with_P", [False, True])
+def test_persistent_cg_bit_identical(hip, oracle, monkeypatch, cfg, with_P):
+    """Both paths run the same per-block bodies over the same block decomposition and reduce the same partial
+    arrays in the same order: iterates, CG step counts and the solution must agree to the last bit, for any
+    grid shape (W workgroups x G groups)."""
+    K = {"z": 10, "l": 600, "q": [30, 12, 5], "s": [6, 3], "ep": 4, "p": [0.4, -0.7]}
+    m = pg.cone_dims(K)
+    if with_P:
+        data, _, _ = pg.gen_feasible_qp(K, 400, 7, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    else:
+        data, _, _ = pg.gen_feasible(K, 300, 9, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    stg = dict(STG)
+    stg.update(eps_abs=1e-7, eps_rel=1e-7, max_iters=400)
+    monkeypatch.setenv("SCS_HIP_PERSIST", "0")
+    ref = hip.SCS(*args, **stg).solve(False, None, None, None)
+    monkeypatch.setenv("SCS_HIP_PERSIST", cfg)
+    got = hip.SCS(*args, **stg).solve(False, None, None, None)
+    assert got["info"]["iter"] == ref["info"]["iter"] and got["info"]["cg_iters"] == ref["info"]["cg_iters"]
+    assert got["info"]["status"] == ref["info"]["status"]
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)

@@ -1,0 +1,57 @@
+// psd_lab.hip — phase breakdown of the batched PSD projection kernel (K9) with PSD_PROFILE timers.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPSD_PROFILE=1 -o devtools/psd_lab tools/psd_lab.hip
+//   ./devtools/psd_lab [order] [count] [calls] [perturbation]
+// First call is cold (V = I); later calls are warm-started on a matrix perturbed by `perturbation` (relative),
+// which is what consecutive ADMM iterations look like.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../scs-python_amd/csrc/psd.hpp"
+
+using namespace scship;
+
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 200, cnt = argc > 2 ? atoi(argv[2]) : 50, calls = argc > 3 ? atoi(argv[3]) : 6;
+  const double pert = argc > 4 ? atof(argv[4]) : 1e-3;
+  const long vlen = (long)n * (n + 1) / 2;
+  std::vector<int> off(cnt), ord(cnt, n);
+  std::vector<long> woff(cnt);
+  long wtot = 0;
+  for (int c = 0; c < cnt; ++c) { off[c] = (int)(c * vlen); woff[c] = wtot; wtot += psd_scratch_doubles(n); }
+  std::mt19937_64 g(1);
+  std::normal_distribution<double> nd;
+  std::vector<double> x0(cnt * vlen), x(cnt * vlen);
+  for (auto &v : x0) v = nd(g);
+  int *d_off, *d_ord; long *d_woff; double *d_x, *d_scr;
+  HIP_CHECK(hipMalloc(&d_off, cnt * 4)); HIP_CHECK(hipMalloc(&d_ord, cnt * 4)); HIP_CHECK(hipMalloc(&d_woff, cnt * 8));
+  HIP_CHECK(hipMalloc(&d_x, x.size() * 8)); HIP_CHECK(hipMalloc(&d_scr, wtot * 8));
+  HIP_CHECK(hipMemcpy(d_off, off.data(), cnt * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(d_ord, ord.data(), cnt * 4, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(d_woff, woff.data(), cnt * 8, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemset(d_scr, 0, wtot * 8));
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_psd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsdLdsBytes));
+  PsdBatch B{d_off, d_ord, d_woff, cnt};
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  std::printf("order %d (padded %ld), %d matrices, perturbation %.1e; ticks are 10 ns (thread 0 of matrix 0)\n", n, psd_np(n), cnt, pert);
+  std::printf("call   total_us | unpack  warmGEMM   pivots  updates  norms+sched  reconstruct | sweeps  steps  pivot_us/step  update_us/step\n");
+  const long np = psd_np(n);
+  const long st_off = psd_scratch_doubles(n) - 8;  // state[] at the end of matrix 0's scratch
+  for (int call = 0; call < calls; ++call) {
+    for (size_t i = 0; i < x.size(); ++i) x[i] = x0[i] * (1.0 + pert * call) + pert * call * nd(g);
+    HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipEventRecord(e0));
+    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1);
+    else hipLaunchKernelGGL(k_proj_psd, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1);
+    HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
+    float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double st[8];
+    HIP_CHECK(hipMemcpy(st, d_scr + st_off, sizeof st, hipMemcpyDeviceToHost));
+    const double steps = n <= kPsdSmallMax ? st[7] * (((n + 1) & ~1) - 1) : st[7] * (np / 8 - 1);  // rounds of the one-wave kernel / outer steps
+    std::printf("%3d  %9.1f | %6.1f  %8.1f  %7.1f  %7.1f  %11.1f  %11.1f | %6.0f  %5.0f  %13.2f  %14.2f\n", call, ms * 1e3, st[1] / 100, st[2] / 100,
+                st[3] / 100, st[4] / 100, st[5] / 100, st[6] / 100, st[7], steps, steps ? st[3] / 100 / steps : 0., steps ? st[4] / 100 / steps : 0.);
+  }
+  return 0;
+}

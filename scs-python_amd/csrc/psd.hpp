@@ -56,7 +56,10 @@ constexpr int kPsdWLd = PSD_WLD;      // leading dimension of W
 constexpr int kPsdWsz = 16 * 17;  // 272 doubles reserved per S / W
 constexpr int kPsdWaveLds = 2 * kPsdWsz;  // per wave: S (also the 16x17 transpose scratch), W
 constexpr int kPsdWarmPeriod = 32;  // calls between two cold (V = I) eigen-solves
-constexpr int kPsdDepth = 4;  // block tasks whose global loads are in flight per wave
+#ifndef PSD_DEPTH
+#define PSD_DEPTH 1
+#endif
+constexpr int kPsdDepth = PSD_DEPTH;  // phase 2: prefetch distance (tasks) of each wave's software pipeline
 constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
 constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int) + 256;
 
@@ -350,86 +353,101 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       __syncthreads();
       PSD_TICK(t_s2);
       PSD_ACC(3, t_s1, t_s2);
-      // ---------------- phase 2a: A <- W' A W over blocks k <= k', 4 tasks in flight per wave ----------------
-      for (int base = wave; base < nblk; base += kPsdDepth * kPsdWaves) {
-        int tk[kPsdDepth], tk2[kPsdDepth];
-        double av[kPsdDepth][4];
-#pragma unroll
-        for (int j = 0; j < kPsdDepth; ++j) {
-          const int task = base + j * kPsdWaves;
-          tk[j] = -1;
+      // ---------------- phase 2: A <- W' A W over block pairs k <= k' and V <- V W over (row tile, pivot) ----------------
+      // One task list per step: nblk A tasks, then H * ntile V tasks; wave w takes tasks w, w + 16, ...
+      // Software-pipelined: the four global loads of the wave's NEXT task are in flight while the current one
+      // runs its MFMAs and stores (all waves reach the same phase at the same time, so without this the
+      // matrix cores idle during the loads and the memory path idles during the MFMAs).
+      {
+        const int ntask = nblk + H * ntile;
+        auto decode = [&](int task, int &k, int &k2) {  // A task: (k, k2 >= k); V task: (k, row tile) with k2 = -1 - tile
           if (task < nblk) {
-            int k = 0, rem = task;  // unrank task -> (k, k2), k <= k2
-            while (rem >= H - k) { rem -= H - k; ++k; }
-            tk[j] = k;
-            tk2[j] = k + rem;
-            const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * tk2[j]], q2 = osch[2 * tk2[j] + 1];
+            int kk = 0, rem = task;
+            while (rem >= H - kk) { rem -= H - kk; ++kk; }
+            k = kk;
+            k2 = kk + rem;
+          } else {
+            const int t = task - nblk;
+            k = t % H;
+            k2 = -1 - t / H;
+          }
+        };
+        auto load = [&](int k, int k2, double (&av)[4]) {
+          const int p = osch[2 * k], q = osch[2 * k + 1];
+          if (k2 >= 0) {
+            const int p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
             const int row = pq_index(li, p, q);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) av[j][kk] = A[row + (size_t)ld * pq_index(4 * kk + lk, p2, q2)];
+            for (int kk = 0; kk < 4; ++kk) av[kk] = A[row + (size_t)ld * pq_index(4 * kk + lk, p2, q2)];
+          } else {
+            const int rt = -1 - k2;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) av[kk] = V[(rt * 16 + li) + (size_t)ld * pq_index(4 * kk + lk, p, q)];
           }
-        }
-#pragma unroll
-        for (int j = 0; j < kPsdDepth; ++j) {
-          if (tk[j] < 0) continue;
-          const int k = tk[j], k2 = tk2[j];
-          const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
-          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + kPsdWsz : Wg + (size_t)k * kPsdWsz;
-          const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + kPsdWsz : Wg + (size_t)k2 * kPsdWsz;
-          f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][kk], W2[(4 * kk + lk) + kPsdWLd * li], T, 0, 0, 0);
-          f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T  (B operand of k-step t is T[t])
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + kPsdWLd * li], T[t], Rr, 0, 0, 0);
-          // Stores.  Lane holds R[row = lk + 4t][col = li].  The mirror block (k2,k) = R' is written straight
-          // from this layout (li runs down a column: full 128-byte lines).  The direct block goes through a
-          // 16x17 LDS transpose in the wave's private scratch so that li runs down its columns as well.
-          const int gi = pq_index(li, p2, q2);
-          if (k != k2) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) A[gi + (size_t)ld * pq_index(lk + 4 * t, p, q)] = Rr[t];
-          }
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
-          wave_sync();
-          const int gr = pq_index(li, p, q);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) A[gr + (size_t)ld * pq_index(lk + 4 * t, p2, q2)] = Sw[li + 17 * (lk + 4 * t)];
-          wave_sync();
-        }
-      }
-      // ---------------- phase 2b: V <- V W (16-row tiles x pivots), 4 tasks in flight per wave ----------------
-      for (int base = wave; base < H * ntile; base += kPsdDepth * kPsdWaves) {
-        int tk[kPsdDepth], trt[kPsdDepth];
-        double av[kPsdDepth][4];
-#pragma unroll
-        for (int j = 0; j < kPsdDepth; ++j) {
-          const int task = base + j * kPsdWaves;
-          tk[j] = -1;
-          if (task < H * ntile) {
-            tk[j] = task % H;
-            trt[j] = task / H;
-            const int p = osch[2 * tk[j]], q = osch[2 * tk[j] + 1];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) av[j][kk] = V[(trt[j] * 16 + li) + (size_t)ld * pq_index(4 * kk + lk, p, q)];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kPsdDepth; ++j) {
-          if (tk[j] < 0) continue;
-          const int k = tk[j];
+        };
+        auto run = [&](int k, int k2, const double (&av)[4]) {
           const int p = osch[2 * k], q = osch[2 * k + 1];
           const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + kPsdWsz : Wg + (size_t)k * kPsdWsz;
-          f64x4 T = {0., 0., 0., 0.};
+          if (k2 >= 0) {
+            const int p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
+            const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + kPsdWsz : Wg + (size_t)k2 * kPsdWsz;
+            f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + kPsdWLd * li], av[j][kk], T, 0, 0, 0);  // (V_blk W)'
-          // lane holds (V_blk W)[row = li][col = lk + 4t]: li runs down a column -> full-line stores
+            for (int kk = 0; kk < 4; ++kk)
+              T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], W2[(4 * kk + lk) + kPsdWLd * li], T, 0, 0, 0);
+            f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T  (B operand of k-step t is T[t])
 #pragma unroll
-          for (int t = 0; t < 4; ++t) V[(trt[j] * 16 + li) + (size_t)ld * pq_index(lk + 4 * t, p, q)] = T[t];
+            for (int t = 0; t < 4; ++t)
+              Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + kPsdWLd * li], T[t], Rr, 0, 0, 0);
+            // Stores.  Lane holds R[row = lk + 4t][col = li].  The mirror block (k2,k) = R' is written straight
+            // from this layout (li runs down a column: full 128-byte lines).  The direct block goes through a
+            // 16x17 LDS transpose in the wave's private scratch so that li runs down its columns as well.
+            const int gi = pq_index(li, p2, q2);
+            if (k != k2) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) A[gi + (size_t)ld * pq_index(lk + 4 * t, p, q)] = Rr[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
+            wave_sync();
+            const int gr = pq_index(li, p, q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) A[gr + (size_t)ld * pq_index(lk + 4 * t, p2, q2)] = Sw[li + 17 * (lk + 4 * t)];
+            wave_sync();
+          } else {
+            const int rt = -1 - k2;
+            f64x4 T = {0., 0., 0., 0.};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + kPsdWLd * li], av[kk], T, 0, 0, 0);  // (V_blk W)'
+            // lane holds (V_blk W)[row = li][col = lk + 4t]: li runs down a column -> full-line stores
+#pragma unroll
+            for (int t = 0; t < 4; ++t) V[(rt * 16 + li) + (size_t)ld * pq_index(lk + 4 * t, p, q)] = T[t];
+          }
+        };
+        constexpr int D = kPsdDepth;  // prefetch distance in tasks; D + 1 register buffers
+        double buf[D + 1][4];
+        int bk[D + 1], bk2[D + 1];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const int t = wave + j * kPsdWaves;
+          bk[j] = bk2[j] = 0;
+          if (t < ntask) { decode(t, bk[j], bk2[j]); load(bk[j], bk2[j], buf[j]); }
+        }
+        bk[D] = bk2[D] = 0;
+        for (int base = wave; base < ntask; base += (D + 1) * kPsdWaves) {
+#pragma unroll
+          for (int j = 0; j <= D; ++j) {  // static buffer indices
+            const int tcur = base + j * kPsdWaves;
+            if (tcur < ntask) {
+              const int tpre = tcur + D * kPsdWaves;
+              constexpr int dummy = 0;
+              (void)dummy;
+              const int sp = (j + D) % (D + 1);
+              if (tpre < ntask) { decode(tpre, bk[sp], bk2[sp]); load(bk[sp], bk2[sp], buf[sp]); }
+              run(bk[j], bk2[j], buf[j]);
+            }
+          }
         }
       }
       __syncthreads();

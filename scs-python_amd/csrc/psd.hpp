@@ -61,12 +61,16 @@ constexpr int kPsdWarmPeriod = 32;  // calls between two cold (V = I) eigen-solv
 #endif
 constexpr int kPsdDepth = PSD_DEPTH;  // phase 2: prefetch distance (tasks) of each wave's software pipeline
 constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
+#ifndef PSD_OFFTOL2
+#define PSD_OFFTOL2 1e-16
+#endif
+constexpr double kPsdOffTol2 = PSD_OFFTOL2;  // sweeps stop at ||offdiag||_F^2 <= this * ||A||_F^2 (see the reconstruction)
 constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int) + 256;
 
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T (NP*NP each), W (NB/2 * 16x17), lam (NP), state (8)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T, V' (NP*NP each), W (NB/2 * 16x17), lam (NP), state (8)
   int count;
 };
 
@@ -78,7 +82,7 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
 }
 __host__ __device__ inline long psd_scratch_doubles(long n) {
   const long np = psd_np(n);
-  return 3 * np * np + (np / 16) * kPsdWsz + np + 8;
+  return 4 * np * np + (np / 16) * kPsdWsz + np + 8;
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -180,6 +184,31 @@ __device__ inline void wave_jacobi16(double *S, double *W, int lane) {
 // index of local row/col i (0..15) of the pivot (p,q): block p for i<8, block q otherwise
 __device__ __forceinline__ int pq_index(int i, int p, int q) { return (i < 8 ? p * kPsdB : q * kPsdB - 8) + i; }
 
+// acc[j] = (row tile ti of Aop) x (row tile tj0 + j of Bop)', j < kPsdNJ: C[i][jj] = sum_k Aop[i][k] Bop[jj][k], both
+// operands column-major with the contraction index along the columns, so every load runs down a column (full
+// 128-byte lines).  The a-operand is shared by the kPsdNJ output tiles (1.25 loads per MFMA instead of 2).
+// Tiles beyond `tjmax` are computed on a clamped tile and must be ignored by the caller.
+constexpr int kPsdNJ = 4;
+__device__ __forceinline__ void mma_row(const double *__restrict__ Aop, const double *__restrict__ Bop, int ld, int NP, int ti,
+                                        int tj0, int tjmax, int li, int lk, f64x4 (&acc)[kPsdNJ]) {
+  const double *pa = Aop + (ti * 16 + li) + (size_t)ld * lk;
+  const double *pb[kPsdNJ];
+#pragma unroll
+  for (int j = 0; j < kPsdNJ; ++j) {
+    acc[j] = f64x4{0., 0., 0., 0.};
+    pb[j] = Bop + (min(tj0 + j, tjmax) * 16 + li) + (size_t)ld * lk;
+  }
+#pragma unroll 2
+  for (int k0 = 0; k0 < NP; k0 += 4) {
+    const double a = pa[(size_t)ld * k0];
+    double b[kPsdNJ];
+#pragma unroll
+    for (int j = 0; j < kPsdNJ; ++j) b[j] = pb[j][(size_t)ld * k0];
+#pragma unroll
+    for (int j = 0; j < kPsdNJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
+  }
+}
+
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
@@ -202,7 +231,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   double *A = scratch + B.woff[cidx];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;  // scaled eigenvectors for the reconstruction / temp of the warm start
-  double *Wg = Tm + (size_t)NP * NP;  // H pivots' rotation blocks, 16x17 doubles each (used when H > 16)
+  double *Vt = Tm + (size_t)NP * NP;  // V' for the warm start's GEMMs (every operand load then runs down a column)
+  double *Wg = Vt + (size_t)NP * NP;  // H pivots' rotation blocks, 16x17 doubles each (used when H > 16)
   double *lam = Wg + (size_t)H * kPsdWsz;
   double *state = lam + NP;           // state[0] = number of consecutive warm-started calls (0 = V invalid)
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
@@ -232,14 +262,14 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     isch[2 * tid + 1] = (unsigned char)q;
   }
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
+  for (int e = tid; e < n * n; e += kPsdThreads) {  // one flat pass: independent loads, i runs down packed column j
+    const int j = e / n, i = e - j * n;
+    if (i < j) continue;
     const long base = (long)j * n - (long)j * (j - 1) / 2;  // start of packed column j
-    for (int i = j + tid; i < n; i += kPsdThreads) {
-      double v = X[base + (i - j)];
-      if (i != j) v *= isq2;
-      A[i + (size_t)ld * j] = v;
-      A[j + (size_t)ld * i] = v;
-    }
+    double v = X[base + (i - j)];
+    if (i != j) v *= isq2;
+    A[i + (size_t)ld * j] = v;
+    A[j + (size_t)ld * i] = v;
   }
   __syncthreads();
 
@@ -250,40 +280,61 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   const int nblk = H * (H + 1) / 2, ntile = NP / 16;
 
   if (warm) {
-    // T = A V   (NN: li runs down rows of A -> coalesced loads; stored through the 16x17 LDS transpose)
+    // A0 = V' A V as two GEMMs whose operand loads all run down columns (li contiguous: full 128-byte lines):
+    //   Vt = V'  (16x16 tiles through the 16x17 LDS transpose)
+    //   Tt = Vt A        (A is exactly symmetric: A[k][i] is read as A[i][k])      Tt = (A V)'
+    //   A0[i][j] = sum_k Vt[i][k] Tt[j][k]
     for (int tile = wave; tile < ntile * ntile; tile += kPsdWaves) {
       const int ti = tile % ntile, tj = tile / ntile;
-      f64x4 acc = {0., 0., 0., 0.};
-      for (int k0 = 0; k0 < NP; k0 += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(ti * 16 + li) + (size_t)ld * (k0 + lk)],
-                                                   V[(k0 + lk) + (size_t)ld * (tj * 16 + li)], acc, 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[t];
+      for (int t = 0; t < 4; ++t) Sw[li + 17 * (lk + 4 * t)] = V[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)];
       wave_sync();
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+      for (int t = 0; t < 4; ++t) Vt[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[(lk + 4 * t) + 17 * li];
       wave_sync();
     }
     __syncthreads();
-    // A = V' T   (lower-triangular tiles, mirrored: A stays exactly symmetric)
-    for (int tile = wave; tile < ntile * ntile; tile += kPsdWaves) {
-      const int ti = tile % ntile, tj = tile / ntile;
-      if (tj > ti) continue;
-      f64x4 acc = {0., 0., 0., 0.};
-      for (int k0 = 0; k0 < NP; k0 += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V[(k0 + lk) + (size_t)ld * (ti * 16 + li)],
-                                                   Tm[(k0 + lk) + (size_t)ld * (tj * 16 + li)], acc, 0, 0, 0);
-      // lane holds R[row = lk + 4t][col = li] of tile (ti, tj)
-      if (ti != tj) {
+    const int ngrp = (ntile + kPsdNJ - 1) / kPsdNJ;
+    for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
+      const int tj = task % ntile, ti0 = (task / ntile) * kPsdNJ;  // output tiles (tj, ti0 .. ti0+3) of Tt
+      f64x4 acc[kPsdNJ];
+      mma_row(Vt, A, ld, NP, tj, ti0, ntile - 1, li, lk, acc);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = acc[t];  // mirror
+      for (int j = 0; j < kPsdNJ; ++j) {
+        const int ti = ti0 + j;
+        if (ti >= ntile) break;
+        // lane holds Tt[row = tj*16 + lk + 4t][col = ti*16 + li]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Tm[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+        wave_sync();
       }
+    }
+    __syncthreads();
+    // lower-triangular tiles of A0, mirrored: A stays exactly symmetric
+    for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
+      const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+      if (tj0 > ti) continue;
+      f64x4 acc[kPsdNJ];
+      mma_row(Vt, Tm, ld, NP, ti, tj0, ti, li, lk, acc);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[t];
-      wave_sync();
+      for (int j = 0; j < kPsdNJ; ++j) {
+        const int tj = tj0 + j;
+        if (tj > ti) break;
+        // lane holds R[row = lk + 4t][col = li] of tile (ti, tj)
+        if (ti != tj) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) A[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-      wave_sync();
+          for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = acc[j][t];  // mirror
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) A[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+        wave_sync();
+      }
     }
     __syncthreads();
     // diagonal tiles were written un-symmetrised: average the two triangles inside them
@@ -312,11 +363,11 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     }
     off = block_sum<kPsdThreads>(off, red);
     tot = block_sum<kPsdThreads>(tot, red);
-    // relative off-norm 1e-12; the rounding floor of the MFMA updates is ~(n eps)^2 = 2e-27 at n = 200
+    // relative off-norm 1e-8: the reconstruction below is second-order accurate in what is left
 #if PSD_PROFILE >= 2
     if (tid == 0 && cidx == 0) printf("  block: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
 #endif
-    if (tid == 0) bc[0] = (off <= 1e-24 * tot || off == 0.) ? 1. : 0.;
+    if (tid == 0) bc[0] = (off <= kPsdOffTol2 * tot || off == 0.) ? 1. : 0.;
     __syncthreads();
     const bool done = bc[0] != 0.;
     __syncthreads();
@@ -457,33 +508,65 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   }
   PSD_TICK(t_swept);
 
-  // ---- scaled eigenvector columns: Wc = V diag(sqrt(lambda+)) so X+ = Wc Wc' (V itself is kept for the next call) ----
-  for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? fmax(A[j + (size_t)ld * j], 0.) : 0.;
+  // ---- X+ = V F V' with F = Pi_+(D + E) to second order in the remaining off-diagonal part E of A = D + E ----
+  // The sweeps stop at ||E||_F <= 1e-8 ||A||_F, one sweep earlier than a plain V max(D,0) V' would allow
+  // (its error is first order in E).  For a matrix function f applied to a nearly diagonal matrix,
+  //   f(D + E)_ij = f(d_i) delta_ij + E_ij (f(d_i) - f(d_j)) / (d_i - d_j) + O(|E|^2 / gap)      (Daleckii-Krein),
+  // and for f = max(., 0) the divided difference is 1 (both positive), 0 (both non-positive) or
+  // hi / (hi - lo) in (0, 1] for a pair straddling zero — always well defined.  The eigenvalue estimates d_i are
+  // themselves second-order accurate, so the result is good to ~|E|^2 = 1e-16 relative.
+  for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
   if (tid == 0) state[0] = warm ? state[0] + 1. : 1.;
   __syncthreads();
   for (int e = tid; e < NP * NP; e += kPsdThreads) {
-    const int j = e / NP;
-    Tm[e] = V[e] * sqrt(lam[j]);
+    const int i = e % NP, j = e / NP;
+    const double di = lam[i], dj = lam[j];
+    if (i == j) {
+      A[e] = fmax(di, 0.);
+    } else {
+      const double hi = fmax(di, dj), lo = fmin(di, dj);
+      const double gdd = lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo));
+      A[e] *= gdd;
+    }
+  }
+  __syncthreads();
+  // T = V F  (F symmetric: read by rows; stored through the 16x17 LDS transpose so that li runs down the columns of Tm)
+  const int ngrp_r = (ntile + kPsdNJ - 1) / kPsdNJ;
+  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
+    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+    f64x4 acc[kPsdNJ];
+    mma_row(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
+#pragma unroll
+    for (int j = 0; j < kPsdNJ; ++j) {
+      const int tj = tj0 + j;
+      if (tj >= ntile) break;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+      wave_sync();
+    }
   }
   __syncthreads();
 
-  // ---- X+ = Wc Wc' : one wave per lower-triangular 16x16 output tile ----
-  const int Tn = NP / 16;
-  for (int tile = wave; tile < Tn * Tn; tile += kPsdWaves) {
-    const int ti = tile % Tn, tj = tile / Tn;
-    if (tj > ti) continue;
-    f64x4 acc = {0., 0., 0., 0.};
-    for (int k0 = 0; k0 < NP; k0 += 4) {
-      const double a = Tm[(ti * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc[i][k]
-      const double b = Tm[(tj * 16 + li) + (size_t)ld * (k0 + lk)];  // Wc'[k][j] = Wc[j][k]
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
+  // ---- X+ = T V' : lower-triangular 16x16 output tiles ----
+  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
+    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+    if (tj0 > ti) continue;
+    f64x4 acc[kPsdNJ];
+    mma_row(Tm, V, ld, NP, ti, tj0, ti, li, lk, acc);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
-      if (i < n && j <= i) {
-        const long base = (long)j * n - (long)j * (j - 1) / 2;
-        X[base + (i - j)] = (i == j) ? acc[t] : acc[t] * sq2;
+    for (int jj = 0; jj < kPsdNJ; ++jj) {
+      const int tj = tj0 + jj;
+      if (tj > ti) break;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
+        if (i < n && j <= i) {
+          const long base = (long)j * n - (long)j * (j - 1) / 2;
+          X[base + (i - j)] = (i == j) ? acc[jj][t] : acc[jj][t] * sq2;
+        }
       }
     }
   }
@@ -536,14 +619,14 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
     V[i + ld * j] = warm ? Vg[e] : (i == j ? 1. : 0.);
   }
   wave_sync();
-  for (int j = 0; j < n; ++j) {
+  for (int e = lane; e < n * n; e += 64) {
+    const int j = e / n, i = e - j * n;
+    if (i < j) continue;
     const long base = (long)j * n - (long)j * (j - 1) / 2;
-    for (int i = j + lane; i < n; i += 64) {
-      double v = X[base + (i - j)];
-      if (i != j) v *= isq2;
-      S[i + ld * j] = v;
-      S[j + ld * i] = v;
-    }
+    double v = X[base + (i - j)];
+    if (i != j) v *= isq2;
+    S[i + ld * j] = v;
+    S[j + ld * i] = v;
   }
   wave_sync();
   PSD_TICK(t_unpacked);
@@ -585,7 +668,7 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
 #if PSD_PROFILE >= 2
     if (lane == 0 && cidx == 0) printf("  small: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
 #endif
-    if (off <= 1e-26 * tot || off == 0.) break;
+    if (off <= kPsdOffTol2 * tot || off == 0.) break;
 #if PSD_PROFILE
     prof[7] += 1.;
 #endif
@@ -669,21 +752,35 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
 
   PSD_TICK(t_swept);
   PSD_ACC(3, t_warmed, t_swept);
-  // X+ = (V sqrt(L+)) (V sqrt(L+))'; V itself goes back to the scratch for the next call's warm start
+  // X+ = V F V' with the second-order-accurate F of the block kernel's reconstruction (see there);
+  // V itself goes back to the scratch for the next call's warm start
   for (int e = lane; e < N * N; e += 64) {
     const int j = e / N, i = e - j * N;
-    const double lam = j < n ? fmax(S[j + ld * j], 0.) : 0.;
-    const double v = V[i + ld * j];
-    Vg[e] = v;
-    T[i + ld * j] = v * sqrt(lam);
+    Vg[e] = V[i + ld * j];
+    const double di = i < n ? S[i + ld * i] : 0., dj = j < n ? S[j + ld * j] : 0.;
+    double fij;
+    if (i == j) {
+      fij = fmax(di, 0.);
+    } else {
+      const double hi = fmax(di, dj), lo = fmin(di, dj);
+      fij = S[i + ld * j] * (lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo)));
+    }
+    T[i + ld * j] = fij;  // F (every lane reads only diagonal entries of S it does not write: S is left untouched)
   }
   if (lane == 0) state[0] = warm ? state[0] + 1. : 1.;
   wave_sync();
-  for (int e = lane; e < n * n; e += 64) {
+  for (int e = lane; e < N * N; e += 64) {  // S <- V F
+    const int j = e / N, i = e - j * N;
+    double acc = 0.;
+    for (int kk = 0; kk < N; ++kk) acc += V[i + ld * kk] * T[kk + ld * j];
+    S[i + ld * j] = acc;
+  }
+  wave_sync();
+  for (int e = lane; e < n * n; e += 64) {  // X+ = (V F) V', lower triangle
     const int j = e / n, i = e - j * n;
     if (i < j) continue;
     double acc = 0.;
-    for (int kk = 0; kk < N; ++kk) acc += T[i + ld * kk] * T[j + ld * kk];
+    for (int kk = 0; kk < N; ++kk) acc += S[i + ld * kk] * V[j + ld * kk];
     const long base = (long)j * n - (long)j * (j - 1) / 2;
     X[base + (i - j)] = (i == j) ? acc : acc * sq2;
   }

@@ -55,7 +55,7 @@ constexpr int kPsdLd = PSD_LD;  // leading dimension of the 16x16 pivot S and ro
 constexpr int kPsdWLd = PSD_WLD;      // leading dimension of W
 constexpr int kPsdWsz = 16 * 17;  // 272 doubles reserved per S / W
 constexpr int kPsdWaveLds = 2 * kPsdWsz;  // per wave: S (also the 16x17 transpose scratch), W
-constexpr int kPsdWarmPeriod = 32;  // calls between two cold (V = I) eigen-solves
+constexpr int kPsdWarmPeriod = 32;  // calls between two re-orthogonalisations of the warm-start basis V
 #ifndef PSD_DEPTH
 #define PSD_DEPTH 1
 #endif
@@ -244,9 +244,12 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 
   // Warm start.  Inside ADMM the matrix to project moves little between iterations, so the eigenvectors
   // of the previous call almost diagonalise it: start from A0 = V' A V (two MFMA GEMMs, ~1/4 sweep) and
-  // the Jacobi iteration converges in 1-3 sweeps instead of ~9.  V is refreshed from the identity every
-  // kPsdWarmPeriod calls to stop rounding drift in its orthogonality (each sweep multiplies ~n^2/2 rotations in).
-  const bool warm = allow_warm && state[0] >= 1. && state[0] < (double)kPsdWarmPeriod;
+  // the Jacobi iteration converges in 1-3 sweeps instead of ~9.  Every kPsdWarmPeriod calls V gets one
+  // Newton-Schulz step V <- V (3I - V'V) / 2 (three GEMMs, ~0.4 ms at order 200) that squares its distance
+  // from orthogonality, so the rounding drift of the accumulated rotations (each sweep multiplies ~n^2/2 of
+  // them in) stays at machine precision for arbitrarily long solves.
+  const bool warm = allow_warm && state[0] >= 1.;
+  const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
   __syncthreads();  // everyone has read state[0]
 
   // ---- unpack (lower tri, col-major, off-diag / sqrt2), zero padding; V = I when cold; inner schedule ----
@@ -295,6 +298,57 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     }
     __syncthreads();
     const int ngrp = (ntile + kPsdNJ - 1) / kPsdNJ;
+    if (reorth) {
+      // Tm = (3I - V'V) / 2   (V'V[i][j] = sum_k Vt[i][k] Vt[j][k]; symmetric, so the C layout is stored as its transpose)
+      for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
+        const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+        f64x4 acc[kPsdNJ];
+        mma_row(Vt, Vt, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
+#pragma unroll
+        for (int j = 0; j < kPsdNJ; ++j) {
+          const int tj = tj0 + j;
+          if (tj >= ntile) break;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int row = ti * 16 + lk + 4 * t, col = tj * 16 + li;
+            Tm[col + (size_t)ld * row] = (row == col ? 1.5 : 0.) - 0.5 * acc[j][t];
+          }
+        }
+      }
+      __syncthreads();
+      // Vt (as a plain buffer) = V Tm, then V <- it and Vt <- V' again
+      for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
+        const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+        f64x4 acc[kPsdNJ];
+        mma_row(V, Tm, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
+#pragma unroll
+        for (int j = 0; j < kPsdNJ; ++j) {
+          const int tj = tj0 + j;
+          if (tj >= ntile) break;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+          wave_sync();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Vt[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+          wave_sync();
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < NP * NP; e += kPsdThreads) V[e] = Vt[e];
+      __syncthreads();
+      for (int tile = wave; tile < ntile * ntile; tile += kPsdWaves) {
+        const int ti = tile % ntile, tj = tile / ntile;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Sw[li + 17 * (lk + 4 * t)] = V[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)];
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Tm[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[(lk + 4 * t) + 17 * li];
+        wave_sync();
+      }
+      __syncthreads();
+      for (int e = tid; e < NP * NP; e += kPsdThreads) Vt[e] = Tm[e];
+      __syncthreads();
+    }
     for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
       const int tj = task % ntile, ti0 = (task / ntile) * kPsdNJ;  // output tiles (tj, ti0 .. ti0+3) of Tt
       f64x4 acc[kPsdNJ];
@@ -586,7 +640,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 // N-1 rounds of N/2 disjoint rotations per sweep and one wavefront covers a round in two LDS round trips:
 // lanes k < N/2 compute (c,s) of pair k; lane (k = lane&15, g = lane>>4) then rotates the 2x2 blocks
 // rows{p,q} x cols{p2,q2} of pairs (k, k2 = g+4h) and rows g+4h' of the eigenvector columns p,q.
-// Same warm start (A0 = V'AV from the previous call's V, cold restart every kPsdWarmPeriod calls), same
+// Same warm start (A0 = V'AV from the previous call's V, Newton-Schulz re-orthogonalisation every kPsdWarmPeriod calls), same
 // rotation formula, same packed layout.  Scratch per matrix: V (N x N) at woff, state at the end of the slot.
 // ---------------------------------------------------------------------------
 constexpr int kPsdSmallMax = 32;
@@ -607,7 +661,8 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
   double *Vg = scratch + B.woff[cidx];
   double *state = Vg + psd_scratch_doubles(n) - 8;
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
-  const bool warm = allow_warm && state[0] >= 1. && state[0] < (double)kPsdWarmPeriod;
+  const bool warm = allow_warm && state[0] >= 1.;
+  const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
 #if PSD_PROFILE
   double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
 #endif
@@ -631,6 +686,31 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
   wave_sync();
   PSD_TICK(t_unpacked);
   PSD_ACC(1, t_begin, t_unpacked);
+  if (reorth) {  // V <- V (3I - V'V) / 2
+    for (int e = lane; e < N * N; e += 64) {
+      const int j = e / N, i = e - j * N;
+      double acc = 0.;
+      for (int k = 0; k < N; ++k) acc += V[k + ld * i] * V[k + ld * j];
+      T[i + ld * j] = (i == j ? 1.5 : 0.) - 0.5 * acc;
+    }
+    wave_sync();
+    double vn[(kPsdSmallMax * kPsdSmallMax + 63) / 64];
+#pragma unroll
+    for (int h = 0; h < (kPsdSmallMax * kPsdSmallMax + 63) / 64; ++h) {
+      const int e = lane + 64 * h, j = e / N, i = e - j * N;
+      double acc = 0.;
+      if (e < N * N)
+        for (int k = 0; k < N; ++k) acc += V[i + ld * k] * T[k + ld * j];
+      vn[h] = acc;
+    }
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < (kPsdSmallMax * kPsdSmallMax + 63) / 64; ++h) {
+      const int e = lane + 64 * h, j = e / N, i = e - j * N;
+      if (e < N * N) V[i + ld * j] = vn[h];
+    }
+    wave_sync();
+  }
   if (warm) {  // S <- V' S V
     for (int e = lane; e < N * N; e += 64) {
       const int j = e / N, i = e - j * N;

@@ -3,6 +3,8 @@
 //   ./devtools/psd_lab [order] [count] [calls] [perturbation]
 // First call is cold (V = I); later calls are warm-started on a matrix perturbed by `perturbation` (relative),
 // which is what consecutive ADMM iterations look like.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -52,6 +54,20 @@ int main(int argc, char **argv) {
     const double steps = n <= kPsdSmallMax ? st[7] * (((n + 1) & ~1) - 1) : st[7] * (np / 8 - 1);  // rounds of the one-wave kernel / outer steps
     std::printf("%3d  %9.1f | %6.1f  %8.1f  %7.1f  %7.1f  %11.1f  %11.1f | %6.0f  %5.0f  %13.2f  %14.2f\n", call, ms * 1e3, st[1] / 100, st[2] / 100,
                 st[3] / 100, st[4] / 100, st[5] / 100, st[6] / 100, st[7], steps, steps ? st[3] / 100 / steps : 0., steps ? st[4] / 100 / steps : 0.);
+  }
+  {  // orthogonality of the warm-start basis of matrix 0 after all calls
+    const bool small = n <= kPsdSmallMax;
+    const long N = small ? ((n + 1) & ~1) : np;
+    std::vector<double> Vh(N * N);
+    HIP_CHECK(hipMemcpy(Vh.data(), d_scr + (small ? 0 : np * np), Vh.size() * 8, hipMemcpyDeviceToHost));
+    double worst = 0.;
+    for (long i = 0; i < N; ++i)
+      for (long j = 0; j <= i; ++j) {
+        double acc = 0.;
+        for (long k = 0; k < N; ++k) acc += Vh[k + N * i] * Vh[k + N * j];
+        worst = std::max(worst, std::fabs(acc - (i == j ? 1. : 0.)));
+      }
+    std::printf("max |V'V - I| after %d calls: %.3e\n", calls, worst);
   }
   return 0;
 }

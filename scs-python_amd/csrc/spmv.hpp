@@ -485,10 +485,26 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
       }
     }
   }
+  // Epilogue.  A lane owns RPT consecutive rows, so applying the epilogue functor directly would make every
+  // access to its vectors (R_y, v, M, ... and the output) touch 64 different 128-byte lines per instruction —
+  // measured +10 us (one vector) to +40 us (six vectors, EpiR0) per launch at m = 2e6.  The row sums go through
+  // LDS (stride-17 padding: conflict-free both ways) so that lane t finishes rows t, t + 256, ...: coalesced.
+  if constexpr (RPT > 1) {
+    static_assert(R + R / 16 <= STAGE, "row sums are transposed through the product buffer");
 #pragma unroll
-  for (int j = 0; j < RPT; ++j) {
-    const int r = c * R + tid * RPT + j;
-    if (r < A.rows) epi(r, acc[j], sums, maxs);
+    for (int j = 0; j < RPT; ++j) {
+      const int rl = tid * RPT + j;
+      prod[rl + (rl >> 4)] = acc[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int rl = j * kSpmvThreads + tid, r = c * R + rl;
+      if (r < A.rows) epi(r, prod[rl + (rl >> 4)], sums, maxs);
+    }
+  } else {
+    const int r = c * R + tid;
+    if (r < A.rows) epi(r, acc[0], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll

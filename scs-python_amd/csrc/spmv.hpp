@@ -273,9 +273,10 @@ inline int slab_shift() {
   return (v >= 10 && v <= 24) ? v : kSlabShiftDefault;
 }
 
+constexpr int kSlabRoffPad = 16;  // row offsets of a segment: R + 1 used, stride R + 16 ushorts (32-byte aligned rows of 16)
 struct SlabView {
   const int *segptr;            // nchunks*S + 1 offsets into val/col (multiples of 4)
-  const unsigned short *roff;   // (nchunks*S) x (R+1) row offsets inside a segment
+  const unsigned short *roff;   // (nchunks*S) x (R+16): R+1 row offsets inside a segment, padded
   const int *col;
   const double *val;
   int rows, cols, nchunks, S, R, max_seg;
@@ -307,7 +308,7 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
   const long nnz = rowptr[rows];
   out.rows = rows; out.cols = cols; out.R = R; out.S = S; out.nchunks = nchunks; out.max_seg = 0;
   out.segptr.assign((size_t)nchunks * S + 1, 0);
-  out.roff.assign((size_t)nchunks * S * (R + 1), 0);
+  out.roff.assign((size_t)nchunks * S * (R + kSlabRoffPad), 0);
   out.col.clear(); out.val.clear();
   if (src) { src->clear(); src->reserve(nnz + 4L * nchunks * S); }
   out.col.reserve(nnz + 4L * nchunks * S);
@@ -322,7 +323,7 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
       const long seg0 = (long)out.col.size();
       if (seg0 > 2000000000L) return false;
       out.segptr[seg] = (int)seg0;
-      unsigned short *ro = &out.roff[seg * (R + 1)];
+      unsigned short *ro = &out.roff[seg * (R + kSlabRoffPad)];
       const long chi = (long)(s + 1) << shift;  // first column beyond this slab
       for (int r = r0; r < r1; ++r) {
         const long off = (long)out.col.size() - seg0;
@@ -349,6 +350,27 @@ inline bool build_slab(const int *rowptr, const int *col, const double *val, int
   }
   out.segptr[(size_t)nchunks * S] = (int)out.col.size();
   return copied == nnz;
+}
+
+// the RPT + 1 row offsets of lane tid (rows tid*RPT ...): 16-byte loads where the lane's run is 16-byte aligned
+// (RPT = 8, 16: 1 or 2 uint4 + the closing offset) instead of RPT + 1 two-byte loads that each touch 16 lines
+template <int RPT>
+__device__ __forceinline__ void slab_load_offs(const unsigned short *__restrict__ seg_roff, int tid, int (&o)[RPT + 1]) {
+  const unsigned short *ro = seg_roff + tid * RPT;
+  if constexpr (RPT % 8 == 0) {
+#pragma unroll
+    for (int v = 0; v < RPT / 8; ++v) {
+      const uint4 w = reinterpret_cast<const uint4 *>(ro)[v];
+      o[8 * v + 0] = w.x & 0xffff; o[8 * v + 1] = w.x >> 16;
+      o[8 * v + 2] = w.y & 0xffff; o[8 * v + 3] = w.y >> 16;
+      o[8 * v + 4] = w.z & 0xffff; o[8 * v + 5] = w.z >> 16;
+      o[8 * v + 6] = w.w & 0xffff; o[8 * v + 7] = w.w >> 16;
+    }
+    o[RPT] = ro[RPT];
+  } else {
+#pragma unroll
+    for (int j = 0; j <= RPT; ++j) o[j] = ro[j];
+  }
 }
 
 // register image of one pass: NQ quads (4 nonzeros each) per lane
@@ -425,11 +447,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
     int p0 = A.segptr[seg0], p1 = A.segptr[seg0 + 1];
     int cnt4 = (p1 - p0) >> 2;
     slab_load<NQ>(cur, reinterpret_cast<const int4 *>(A.col + p0), reinterpret_cast<const double2 *>(A.val + p0), cnt4, tid);
-    {
-      const unsigned short *ro = A.roff + seg0 * (R + 1) + tid * RPT;
-#pragma unroll
-      for (int j = 0; j <= RPT; ++j) o_cur[j] = ro[j];
-    }
+    slab_load_offs<RPT>(A.roff + seg0 * (R + kSlabRoffPad), tid, o_cur);
     for (int s = 0; s < A.S; ++s) {
       slab_gather<NQ>(cur, x, cnt4, tid);
       int cnt4_n = 0;
@@ -437,9 +455,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
         const int q0 = p1, q1 = A.segptr[seg0 + s + 2];
         cnt4_n = (q1 - q0) >> 2;
         slab_load<NQ>(nxt, reinterpret_cast<const int4 *>(A.col + q0), reinterpret_cast<const double2 *>(A.val + q0), cnt4_n, tid);
-        const unsigned short *ro = A.roff + (seg0 + s + 1) * (R + 1) + tid * RPT;
-#pragma unroll
-        for (int j = 0; j <= RPT; ++j) o_nxt[j] = ro[j];
+        slab_load_offs<RPT>(A.roff + (seg0 + s + 1) * (R + kSlabRoffPad), tid, o_nxt);
         p1 = q1;
       }
       slab_stage<NQ>(cur, prod, cnt4, tid);
@@ -461,10 +477,8 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
     for (int s = 0; s < A.S; ++s) {
       const size_t seg = (size_t)c * A.S + s;
       const int p0 = A.segptr[seg], n_seg = A.segptr[seg + 1] - p0;  // both multiples of 4
-      const unsigned short *ro = A.roff + seg * (R + 1) + tid * RPT;
       int o[RPT + 1];
-#pragma unroll
-      for (int j = 0; j <= RPT; ++j) o[j] = ro[j];
+      slab_load_offs<RPT>(A.roff + seg * (R + kSlabRoffPad), tid, o);
       for (int base = 0; base < n_seg; base += STAGE) {
         const int cnt4 = min(STAGE, n_seg - base) >> 2;
         SlabRegs<NQ> cur;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const
       if (s + 2 < A.S) {
         const int q0 = A.segptr[sg + s + 2], q1 = A.segptr[sg + s + 3];
         t0 = touch_lines(A.val + q0, (long)(q1 - q0) * 8, lane, 64 * PF);
-        t1 = touch_lines(A.roff + (sg + s + 2) * (R + 1), (long)(R + 1) * 2, lane, 64 * PF);
+        t1 = touch_lines(A.roff + (sg + s + 2) * (R + kSlabRoffPad), (long)(R + 1) * 2, lane, 64 * PF);
       }
       if (s + 3 < A.S) {
         const int q0 = A.segptr[sg + s + 3], q1 = A.segptr[sg + s + 4];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const
     }
   };
   auto load_offs = [&](size_t seg, unsigned *o) {
-    const unsigned short *ro = A.roff + seg * (R + 1) + tid;
+    const unsigned short *ro = A.roff + seg * (R + kSlabRoffPad) + tid;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
       unsigned u;

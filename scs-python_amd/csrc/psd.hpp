@@ -198,7 +198,7 @@ __device__ __forceinline__ void mma_row(const double *__restrict__ Aop, const do
     acc[j] = f64x4{0., 0., 0., 0.};
     pb[j] = Bop + (min(tj0 + j, tjmax) * 16 + li) + (size_t)ld * lk;
   }
-#pragma unroll 2
+
   for (int k0 = 0; k0 < NP; k0 += 4) {
     const double a = pa[(size_t)ld * k0];
     double b[kPsdNJ];

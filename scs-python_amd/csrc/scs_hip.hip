@@ -228,7 +228,9 @@ struct ScsHipWork {
 
   DevBuf<double> v, v_prev, u, ut, rsk, g, h, diag_r, D, E, Dinv, Einv;
   DevBuf<double> cg_b, cg_p, cg_r, cg_Gp, cg_M, tmp_m, ws, px;
-  DevBuf<double> part, part2, sc, out;  // part2: partials of k_cg_update (read by k_cg_dir while `part` is reused)
+  DevBuf<double> part, part2, sc, out;  // part2: partials of k_cg_update (read by k_cg_dir while `part` is reused), of k_prep
+  DevBuf<double> part_v;                // sum-of-squares partials of v for the next k_prep
+  bool v_norm_fresh = false;
   DevBuf<int> fl;
   DevBuf<double> solx, soly, sols;
   int part_len = 0;
@@ -374,7 +376,7 @@ struct ScsHipWork {
     }
     const bool use_graph = started && xout == ut.p;  // graphs are captured for the ADMM buffers only
     double *yacc = (xout == ut.p) ? ut.p + n : nullptr;  // ADMM path carries the y block along the recurrence
-    int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 1, 64));
+    int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 2, 64));  // a host round trip costs ~30 us, an unused CG step four ~1 us launches
     while (true) {
       const int iters_before = done_iters;
       if (use_graph) {
@@ -452,28 +454,30 @@ struct ScsHipWork {
   // everything of project_lin_sys up to (and including) the fused, warm-started CG start
   void enqueue_lin_sys_head() {
     const int nbl = vb(l);
-    hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
-    hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
+    // (the sum-of-squares partials of v are in part_v: enqueue_v_update of the previous iteration or ensure_v_norm)
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
-                       d_params, sc.p, part.p);
-    hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 0.0, 1.0, 0.0, 1, d_params, sc.p, fl.p);
+                       d_params, part_v.p, nbl, sc.p, part2.p);
     // y0 = v_y + R_y^{-1} A ws   (start of the y recurrence, lives in ut_y)
     launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);
     // r0 = R_x (v_x - ws) - P ws - A' y0 ; p0 = M r0 ; partials for ||r0||_inf and r0'M r0
     if (has_P) launch_spmv(Pf.view(), ws.p, EpiStore{cg_Gp.p, 0}, nullptr, stream);
     launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, diag_r.p, v.p, ws.p, has_P ? cg_Gp.p : nullptr, part.p},
                 nullptr, stream);
-    hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, At.nwg(), 1, sc.p, fl.p);
-    hipLaunchKernelGGL(k_zero_if_flag, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, ut.p, (long)n + m, fl.p);
-    HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
+    // tolerance, ||r0||, r0'M r0, step counter, zero-rhs short circuit: one finalize launch
+    hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
+                       ut.p, (long)n + m);
+  }
+  // ||v||^2 partials for k_prep when something other than enqueue_v_update wrote v (start, AA, scale update)
+  void ensure_v_norm() {
+    if (v_norm_fresh) return;
+    hipLaunchKernelGGL(k_sumsq, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, l, part_v.p);
+    v_norm_fresh = true;
   }
   // small-problem variant: same normalisation / warm start, then ONE launch for tolerance, CG start and CG loop
   void enqueue_lin_sys_persist() {
     const int nbl = vb(l);
-    hipLaunchKernelGGL(k_sumsq, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, l, part.p);
-    hipLaunchKernelGGL(k_fin_vscale, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, (double)l, sc.p);
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
-                       d_params, sc.p, part2.p);
+                       d_params, part_v.p, nbl, sc.p, part2.p);
     CgPersistArgs a{};
     a.Ar = Ar.view().csr; a.At = At.view().csr;
     if (has_P) a.Pf = Pf.view().csr;
@@ -500,15 +504,15 @@ struct ScsHipWork {
   void enqueue_lin_sys_tail() {
     const int nb1 = vb(l - 1);
     hipLaunchKernelGGL(k_tau_dots, dim3(nb1), dim3(kVecThreads), 0, stream, ut.p, v.p, g.p, diag_r.p, l - 1, part.p);
-    hipLaunchKernelGGL(k_fin_tau, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb1, v.p, diag_r.p, l, d_params, sc.p);
   }
-  void enqueue_cones() {
+  void enqueue_cones() {  // (tau is formed in k_cone_pre's prologue from the k_tau_dots partials)
     hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
-                       d_params, sc.p);
+                       d_params, sc.p, part.p, vb(l - 1), diag_r.p);
     project_nonlinear_cones(u.p + n, 1);
   }
   void enqueue_v_update() {
-    hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l);
+    hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l, part_v.p);
+    v_norm_fresh = true;
   }
 
   hipGraphExec_t capture(const std::function<void()> &body) {
@@ -529,6 +533,7 @@ struct ScsHipWork {
   }
   void build_graphs() {
     if (graphs_ready || !graphs_enabled) return;
+    const bool keep_fresh = v_norm_fresh;  // capturing enqueues nothing: host-side state must not move
     if (persist_wgs > 0) g_pre[0] = capture([&] { enqueue_lin_sys_persist(); });
     for (int i = 0; i < kNumGraphs && persist_wgs == 0; ++i) {
       const int c = kGraphSteps[i];
@@ -547,11 +552,13 @@ struct ScsHipWork {
       enqueue_cones();
       enqueue_v_update();
     });
+    v_norm_fresh = keep_fresh;
     graphs_ready = true;
   }
 
   void project_lin_sys(int iter, bool graph) {
     set_iter_params(iter);
+    ensure_v_norm();
     if (persist_wgs > 0) {
       if (graph) HIP_CHECK(hipGraphLaunch(g_pre[0], stream));
       else enqueue_lin_sys_persist();
@@ -560,8 +567,8 @@ struct ScsHipWork {
     }
     if (graph) {
       int gi = 0;
-      const int want = std::max(1, std::min(last_cg_iters + 1, kGraphSteps[kNumGraphs - 1]));
-      while (gi + 1 < kNumGraphs && kGraphSteps[gi + 1] <= want) ++gi;
+      const int want = std::max(1, std::min(last_cg_iters + 2, kGraphSteps[kNumGraphs - 1]));
+      while (gi + 1 < kNumGraphs && kGraphSteps[gi] < want) ++gi;  // smallest captured chunk that covers `want`
       HIP_CHECK(hipGraphLaunch(g_pre[gi], stream));
       sync_flags();
       run_cg(ut.p, ws.p, 10 * n, 2);
@@ -702,6 +709,7 @@ struct ScsHipWork {
       update_work_cache();
       aa_iter = 0;  // reset acceleration
       hipLaunchKernelGGL(k_v_rescale, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, rsk.p, u.p, ut.p, diag_r.p, l);
+      v_norm_fresh = false;
     }
   }
 
@@ -762,6 +770,7 @@ struct ScsHipWork {
         if (aa_norm == 0) aa_norm = -1.;
       } else {
         HIP_CHECK(hipMemcpyAsync(aa_gamma.p, w.data(), sizeof(double) * len, hipMemcpyHostToDevice, stream));
+        v_norm_fresh = false;
         hipLaunchKernelGGL(k_aa_apply, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, aa_D.p, aa_S.p, aa_x.p, aa_gamma.p, l, len,
                            stgs.acceleration_relaxation);
         HIP_CHECK(hipStreamSynchronize(stream));  // w is a local
@@ -780,6 +789,7 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_aa_diffsq, dim3(nbl), dim3(kVecThreads), 0, stream, v_prev.p, v.p, l, part.p);
     hipLaunchKernelGGL(k_fin_safeguard, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 1.0, sc.p, fl.p);
     hipLaunchKernelGGL(k_aa_restore, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, aa_f.p, aa_x.p, l, fl.p);
+    v_norm_fresh = false;
     aa_pending_safeguard = true;
   }
 
@@ -1071,6 +1081,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->part_len = std::max(w->part_len, 3 * kAaMaxMem * kMaxVecBlocks);
   w->part.alloc_zero(w->part_len, s);
   w->part2.alloc_zero(2 * kMaxVecBlocks, s);
+  w->part_v.alloc_zero(kMaxVecBlocks, s);
   {
     // Persistent one-launch CG (cg_persist.hpp): bit-identical to the launch-per-kernel path, but NOT faster on
     // this GPU (a grid barrier costs what a kernel boundary costs: the L2 invalidate + the dependent-load chain
@@ -1180,6 +1191,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     }
     v0[l - 1] = 1.0;
     HIP_CHECK(hipMemcpyAsync(w->v.p, v0.data(), sizeof(double) * l, hipMemcpyHostToDevice, s));
+    w->v_norm_fresh = false;
     HIP_CHECK(hipMemsetAsync(w->u.p, 0, sizeof(double) * l, s));
     const double one = 1.0;
     HIP_CHECK(hipMemcpyAsync(w->u.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, s));
@@ -1238,6 +1250,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     t = now_ms();
     if (use_graphs && plain_iter) {
       HIP_CHECK(hipGraphLaunch(w->g_post, s));  // y, tau, cones, v += alpha (u - u_t)
+      w->v_norm_fresh = true;
       t_cone += now_ms() - t;
     } else {
       w->enqueue_lin_sys_tail();

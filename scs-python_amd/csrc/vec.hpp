@@ -66,26 +66,31 @@ __global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict_
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-// sc[S_VSCALE] = sqrt(l) / ||v||   (iterate normalisation)
-__global__ __launch_bounds__(kVecThreads) void k_fin_vscale(const double *part, int np, double l, double *sc) {
-  __shared__ double sm[kVecThreads / 64];
-  const double s = part_sum(part, np, sm);
-  if (threadIdx.x == 0) sc[S_VSCALE] = sqrt(l) / fmax(sqrt(s), 1e-300);
-}
-
 // Start of project_lin_sys: normalise v, snapshot v_prev and form the CG warm start
 //   ws = u_x + tau g_x   (also copied into ut_x: the CG iterate x starts there).
 // The KKT right-hand side [R_x v_x; -R_y v_y] is never materialised: the warm-started CG only needs
 //   r0 = rhs_x + A' R_y^{-1} rhs_y - (R_x + P + A' R_y^{-1} A) ws = R_x (v_x - ws) - P ws - A' (v_y + R_y^{-1} A ws)
 // which costs ONE A product and ONE A' product (epilogues EpiY / EpiR0) instead of three.
 // Partials: [max |ws| , max |rhs|] (the latter for the zero-rhs short-circuit).
+// The iterate normalisation factor sqrt(l) / ||v|| is formed in the prologue from the
+// sum-of-squares partials `vpart` (written by k_v_update of the previous iteration, or by k_sumsq after
+// anything else touched v): every workgroup reduces them in the same fixed order, no finalize launch.
 __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *ws,
                                                       const double *__restrict__ u, const double *__restrict__ g,
                                                       const double *__restrict__ diag_r, int n, int m, const double *params,
-                                                      const double *sc, double *part) {
+                                                      const double *vpart, int nvp, double *sc, double *part) {
   __shared__ double sm[kVecThreads / 64];
+  __shared__ double bc;
   const long l = (long)n + m + 1;
-  const double scale = params[P_DO_SCALE] != 0. ? sc[S_VSCALE] : 1.0;
+  {
+    const double ss = part_sum(vpart, nvp, sm);
+    if (threadIdx.x == 0) {
+      bc = sqrt((double)l) / fmax(sqrt(ss), 1e-300);
+      if (blockIdx.x == 0) sc[S_VSCALE] = bc;
+    }
+    __syncthreads();
+  }
+  const double scale = params[P_DO_SCALE] != 0. ? bc : 1.0;
   const double tau = u[l - 1];
   double mx = 0., mr = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
@@ -184,6 +189,34 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part,
 __global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n, const int *fl) {
   if (!fl[F_ZERO_RHS]) return;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) x[i] = 0.;
+}
+
+// ADMM path: k_fin_tol + k_fin_cg_init + the CG step counter reset + the zero-rhs short circuit in ONE
+// single-workgroup launch after the fused CG start (the two SpMVs of the start do not depend on the tolerance).
+//   prep_part = k_prep's [max |ws| (np_p) | max |rhs| (np_p)],  r0_part = EpiR0's [sum r0'M r0 (np_r) | max |r0| (np_r)]
+__global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_part, int np_p, const double *r0_part, int np_r,
+                                                          const double *params, double *sc, int *fl, double *ut, long nm) {
+  __shared__ double sm[kVecThreads / 64];
+  __shared__ int zero_rhs;
+  const double ws = part_max(prep_part, np_p, sm);
+  const double rhs = part_max(prep_part + np_p, np_p, sm);
+  const double ztr = part_sum(r0_part, np_r, sm);
+  const double rn = part_max(r0_part + np_r, np_r, sm);
+  if (threadIdx.x == 0) {
+    const double tol = fmax(1e-12, 0.2 * fmin(params[P_RES_MIN], ws / params[P_IPOW]));
+    const int zero = (rhs <= 1e-12) ? 1 : 0;
+    sc[S_TOL] = tol;
+    sc[S_WSNORM] = ws;
+    sc[S_RNORM] = rn;
+    sc[((fl[F_STEP] + 1) & 1) ? S_ZTR_B : S_ZTR] = ztr;  // the first CG step bumps F_STEP, then reads this slot
+    fl[F_ZERO_RHS] = zero;
+    fl[F_ITERS] = 0;
+    fl[F_DONE] = (zero || rn < fmax(tol, 1e-12)) ? 1 : 0;
+    zero_rhs = zero;
+  }
+  __syncthreads();
+  if (zero_rhs)  // zero right-hand side => zero solution (happens at most at the first iteration of a cold start)
+    for (long i = threadIdx.x; i < nm; i += kVecThreads) ut[i] = 0.;
 }
 
 // x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r].
@@ -309,36 +342,40 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_store_sum(const double *par
   if (threadIdx.x == 0) sc[slot] = s;
 }
 
-// tau_tilde = positive root of the scalar quadratic
-__global__ __launch_bounds__(kVecThreads) void k_fin_tau(const double *part, int np, const double *v, const double *diag_r,
-                                                         long l, const double *params, double *sc) {
-  const int first_iter = params[P_FIRST] != 0.;
-  __shared__ double sm[kVecThreads / 64];
-  const double pg = part_sum(part, np, sm);
-  const double pp = part_sum(part + np, np, sm);
-  const double pmu = part_sum(part + 2 * np, np, sm);
-  const double mug = part_sum(part + 3 * np, np, sm);
-  if (threadIdx.x == 0) {
-    double t = 1.0;
-    if (!first_iter) {
-      const double tau_scale = diag_r[l - 1], eta = v[l - 1];
-      const double a = tau_scale + sc[S_GG];
-      const double b = mug - 2 * pg - eta * tau_scale;
-      const double c = pp - pmu;
-      t = (-b + sqrt(fmax(b * b - 4 * a * c, 0.))) / (2 * a);
-    }
-    sc[S_TAUT] = t;
-  }
+// tau_tilde = positive root of the scalar quadratic from the partials of k_tau_dots
+__device__ __forceinline__ double tau_root(double pg, double pp, double pmu, double mug, double eta, double tau_scale, double gg,
+                                           int first_iter) {
+  if (first_iter) return 1.0;
+  const double a = tau_scale + gg;
+  const double b = mug - 2 * pg - eta * tau_scale;
+  const double c = pp - pmu;
+  return (-b + sqrt(fmax(b * b - 4 * a * c, 0.))) / (2 * a);
 }
 
 // u_t -= tau_t g;  u = 2 u_t - v;  free / zero-cone / nonnegative rows finished here
 //   x rows: identity.  zero-cone rows: dual cone is free -> identity.  l rows: max(.,0).
+// tau_t is formed in the prologue: every workgroup reduces the four k_tau_dots partial arrays in the same
+// fixed order (no single-workgroup finalize launch in between); workgroup 0 publishes it in sc[S_TAUT].
 __global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
                                                           const double *__restrict__ g, int n, int m, int nz, int nl,
-                                                          const double *params, const double *sc) {
+                                                          const double *params, double *sc, const double *tau_part, int np,
+                                                          const double *__restrict__ diag_r) {
   const long l = (long)n + m + 1;
   const int first_iter = params[P_FIRST] != 0.;
-  const double taut = sc[S_TAUT];
+  __shared__ double sm[kVecThreads / 64];
+  __shared__ double bc;
+  {
+    const double pg = part_sum(tau_part, np, sm);
+    const double pp = part_sum(tau_part + np, np, sm);
+    const double pmu = part_sum(tau_part + 2 * np, np, sm);
+    const double mug = part_sum(tau_part + 3 * np, np, sm);
+    if (threadIdx.x == 0) {
+      bc = tau_root(pg, pp, pmu, mug, v[l - 1], diag_r[l - 1], sc[S_GG], first_iter);
+      if (blockIdx.x == 0) sc[S_TAUT] = bc;
+    }
+    __syncthreads();
+  }
+  const double taut = bc;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
     if (i < l - 1) {
       const double t = ut[i] - taut * g[i];
@@ -360,11 +397,19 @@ __global__ __launch_bounds__(kVecThreads) void k_rsk(double *rsk, const double *
     rsk[i] = (v[i] + u[i] - 2 * ut[i]) * diag_r[i];
 }
 
-// v += alpha (u - u_t)
+// v += alpha (u - u_t); vpart[block] = partial ||v_new||^2 — same partition and order as k_sumsq, so the next
+// iteration's k_prep normalises with the same bits as if k_sumsq had run
 __global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const double *__restrict__ u, const double *__restrict__ ut,
-                                                          double alpha, long l) {
-  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
-    v[i] += alpha * (u[i] - ut[i]);
+                                                          double alpha, long l, double *vpart) {
+  __shared__ double sm[kVecThreads / 64];
+  double s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
+    const double vi = v[i] + alpha * (u[i] - ut[i]);
+    v[i] = vi;
+    s += vi * vi;
+  }
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) vpart[blockIdx.x] = s;
 }
 
 // after a scale update: v = rsk / R+ + 2 u_t - u

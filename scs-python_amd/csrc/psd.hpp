@@ -70,7 +70,7 @@ constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * siz
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T, V' (NP*NP each), W (NB/2 * 16x17), lam (NP), state (8)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T, V' (NP*NP each), W (NB/2 * 16x17), rotation log, lam (NP), state (8)
   int count;
 };
 
@@ -80,9 +80,14 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
   if (nb < 2) nb = 2;
   return nb * kPsdB;
 }
+constexpr int kPsdLogSweeps = 4;  // split mode: sweeps whose pivot rotations fit in the log of one round
+__host__ __device__ inline long psd_log_doubles(long n) {  // rotation log: sweeps x steps x pivots x 16x17
+  const long np = psd_np(n), nb = np / kPsdB;
+  return (long)kPsdLogSweeps * (nb - 1) * (nb / 2) * kPsdWsz;
+}
 __host__ __device__ inline long psd_scratch_doubles(long n) {
   const long np = psd_np(n);
-  return 4 * np * np + (np / 16) * kPsdWsz + np + 8;
+  return 4 * np * np + (np / 16) * kPsdWsz + psd_log_doubles(n) + np + 8;
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -209,7 +214,84 @@ __device__ __forceinline__ void mma_row(const double *__restrict__ Aop, const do
   }
 }
 
-__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm) {
+// ---- X+ = V F V' with F = Pi_+(D + E) to second order in the remaining off-diagonal part E of A = D + E ----
+// (one 1024-lane workgroup; A is overwritten by F, Tm by V F; Sw = this wave's 16x17 LDS scratch)
+__device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double *A, const double *V, double *Tm, double *lam,
+                                                double *Sw) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int ld = NP, ntile = NP / 16;
+  const double sq2 = 1.41421356237309504880;
+  // The sweeps stop at ||E||_F <= 1e-8 ||A||_F, one sweep earlier than a plain V max(D,0) V' would allow
+  // (its error is first order in E).  For a matrix function f applied to a nearly diagonal matrix,
+  //   f(D + E)_ij = f(d_i) delta_ij + E_ij (f(d_i) - f(d_j)) / (d_i - d_j) + O(|E|^2 / gap)      (Daleckii-Krein),
+  // and for f = max(., 0) the divided difference is 1 (both positive), 0 (both non-positive) or
+  // hi / (hi - lo) in (0, 1] for a pair straddling zero — always well defined.  The eigenvalue estimates d_i are
+  // themselves second-order accurate, so the result is good to ~|E|^2 = 1e-16 relative.
+  for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
+  __syncthreads();
+  for (int e = tid; e < NP * NP; e += kPsdThreads) {
+    const int i = e % NP, j = e / NP;
+    const double di = lam[i], dj = lam[j];
+    if (i == j) {
+      A[e] = fmax(di, 0.);
+    } else {
+      const double hi = fmax(di, dj), lo = fmin(di, dj);
+      const double gdd = lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo));
+      A[e] *= gdd;
+    }
+  }
+  __syncthreads();
+  // T = V F  (F symmetric: read by rows; stored through the 16x17 LDS transpose so that li runs down the columns of Tm)
+  const int ngrp_r = (ntile + kPsdNJ - 1) / kPsdNJ;
+  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
+    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+    f64x4 acc[kPsdNJ];
+    mma_row(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
+#pragma unroll
+    for (int j = 0; j < kPsdNJ; ++j) {
+      const int tj = tj0 + j;
+      if (tj >= ntile) break;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+      wave_sync();
+    }
+  }
+  __syncthreads();
+
+  // ---- X+ = T V' : lower-triangular 16x16 output tiles ----
+  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
+    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+    if (tj0 > ti) continue;
+    f64x4 acc[kPsdNJ];
+    mma_row(Tm, V, ld, NP, ti, tj0, ti, li, lk, acc);
+#pragma unroll
+    for (int jj = 0; jj < kPsdNJ; ++jj) {
+      const int tj = tj0 + jj;
+      if (tj > ti) break;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
+        if (i < n && j <= i) {
+          const long base = (long)j * n - (long)j * (j - 1) / 2;
+          X[base + (i - j)] = (i == j) ? acc[jj][t] : acc[jj][t] * sq2;
+        }
+      }
+    }
+  }
+}
+
+// MODE 0: the whole projection in one launch (one workgroup = one CU per matrix; right when the batch fills the GPU).
+// MODE 1: split mode for small batches of large matrices (config 4: 50 matrices on 256 CUs).  This kernel then only
+//   diagonalises A (pivots + A updates) and LOGS every pivot's 16x16 rotation; k_psd_apply_v applies the logged
+//   rotations to V with one workgroup per 16-row strip of V (13 x 50 workgroups instead of 50: the V update is 2/3
+//   of the update work) and k_psd_recon forms X+.  A round logs at most kPsdLogSweeps sweeps; the host enqueues
+//   [sweep, apply] rounds back to back, later rounds return at once when the matrix has already converged
+//   (state[1]).  Same rotations, same MFMA sequences on V: bit-identical to MODE 0.
+template <int MODE>
+__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
   //      inner N=16 schedule (15*16 bytes)
@@ -233,8 +315,9 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   double *Tm = V + (size_t)NP * NP;  // scaled eigenvectors for the reconstruction / temp of the warm start
   double *Vt = Tm + (size_t)NP * NP;  // V' for the warm start's GEMMs (every operand load then runs down a column)
   double *Wg = Vt + (size_t)NP * NP;  // H pivots' rotation blocks, 16x17 doubles each (used when H > 16)
-  double *lam = Wg + (size_t)H * kPsdWsz;
-  double *state = lam + NP;           // state[0] = number of consecutive warm-started calls (0 = V invalid)
+  double *Wlog = Wg + (size_t)H * kPsdWsz;  // split mode: (step, pivot) -> 16x17 rotation, steps of this round
+  double *lam = Wlog + psd_log_doubles(n);
+  double *state = lam + NP;           // [0] consecutive warm-started calls (0 = V invalid); split mode: [1] converged, [2] steps logged
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
 #if PSD_PROFILE
   double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};  // [1] unpack [2] warm GEMMs [3] pivots [4] updates [5] norms+schedule [6] reconstruct [7] sweeps
@@ -250,8 +333,21 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   // them in) stays at machine precision for arbitrarily long solves.
   const bool warm = allow_warm && state[0] >= 1.;
   const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
-  __syncthreads();  // everyone has read state[0]
+  const bool resumed = MODE == 1 && round > 0;  // a later round of the split mode: A is already being diagonalised
+  const bool finished = resumed && state[1] != 0.;
+  __syncthreads();  // everyone has read state[]
+  if (MODE == 1) {
+    if (tid == 0) {
+      state[2] = 0.;  // steps logged in this round
+      if (round == 0) state[1] = 0.;
+    }
+    if (finished) return;  // converged in an earlier round: nothing to log, k_psd_apply_v has nothing to do
+  }
+  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nblk = H * (H + 1) / 2, ntile = NP / 16;
 
+  if (!resumed) {
   // ---- unpack (lower tri, col-major, off-diag / sqrt2), zero padding; V = I when cold; inner schedule ----
   for (int e = tid; e < NP * NP; e += kPsdThreads) {
     const int i = e % NP, j = e / NP;
@@ -278,9 +374,6 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 
   PSD_TICK(t_unpacked);
   PSD_ACC(1, t_begin, t_unpacked);
-  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
-  const int li = lane & 15, lk = lane >> 4;
-  const int nblk = H * (H + 1) / 2, ntile = NP / 16;
 
   if (warm) {
     // A0 = V' A V as two GEMMs whose operand loads all run down columns (li contiguous: full 128-byte lines):
@@ -406,6 +499,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
+  }  // !resumed
+  int nlog = 0;  // split mode: steps logged in this round
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_sw0);
     double off = 0., tot = 0.;
@@ -427,7 +522,11 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     __syncthreads();
     PSD_TICK(t_sw1);
     PSD_ACC(5, t_sw0, t_sw1);
-    if (done) break;
+    if (done) {
+      if (MODE == 1 && tid == 0) state[1] = 1.;
+      break;
+    }
+    if (MODE == 1 && sweep >= kPsdLogSweeps) break;  // log full: the next round continues
 #if PSD_PROFILE
     prof[7] += 1.;
 #endif
@@ -454,6 +553,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
         wave_jacobi16(Sw, Ww, lane);
         if (!w_in_lds)
           for (int e = lane; e < kPsdWsz; e += 64) Wg[(size_t)k * kPsdWsz + e] = Ww[e];
+        if (MODE == 1)
+          for (int e = lane; e < kPsdWsz; e += 64) Wlog[((size_t)nlog * H + k) * kPsdWsz + e] = Ww[e];
       }
       __syncthreads();
       PSD_TICK(t_s2);
@@ -464,7 +565,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       // runs its MFMAs and stores (all waves reach the same phase at the same time, so without this the
       // matrix cores idle during the loads and the memory path idles during the MFMAs).
       {
-        const int ntask = nblk + H * ntile;
+        const int ntask = MODE == 1 ? nblk : nblk + H * ntile;  // split mode: the V tasks run in k_psd_apply_v
         auto decode = [&](int task, int &k, int &k2) {  // A task: (k, k2 >= k); V task: (k, row tile) with k2 = -1 - tile
           if (task < nblk) {
             int kk = 0, rem = task;
@@ -558,72 +659,17 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       __syncthreads();
       PSD_TICK(t_s3);
       PSD_ACC(4, t_s2, t_s3);
+      ++nlog;
     }
   }
   PSD_TICK(t_swept);
+  if (MODE == 1) {
+    if (tid == 0) state[2] = (double)nlog;
+    return;
+  }
 
-  // ---- X+ = V F V' with F = Pi_+(D + E) to second order in the remaining off-diagonal part E of A = D + E ----
-  // The sweeps stop at ||E||_F <= 1e-8 ||A||_F, one sweep earlier than a plain V max(D,0) V' would allow
-  // (its error is first order in E).  For a matrix function f applied to a nearly diagonal matrix,
-  //   f(D + E)_ij = f(d_i) delta_ij + E_ij (f(d_i) - f(d_j)) / (d_i - d_j) + O(|E|^2 / gap)      (Daleckii-Krein),
-  // and for f = max(., 0) the divided difference is 1 (both positive), 0 (both non-positive) or
-  // hi / (hi - lo) in (0, 1] for a pair straddling zero — always well defined.  The eigenvalue estimates d_i are
-  // themselves second-order accurate, so the result is good to ~|E|^2 = 1e-16 relative.
-  for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
   if (tid == 0) state[0] = warm ? state[0] + 1. : 1.;
-  __syncthreads();
-  for (int e = tid; e < NP * NP; e += kPsdThreads) {
-    const int i = e % NP, j = e / NP;
-    const double di = lam[i], dj = lam[j];
-    if (i == j) {
-      A[e] = fmax(di, 0.);
-    } else {
-      const double hi = fmax(di, dj), lo = fmin(di, dj);
-      const double gdd = lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo));
-      A[e] *= gdd;
-    }
-  }
-  __syncthreads();
-  // T = V F  (F symmetric: read by rows; stored through the 16x17 LDS transpose so that li runs down the columns of Tm)
-  const int ngrp_r = (ntile + kPsdNJ - 1) / kPsdNJ;
-  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
-    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
-    f64x4 acc[kPsdNJ];
-    mma_row(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
-#pragma unroll
-    for (int j = 0; j < kPsdNJ; ++j) {
-      const int tj = tj0 + j;
-      if (tj >= ntile) break;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
-      wave_sync();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-      wave_sync();
-    }
-  }
-  __syncthreads();
-
-  // ---- X+ = T V' : lower-triangular 16x16 output tiles ----
-  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
-    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
-    if (tj0 > ti) continue;
-    f64x4 acc[kPsdNJ];
-    mma_row(Tm, V, ld, NP, ti, tj0, ti, li, lk, acc);
-#pragma unroll
-    for (int jj = 0; jj < kPsdNJ; ++jj) {
-      const int tj = tj0 + jj;
-      if (tj > ti) break;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
-        if (i < n && j <= i) {
-          const long base = (long)j * n - (long)j * (j - 1) / 2;
-          X[base + (i - j)] = (i == j) ? acc[jj][t] : acc[jj][t] * sq2;
-        }
-      }
-    }
-  }
+  psd_reconstruct(X, n, NP, A, V, Tm, lam, Sw);
 #if PSD_PROFILE
   __syncthreads();
   PSD_TICK(t_end);
@@ -631,6 +677,67 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   if (tid == 0)
     for (int i = 1; i < 8; ++i) state[i] = prof[i];
 #endif
+}
+
+// Split mode, V <- V W_1 W_2 ... : one 256-lane workgroup per (matrix, 16-row strip of V).  The strip lives in LDS
+// (16 x NP doubles); step t rotates, for every pivot (p,q) of that step, the strip's 16 columns {block p, block q}
+// by the logged 16x16 W — 4 MFMAs per pivot, the same instruction sequence as the in-kernel V tasks of MODE 0.
+constexpr int kPsdApplyThreads = 256;
+__global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, double *scratch) {
+  extern __shared__ __attribute__((aligned(16))) double strip[];  // [row + 16 * col]
+  const int n = B.order[blockIdx.y];
+  if (n < 2) return;
+  const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP, ntile = NP / 16;
+  const int rt = blockIdx.x;
+  if (rt >= ntile) return;
+  double *A = scratch + B.woff[blockIdx.y];
+  double *V = A + (size_t)NP * NP;
+  const double *Wlog = V + 3 * (size_t)NP * NP + (size_t)H * kPsdWsz;
+  const double *state = Wlog + psd_log_doubles(n) + NP;
+  const int nsteps = (int)state[2];
+  if (nsteps == 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) strip[e] = V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)];
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    const int r = t % (NB - 1);
+    for (int k = wave; k < H; k += kPsdApplyThreads / 64) {
+      int p, q;
+      rr_pair(r, k, NB, p, q);
+      const double *W1 = Wlog + ((size_t)t * H + k) * kPsdWsz;
+      double av[4], w[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        av[kk] = strip[li + 16 * pq_index(4 * kk + lk, p, q)];
+        w[kk] = W1[(4 * kk + lk) + kPsdWLd * li];
+      }
+      f64x4 T = {0., 0., 0., 0.};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) T = __builtin_amdgcn_mfma_f64_16x16x4f64(w[kk], av[kk], T, 0, 0, 0);  // (V_blk W)'
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) strip[li + 16 * pq_index(lk + 4 * tt, p, q)] = T[tt];
+    }
+    __syncthreads();  // the next step pairs the column blocks differently
+  }
+  for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)] = strip[e];
+}
+
+// Split mode, last kernel: X+ from the diagonalised A and the updated V (one workgroup per matrix).
+__global__ __launch_bounds__(kPsdThreads) void k_psd_recon(double *x, PsdBatch B, double *scratch, int allow_warm) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  const int n = B.order[blockIdx.x];
+  if (n < 2) return;  // orders 0 and 1 were finished by the sweep kernel
+  const int NP = (int)psd_np(n), H = NP / kPsdB / 2;
+  double *A = scratch + B.woff[blockIdx.x];
+  double *V = A + (size_t)NP * NP;
+  double *Tm = V + (size_t)NP * NP;
+  double *lam = Tm + 2 * (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n);
+  double *state = lam + NP;
+  const bool warm = allow_warm && state[0] >= 1.;
+  __syncthreads();
+  if (threadIdx.x == 0) state[0] = warm ? state[0] + 1. : 1.;
+  psd_reconstruct(x + B.off[blockIdx.x], n, NP, A, V, Tm, lam, lds + (threadIdx.x >> 6) * kPsdWaveLds);
 }
 
 // ---------------------------------------------------------------------------

@@ -243,6 +243,10 @@ struct ScsHipWork {
   DevBuf<long> psd_woff;
   DevBuf<double> psd_scratch;
   int n_psd = 0, n_psd_big = 0;
+  // split mode of the block kernel (psd.hpp): worth it when the large matrices alone leave most CUs idle
+  static constexpr int kPsdSplitRounds = 3;  // x kPsdLogSweeps sweeps: a cold start needs ~9
+  bool psd_split = false;
+  int psd_max_np = 0, psd_max_tiles = 0;
   // complex PSD cones: projected through the packed 2k x 2k real embedding held in cs_stage (psd.hpp)
   DevBuf<int> cs_off, cs_order, cs_poff, cs_porder;  // same ordering: embeddings of order > kPsdSmallMax first
   DevBuf<long> cs_soff, cs_woff;
@@ -253,7 +257,17 @@ struct ScsHipWork {
   void launch_psd(double *base, const int *off, const int *order, const long *woff, int count, int big) {
     if (big > 0) {
       PsdBatch B{off, order, woff, big};
-      hipLaunchKernelGGL(k_proj_psd, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm);
+      if (psd_split) {
+        // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
+        for (int round = 0; round < kPsdSplitRounds; ++round) {
+          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round);
+          hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
+                             stream, B, psd_scratch.p);
+        }
+        hipLaunchKernelGGL(k_psd_recon, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm);
+      } else {
+        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0);
+      }
     }
     if (count > big) {
       PsdBatch B{off + big, order + big, woff + big, count - big};
@@ -905,6 +919,17 @@ static void upload_cone_meta(ScsHipWork *w) {
     w->cs_stage.alloc_zero((size_t)std::max(stot, 1L), s);
   }
   if (w->n_psd || w->n_cs) w->psd_scratch.alloc_zero((size_t)std::max(wtot, 1L), s);
+  {
+    int big_total = 0, max_order = 0;
+    for (int sdim : c.s)
+      if (sdim > kPsdSmallMax) { ++big_total; max_order = std::max(max_order, sdim); }
+    for (int k : c.cs)
+      if (2 * k > kPsdSmallMax) { ++big_total; max_order = std::max(max_order, 2 * k); }
+    w->psd_max_np = (int)psd_np(std::max(max_order, 2));
+    w->psd_max_tiles = w->psd_max_np / 16;
+    w->psd_split = big_total > 0 && big_total <= 128;  // one CU per matrix leaves at least half of the GPU idle
+    if (const char *env = getenv("SCS_HIP_PSD_SPLIT")) w->psd_split = big_total > 0 && env[0] == '1';  // A/B and tests
+  }
   HIP_CHECK(hipStreamSynchronize(s));
 }
 

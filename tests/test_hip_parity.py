@@ -408,3 +408,26 @@ def test_persistent_cg_bit_identical(hip, oracle, monkeypatch, cfg, with_P):
     assert got["info"]["status"] == ref["info"]["status"]
     for key in ("x", "y", "s"):
         np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+
+
+# ---- K9 split mode (sweeps on one CU + V updates / reconstruction on the others) vs the one-launch kernel ----
+def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
+    rng = np.random.RandomState(11)
+    K = {"l": 5, "s": [40, 64, 33, 100], "cs": [20]}
+    z = rng.randn(pg.cone_dims(K))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_PSD_SPLIT", mode)
+        out[mode] = hip.proj_cone(z, K)
+    np.testing.assert_array_equal(out["0"], out["1"])
+    # and through a full solve (warm-started calls, re-orthogonalisation, several [sweep, apply] rounds)
+    K = {"l": 30, "s": [40, 35]}
+    data, _, _ = pg.gen_feasible_qp(K, 500, 6, 21, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    sols = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_PSD_SPLIT", mode)
+        sols[mode] = hip.SCS(*args, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iters=300).solve(False, None, None, None)
+    assert sols["0"]["info"]["iter"] == sols["1"]["info"]["iter"]
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)

@@ -17,6 +17,7 @@ using namespace scship;
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 200, cnt = argc > 2 ? atoi(argv[2]) : 50, calls = argc > 3 ? atoi(argv[3]) : 6;
   const double pert = argc > 4 ? atof(argv[4]) : 1e-3;
+  const bool split = argc > 5 && atoi(argv[5]) != 0;
   const long vlen = (long)n * (n + 1) / 2;
   std::vector<int> off(cnt), ord(cnt, n);
   std::vector<long> woff(cnt);
@@ -33,7 +34,7 @@ int main(int argc, char **argv) {
   HIP_CHECK(hipMemcpy(d_ord, ord.data(), cnt * 4, hipMemcpyHostToDevice));
   HIP_CHECK(hipMemcpy(d_woff, woff.data(), cnt * 8, hipMemcpyHostToDevice));
   HIP_CHECK(hipMemset(d_scr, 0, wtot * 8));
-  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_psd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsdLdsBytes));
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_psd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsdLdsBytes));
   PsdBatch B{d_off, d_ord, d_woff, cnt};
   hipEvent_t e0, e1;
   HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
@@ -46,7 +47,13 @@ int main(int argc, char **argv) {
     HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipEventRecord(e0));
     if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1);
-    else hipLaunchKernelGGL(k_proj_psd, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1);
+    else if (split) {
+      for (int round = 0; round < 3; ++round) {
+        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round);
+        hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr);
+      }
+      hipLaunchKernelGGL(k_psd_recon, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1);
+    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0);
     HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     double st[8];

@@ -164,12 +164,17 @@ __device__ inline void wave_jacobi16(double *S, double *W, int lane) {
       rr16(r, lane & 7, p, q);
       rr16(r, lane >> 3, p2, q2);
       const double dpp = S[p + kPsdLd * p], dqq = S[q + kPsdLd * q], dpq = S[p + kPsdLd * q];
-      const double epp = S[p2 + kPsdLd * p2], eqq = S[q2 + kPsdLd * q2], epq = S[p2 + kPsdLd * q2];
       const double app = S[p + kPsdLd * p2], apq = S[p + kPsdLd * q2], aqp = S[q + kPsdLd * p2], aqq = S[q + kPsdLd * q2];
       const double wp0 = W[i0 + kPsdWLd * p], wq0 = W[i0 + kPsdWLd * q], wp1 = W[i1 + kPsdWLd * p], wq1 = W[i1 + kPsdWLd * q];
-      double c = 1., s = 0., c2 = 1., s2 = 0.;
-      if (fabs(dpq) > 1e-300) jacobi_rot(dpp, dqq, dpq, c, s);
-      if (fabs(epq) > 1e-300) jacobi_rot(epp, eqq, epq, c2, s2);
+      // rotation of this lane's row pair k = lane & 7 (branch-free; the 8 lanes sharing k compute the same bits);
+      // the column pair's rotation (k2 = lane >> 3) is lane k2's own: fetched by a wave shuffle instead of a second
+      // evaluation (the 13 concurrent pivot solves of an order-200 matrix are VALU-bound, not latency-bound)
+      const bool rot = fabs(dpq) > 1e-300;
+      double c, s;
+      jacobi_rot(dpp, dqq, rot ? dpq : 1.0, c, s);
+      c = rot ? c : 1.;
+      s = rot ? s : 0.;
+      const double c2 = __shfl(c, lane >> 3, 64), s2 = __shfl(s, lane >> 3, 64);
       wave_sync();  // every lane has read S and W of the previous round's state
       const double t1 = c2 * app - s2 * apq, t2 = s2 * app + c2 * apq;
       const double t3 = c2 * aqp - s2 * aqq, t4 = s2 * aqp + c2 * aqq;

@@ -42,7 +42,8 @@ static double now_ms() {
 
 // ---------------------------------------------------------------- device CSR
 struct DeviceCsr {
-  DevBuf<int> rowptr, col, rowblk;
+  DevBuf<int> rowptr, col;
+  DevBuf<int4> rowblk;
   DevBuf<double> val;
   int rows = 0, cols = 0, nblk = 0;
   long nnz = 0;
@@ -54,8 +55,8 @@ struct DeviceCsr {
   int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
   void upload(int rows_, int cols_, const int *rp, const int *ci, const double *v, hipStream_t s, bool allow_slab = true) {
     rows = rows_; cols = cols_; nnz = rp[rows_];
-    std::vector<int> rb = build_rowblocks(rp, rows);
-    nblk = (int)rb.size() - 1;
+    std::vector<int4> rb = build_rowblocks(rp, rows);
+    nblk = (int)rb.size();
     rowptr.upload(rp, rows + 1, s);
     col.upload(ci, nnz, s);
     val.upload(v, nnz, s);

@@ -25,19 +25,20 @@ namespace scship {
 
 constexpr int kSpmvThreads = 256;
 constexpr int kNnzPerWg = 2048;  // 16 KiB of LDS products per workgroup
+constexpr int kRowsPerLane = 4;  // a row block holds at most kRowsPerLane * kSpmvThreads rows
 
 // Device view of a CSR matrix plus its row-block partition.
 struct CsrView {
   const int *rowptr;
   const int *col;
   const double *val;
-  const int *rowblk;  // nblk + 1 row boundaries
+  const int4 *blk;    // per row block {first row, end row, first nonzero, end nonzero}: one load instead of a dependent pair
   int rows, cols, nblk;
   long nnz;
 };
 
 // Host-side: split rows into blocks of <= kNnzPerWg nonzeros (a longer row is alone in its block).
-inline std::vector<int> build_rowblocks(const int *rowptr, int rows) {
+inline std::vector<int> build_rowblock_bounds(const int *rowptr, int rows) {
   std::vector<int> rb;
   rb.push_back(0);
   int start = 0;
@@ -45,12 +46,19 @@ inline std::vector<int> build_rowblocks(const int *rowptr, int rows) {
     int end = start;
     long base = rowptr[start];
     // also cap rows per block so every lane has at most a few rows to reduce
-    while (end < rows && (rowptr[end + 1] - base) <= kNnzPerWg && (end - start) < 4 * kSpmvThreads) ++end;
+    while (end < rows && (rowptr[end + 1] - base) <= kNnzPerWg && (end - start) < kRowsPerLane * kSpmvThreads) ++end;
     if (end == start) end = start + 1;  // single long row
     rb.push_back(end);
     start = end;
   }
   return rb;
+}
+
+inline std::vector<int4> build_rowblocks(const int *rowptr, int rows) {
+  const std::vector<int> rb = build_rowblock_bounds(rowptr, rows);
+  std::vector<int4> out(rb.size() - 1);
+  for (size_t b = 0; b + 1 < rb.size(); ++b) out[b] = int4{rb[b], rb[b + 1], rowptr[rb[b]], rowptr[rb[b + 1]]};
+  return out;
 }
 
 // ---- epilogues -------------------------------------------------------------
@@ -187,8 +195,8 @@ __device__ __forceinline__ void spmv_stream_block(const CsrView &A, const double
     for (int i = 0; i < 3 + 2 * (Epi::kSums + Epi::kMaxs); ++i) sync();
     return;
   }
-  const int r0 = A.rowblk[b], r1 = A.rowblk[b + 1];
-  const int p0 = A.rowptr[r0], p1 = A.rowptr[r1];
+  const int4 bi = A.blk[b];
+  const int r0 = bi.x, r1 = bi.y, p0 = bi.z, p1 = bi.w;
   const int nnz = p1 - p0;
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
   double sums[NS], maxs[NM];
@@ -200,14 +208,26 @@ __device__ __forceinline__ void spmv_stream_block(const CsrView &A, const double
   if (nnz <= kNnzPerWg) {
     const double *__restrict__ v = A.val + p0;
     const int *__restrict__ c = A.col + p0;
+    // the row extents of this lane's (at most 4) rows do not depend on the products: fetch them together with
+    // the nonzeros instead of after the barrier (one global round trip less on the critical path)
+    int ra[kRowsPerLane], re[kRowsPerLane];
+#pragma unroll
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      const int r = r0 + tid + j * kSpmvThreads;
+      ra[j] = r < r1 ? A.rowptr[r] - p0 : 0;
+      re[j] = r < r1 ? A.rowptr[r + 1] - p0 : 0;
+    }
 #pragma unroll 8
     for (int k = tid; k < nnz; k += kSpmvThreads) prod[k] = v[k] * x[c[k]];
     sync();
-    for (int r = r0 + tid; r < r1; r += kSpmvThreads) {
-      const int a = A.rowptr[r] - p0, e = A.rowptr[r + 1] - p0;
-      double s = 0.;
-      for (int k = a; k < e; ++k) s += prod[k];
-      epi(r, s, sums, maxs);
+#pragma unroll
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      const int r = r0 + tid + j * kSpmvThreads;
+      if (r < r1) {
+        double s = 0.;
+        for (int k = ra[j]; k < re[j]; ++k) s += prod[k];
+        epi(r, s, sums, maxs);
+      }
     }
     if (UNIFORM) { sync(); sync(); }
   } else {  // one long row: the whole group reduces it (fixed order)

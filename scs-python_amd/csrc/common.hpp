@@ -121,6 +121,9 @@ __device__ __forceinline__ double block_max(double v, double *sm) {
   return group_max<NT>(v, sm, (int)threadIdx.x, BlockSync{});
 }
 
+// run-ahead mode of the ADMM loop (vec.hpp, F_STALL): kernels queued behind a stalled CG solve return at once
+#define SCS_STALL_GUARD(stall) do { if ((stall) && *(stall)) return; } while (0)
+
 // abs that propagates NaN into max-reductions as +inf (so a NaN iterate never passes a tolerance test)
 __device__ __forceinline__ double abs_nan_inf(double x) { return (x != x) ? INFINITY : fabs(x); }
 

@@ -29,7 +29,8 @@ constexpr int kSocBig = 4096;
 // ------------------------------------------------------------------ SOC
 // in-place Pi_SOC on slices x[off[c] .. off[c]+dim[c]); one wave per cone
 __global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const int *__restrict__ off,
-                                                                const int *__restrict__ dim, int ncones) {
+                                                                const int *__restrict__ dim, int ncones, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kConeThreads / 64) + (threadIdx.x >> 6);
   if (c >= ncones) return;
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const
 
 // one workgroup per big cone
 __global__ __launch_bounds__(kConeThreads) void k_proj_soc_block(double *x, const int *__restrict__ off,
-                                                                 const int *__restrict__ dim, const int *__restrict__ big, int nbig) {
+                                                                 const int *__restrict__ dim, const int *__restrict__ big, int nbig, const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double sm[kConeThreads / 64];
   __shared__ double bc;
   const int c = big[blockIdx.x];
@@ -112,7 +114,8 @@ __device__ inline void proj_power_cone(double *v, double a) {
 }
 
 // lane-per-cone: u = Pi_{K*}(w).  a >= 0: K = pow(a): u = w + Pi_K(-w);  a < 0: K* = pow(|a|): u = Pi_{pow(|a|)}(w)
-__global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const double *__restrict__ a, int ncones) {
+__global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const double *__restrict__ a, int ncones, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int c = blockIdx.x * kConeThreads + threadIdx.x;
   if (c >= ncones) return;
   double *w = x + 3L * c;
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const
   }
 }
 // primal-cone variant (test entry point): a >= 0: Pi_{pow(a)}(w);  a < 0: w + Pi_{pow(|a|)}(-w)
-__global__ __launch_bounds__(kConeThreads) void k_proj_pow_primal(double *x, const double *__restrict__ a, int ncones) {
+__global__ __launch_bounds__(kConeThreads) void k_proj_pow_primal(double *x, const double *__restrict__ a, int ncones, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int c = blockIdx.x * kConeThreads + threadIdx.x;
   if (c >= ncones) return;
   double *w = x + 3L * c;
@@ -317,7 +321,8 @@ __device__ inline void proj(double *v0, int primal) {
 
 // lane-per-cone.  mode 0: u = Pi_{K*}(w) for the ep block (K = K_exp): dual projection;
 //                 mode 1: ed block (K = K_exp^*): K* = K_exp: primal projection.
-__global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones, int primal) {
+__global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones, int primal, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int c = blockIdx.x * kConeThreads + threadIdx.x;
   if (c >= ncones) return;
   double *w = x + 3L * c;
@@ -331,7 +336,8 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones
 // One workgroup; Newton on t of a piecewise quadratic, warm-started from sc_t (device scalar).
 constexpr int kBoxThreads = 1024;
 __global__ __launch_bounds__(kBoxThreads) void k_proj_box(double *x, const double *__restrict__ bl, const double *__restrict__ bu,
-                                                          int bsize, double *t_warm, int dual) {
+                                                          int bsize, double *t_warm, int dual, const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double sm[kBoxThreads / 64];
   __shared__ double bc[2];
   const double sgn = dual ? -1.0 : 1.0;

@@ -296,7 +296,8 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
 //   [sweep, apply] rounds back to back, later rounds return at once when the matrix has already converged
 //   (state[1]).  Same rotations, same MFMA sequences on V: bit-identical to MODE 0.
 template <int MODE>
-__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round) {
+__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall) {
+  SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
   //      inner N=16 schedule (15*16 bytes)
@@ -688,7 +689,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 // (16 x NP doubles); step t rotates, for every pivot (p,q) of that step, the strip's 16 columns {block p, block q}
 // by the logged 16x16 W — 4 MFMAs per pivot, the same instruction sequence as the in-kernel V tasks of MODE 0.
 constexpr int kPsdApplyThreads = 256;
-__global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, double *scratch) {
+__global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, double *scratch, const int *stall) {
+  SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) double strip[];  // [row + 16 * col]
   const int n = B.order[blockIdx.y];
   if (n < 2) return;
@@ -728,7 +730,8 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, do
 }
 
 // Split mode, last kernel: X+ from the diagonalised A and the updated V (one workgroup per matrix).
-__global__ __launch_bounds__(kPsdThreads) void k_psd_recon(double *x, PsdBatch B, double *scratch, int allow_warm) {
+__global__ __launch_bounds__(kPsdThreads) void k_psd_recon(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+  SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *lds = reinterpret_cast<double *>(smem_raw);
   const int n = B.order[blockIdx.x];
@@ -758,7 +761,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_recon(double *x, PsdBatch B
 constexpr int kPsdSmallMax = 32;
 constexpr int kPsdSLd = 33;
 
-__global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm) {
+__global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double S[32 * kPsdSLd], V[32 * kPsdSLd], T[32 * kPsdSLd];
   __shared__ double csc[16], css[16];
   const int lane = threadIdx.x, cidx = blockIdx.x;
@@ -1005,7 +1009,8 @@ struct CsBatch {
 __device__ __forceinline__ long cs_col_start(long j, long k) { return j * (2 * k - j); }
 __device__ __forceinline__ long packed_idx(long I, long J, long N) { return J * N - J * (J - 1) / 2 + (I - J); }  // I >= J
 
-__global__ __launch_bounds__(256) void k_cs_expand(const double *__restrict__ x, CsBatch B, double *stage) {
+__global__ __launch_bounds__(256) void k_cs_expand(const double *__restrict__ x, CsBatch B, double *stage, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int c = blockIdx.x;
   const long k = B.order[c], N = 2 * k;
   const double *X = x + B.off[c];
@@ -1026,7 +1031,8 @@ __global__ __launch_bounds__(256) void k_cs_expand(const double *__restrict__ x,
   }
 }
 
-__global__ __launch_bounds__(256) void k_cs_extract(double *x, CsBatch B, const double *__restrict__ stage) {
+__global__ __launch_bounds__(256) void k_cs_extract(double *x, CsBatch B, const double *__restrict__ stage, const int *stall) {
+  SCS_STALL_GUARD(stall);
   const int c = blockIdx.x;
   const long k = B.order[c], N = 2 * k;
   double *X = x + B.off[c];

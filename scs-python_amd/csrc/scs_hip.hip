@@ -208,7 +208,15 @@ struct ScsHipWork {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   double *h_pin = nullptr;  // pinned scalars
   int *h_flags = nullptr;   // pinned flags
-  double *h_params = nullptr, *d_params = nullptr;  // mapped pinned per-iteration scalars (P_*)
+  double *h_params = nullptr, *d_params = nullptr;  // mapped pinned per-iteration scalars (P_*), slot in use (2 slots)
+  double *h_params_base = nullptr, *d_params_base = nullptr;
+  // run-ahead mode (see F_STALL in vec.hpp): plain iterations are enqueued whole and one ahead of the host's view
+  bool pipelined = false;
+  int pipe_chunk_override = 0, pipe_stalls = 0;  // tests: SCS_HIP_PIPE_CHUNK forces short CG chunks (=> stalls)
+  const int *stall = nullptr;      // fl + F_STALL while a run-ahead iteration is being enqueued, else nullptr
+  int *stall_fl = nullptr;         // fl (or nullptr): k_tau_dots raises the stall, k_cone_pre parks the CG kernels
+  int *h_flags_slot[2] = {nullptr, nullptr};
+  hipEvent_t ev_iter[2] = {nullptr, nullptr};
 
   // hipGraphs of the launch-bound inner loop (built lazily at the first solve):
   //   g_pre[i] : iterate normalisation, rhs, CG start + kGraphSteps[i] CG steps + flag read-back
@@ -261,18 +269,18 @@ struct ScsHipWork {
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
         for (int round = 0; round < kPsdSplitRounds; ++round) {
-          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round);
+          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
-                             stream, B, psd_scratch.p);
+                             stream, B, psd_scratch.p, stall);
         }
-        hipLaunchKernelGGL(k_psd_recon, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm);
+        hipLaunchKernelGGL(k_psd_recon, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, stall);
       } else {
-        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0);
+        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
       }
     }
     if (count > big) {
       PsdBatch B{off + big, order + big, woff + big, count - big};
-      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm);
+      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall);
     }
   }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
@@ -305,7 +313,9 @@ struct ScsHipWork {
     if (g_post) (void)hipGraphExecDestroy(g_post);
     if (h_pin) (void)hipHostFree(h_pin);
     if (h_flags) (void)hipHostFree(h_flags);
-    if (h_params) (void)hipHostFree(h_params);
+    if (h_params_base) (void)hipHostFree(h_params_base);
+    for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
+    for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
@@ -389,7 +399,7 @@ struct ScsHipWork {
         return done_iters;
       }
     }
-    const bool use_graph = started && xout == ut.p;  // graphs are captured for the ADMM buffers only
+    const bool use_graph = started && xout == ut.p && graphs_ready;  // graphs are captured for the ADMM buffers only
     double *yacc = (xout == ut.p) ? ut.p + n : nullptr;  // ADMM path carries the y block along the recurrence
     int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 2, 64));  // a host round trip costs ~30 us, an unused CG step four ~1 us launches
     while (true) {
@@ -460,7 +470,9 @@ struct ScsHipWork {
   }
 
   // ------------------------------------------------------------ ADMM steps
-  void set_iter_params(int iter) {
+  void set_iter_params(int iter, int slot = 0) {
+    h_params = h_params_base + slot * P_COUNT;
+    d_params = d_params_base + slot * P_COUNT;
     h_params[P_DO_SCALE] = iter >= 1 ? 1.0 : 0.0;
     h_params[P_RES_MIN] = cg_res_min;  // residuals of the last convergence CHECK (not of a logging-only evaluation)
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
@@ -471,16 +483,16 @@ struct ScsHipWork {
     const int nbl = vb(l);
     // (the sum-of-squares partials of v are in part_v: enqueue_v_update of the previous iteration or ensure_v_norm)
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
-                       d_params, part_v.p, nbl, sc.p, part2.p);
+                       d_params, part_v.p, nbl, sc.p, part2.p, stall);
     // y0 = v_y + R_y^{-1} A ws   (start of the y recurrence, lives in ut_y)
-    launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, nullptr, stream);
+    launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, stall, stream);
     // r0 = R_x (v_x - ws) - P ws - A' y0 ; p0 = M r0 ; partials for ||r0||_inf and r0'M r0
-    if (has_P) launch_spmv(Pf.view(), ws.p, EpiStore{cg_Gp.p, 0}, nullptr, stream);
+    if (has_P) launch_spmv(Pf.view(), ws.p, EpiStore{cg_Gp.p, 0}, stall, stream);
     launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, diag_r.p, v.p, ws.p, has_P ? cg_Gp.p : nullptr, part.p},
-                nullptr, stream);
+                stall, stream);
     // tolerance, ||r0||, r0'M r0, step counter, zero-rhs short circuit: one finalize launch
     hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
-                       ut.p, (long)n + m);
+                       ut.p, (long)n + m, stall);
   }
   // ||v||^2 partials for k_prep when something other than enqueue_v_update wrote v (start, AA, scale update)
   void ensure_v_norm() {
@@ -492,7 +504,7 @@ struct ScsHipWork {
   void enqueue_lin_sys_persist() {
     const int nbl = vb(l);
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
-                       d_params, part_v.p, nbl, sc.p, part2.p);
+                       d_params, part_v.p, nbl, sc.p, part2.p, stall);
     CgPersistArgs a{};
     a.Ar = Ar.view().csr; a.At = At.view().csr;
     if (has_P) a.Pf = Pf.view().csr;
@@ -518,15 +530,66 @@ struct ScsHipWork {
   // tau (the y block is already in ut_y: it was carried along the CG recurrence)
   void enqueue_lin_sys_tail() {
     const int nb1 = vb(l - 1);
-    hipLaunchKernelGGL(k_tau_dots, dim3(nb1), dim3(kVecThreads), 0, stream, ut.p, v.p, g.p, diag_r.p, l - 1, part.p);
+    hipLaunchKernelGGL(k_tau_dots, dim3(nb1), dim3(kVecThreads), 0, stream, ut.p, v.p, g.p, diag_r.p, l - 1, part.p, stall_fl);
   }
   void enqueue_cones() {  // (tau is formed in k_cone_pre's prologue from the k_tau_dots partials)
     hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
-                       d_params, sc.p, part.p, vb(l - 1), diag_r.p);
+                       d_params, sc.p, part.p, vb(l - 1), diag_r.p, stall_fl);
     project_nonlinear_cones(u.p + n, 1);
   }
   void enqueue_v_update() {
-    hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l, part_v.p);
+    hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l, part_v.p, stall);
+    v_norm_fresh = true;
+  }
+
+  // ---- run-ahead mode: one whole plain iteration (no convergence check, no AA, no logging) in the queue ----
+  // head + CG chunk + tau/cones/v update + flag copy + event; nothing here waits for the device.
+  void enqueue_plain_iteration(int iter) {
+    const int slot = iter & 1;
+    set_iter_params(iter, slot);
+    ensure_v_norm();
+    stall = fl.p + F_STALL;
+    stall_fl = fl.p;
+    enqueue_lin_sys_head();
+    int chunk = std::max(2, last_cg_iters + 3);  // the count is one iteration stale here (is_plain caps it)
+    if (pipe_chunk_override > 0) chunk = pipe_chunk_override;
+    for (int k = 0; k < chunk; ++k) enqueue_cg_step(ut.p, ut.p + n);
+    enqueue_lin_sys_tail();
+    enqueue_cones();
+    enqueue_v_update();
+    stall = nullptr;
+    stall_fl = nullptr;
+    HIP_CHECK(hipMemcpyAsync(h_flags_slot[slot], fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(ev_iter[slot], stream));
+  }
+  // Wait for iteration `iter` of the run-ahead queue.  Returns false if its CG chunk was too short: the rest of that
+  // iteration and everything queued behind it did nothing; the caller finishes the iteration synchronously.
+  bool finish_plain_iteration(int iter) {
+    const int slot = iter & 1;
+    HIP_CHECK(hipEventSynchronize(ev_iter[slot]));
+    const int *hf = h_flags_slot[slot];
+    if (hf[F_STALL]) { ++pipe_stalls; return false; }
+    std::memcpy(h_flags, hf, sizeof(int) * F_COUNT);
+    process_pending_flags();  // e.g. the verdict of the Anderson safeguard enqueued in the iteration before
+    last_cg_iters = hf[F_ITERS];
+    tot_cg_iters += last_cg_iters;
+    return true;
+  }
+  // after a stall: drain the queue, lower the flags and finish iteration `iter` the synchronous way
+  void recover_stalled_iteration(int iter) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::memcpy(h_flags, h_flags_slot[iter & 1], sizeof(int) * F_COUNT);
+    h_flags[F_DONE] = 0;
+    h_flags[F_STALL] = 0;
+    const int zeros[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(fl.p + F_DONE, &zeros[0], sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(fl.p + F_STALL, &zeros[1], sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    set_iter_params(iter, iter & 1);
+    run_cg(ut.p, ws.p, 10 * n, 2);  // continues from the intact CG state (the flags say how far it got)
+    enqueue_lin_sys_tail();
+    enqueue_cones();
+    enqueue_v_update();
     v_norm_fresh = true;
   }
 
@@ -597,36 +660,36 @@ struct ScsHipWork {
   void project_nonlinear_cones(double *y, int dual) {
     if (cone.bsize > 0) {
       hipLaunchKernelGGL(k_proj_box, dim3(1), dim3(kBoxThreads), 0, stream, y + cone.off_box, box_bl.p, box_bu.p, cone.bsize,
-                         sc.p + S_BOX_T, dual);
+                         sc.p + S_BOX_T, dual, stall);
     }
     if (n_soc > 0) {  // self-dual
       hipLaunchKernelGGL(k_proj_soc_wave, dim3(ceil_div(n_soc, kConeThreads / 64)), dim3(kConeThreads), 0, stream, y,
-                         soc_off.p, soc_dim.p, n_soc);
+                         soc_off.p, soc_dim.p, n_soc, stall);
       if (n_soc_big > 0)
         hipLaunchKernelGGL(k_proj_soc_block, dim3(n_soc_big), dim3(kConeThreads), 0, stream, y, soc_off.p, soc_dim.p,
-                           soc_big.p, n_soc_big);
+                           soc_big.p, n_soc_big, stall);
     }
     if (n_psd > 0) launch_psd(y, psd_off.p, psd_order.p, psd_woff.p, n_psd, n_psd_big);  // self-dual
     if (n_cs > 0) {  // Hermitian PSD: self-dual
       CsBatch C{cs_off.p, cs_order.p, cs_soff.p, n_cs};
-      hipLaunchKernelGGL(k_cs_expand, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
+      hipLaunchKernelGGL(k_cs_expand, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p, stall);
       launch_psd(cs_stage.p, cs_poff.p, cs_porder.p, cs_woff.p, n_cs, n_cs_big);
-      hipLaunchKernelGGL(k_cs_extract, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p);
+      hipLaunchKernelGGL(k_cs_extract, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p, stall);
     }
     if (cone.ep > 0)  // K = K_exp: dual -> project onto K_exp^*
       hipLaunchKernelGGL(k_proj_exp, dim3(ceil_div(cone.ep, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_ep,
-                         cone.ep, dual ? 0 : 1);
+                         cone.ep, dual ? 0 : 1, stall);
     if (cone.ed > 0)  // K = K_exp^*: dual -> project onto K_exp
       hipLaunchKernelGGL(k_proj_exp, dim3(ceil_div(cone.ed, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_ed,
-                         cone.ed, dual ? 1 : 0);
+                         cone.ed, dual ? 1 : 0, stall);
     if (!cone.p.empty()) {
       const int np = (int)cone.p.size();
       if (dual)
         hipLaunchKernelGGL(k_proj_pow_dual, dim3(ceil_div(np, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_p,
-                           pow_a.p, np);
+                           pow_a.p, np, stall);
       else
         hipLaunchKernelGGL(k_proj_pow_primal, dim3(ceil_div(np, kConeThreads)), dim3(kConeThreads), 0, stream, y + cone.off_p,
-                           pow_a.p, np);
+                           pow_a.p, np, stall);
     }
   }
 
@@ -1047,12 +1110,21 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   for (auto &e : w->ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc((void **)&w->h_pin, sizeof(double) * 256));
   HIP_CHECK(hipHostMalloc((void **)&w->h_flags, sizeof(int) * F_COUNT));
-  HIP_CHECK(hipHostMalloc((void **)&w->h_params, sizeof(double) * P_COUNT, hipHostMallocMapped));
-  HIP_CHECK(hipHostGetDevicePointer((void **)&w->d_params, w->h_params, 0));
-  std::memset(w->h_params, 0, sizeof(double) * P_COUNT);
+  HIP_CHECK(hipHostMalloc((void **)&w->h_params_base, sizeof(double) * 2 * P_COUNT, hipHostMallocMapped));
+  HIP_CHECK(hipHostGetDevicePointer((void **)&w->d_params_base, w->h_params_base, 0));
+  std::memset(w->h_params_base, 0, sizeof(double) * 2 * P_COUNT);
+  w->h_params = w->h_params_base;
+  w->d_params = w->d_params_base;
+  for (int i = 0; i < 2; ++i) {
+    HIP_CHECK(hipHostMalloc((void **)&w->h_flags_slot[i], sizeof(int) * F_COUNT));
+    HIP_CHECK(hipEventCreateWithFlags(&w->ev_iter[i], hipEventDisableTiming));
+  }
   {
     const char *env = getenv("SCS_HIP_GRAPH");  // "0" keeps every launch eager (A/B measurements)
     w->graphs_enabled = !(env && env[0] == '0');
+    const char *envp = getenv("SCS_HIP_PIPELINE");  // "0": the host looks at the CG flags in every iteration
+    w->pipelined = !(envp && envp[0] == '0');
+    if (const char *envc = getenv("SCS_HIP_PIPE_CHUNK")) w->pipe_chunk_override = std::max(0, atoi(envc));
   }
   hipStream_t s = w->stream;
 
@@ -1253,9 +1325,31 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   const int max_iters = w->stgs.max_iters;
   // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
   // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
-  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= 1000000;
+  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= 1000000 && !w->pipelined;
   bool use_graphs = graphs_wanted && w->graphs_ready;
+  const bool run_ahead = w->pipelined && !w->profile && w->persist_wgs == 0;
+  // an iteration is "plain" when the host has nothing to decide in it: no convergence check / print / log row,
+  // no Anderson step, not the last one.  Plain iterations may be enqueued whole, and one ahead (run-ahead mode).
+  auto is_plain = [&](int it) {
+    if (it <= 0 || it >= max_iters - 1 || csv) return false;
+    if (it % 25 == 0 || (verbose && it % 250 == 0)) return false;
+    if (w->aa_mem > 0 && it % w->stgs.acceleration_interval == 0) return false;
+    if (w->last_cg_iters > 120) return false;  // very long linear solves: enqueue them in adaptive chunks as before
+    return true;
+  };
+  int enq_upto = -1;  // run-ahead: last iteration already in the queue
   for (i = 0; i < max_iters; ++i) {
+    if (run_ahead && (enq_upto >= i || is_plain(i))) {  // (already queued: is_plain may have changed its mind since)
+      double t = now_ms();
+      if (enq_upto < i) { w->enqueue_plain_iteration(i); enq_upto = i; }
+      if (is_plain(i + 1) && enq_upto < i + 1) { w->enqueue_plain_iteration(i + 1); enq_upto = i + 1; }
+      if (!w->finish_plain_iteration(i)) {
+        w->recover_stalled_iteration(i);
+        enq_upto = i;  // whatever was queued behind the stall did nothing
+      }
+      t_lin += now_ms() - t;
+      continue;
+    }
     if (graphs_wanted && !use_graphs && i == 64) {
       w->build_graphs();
       use_graphs = w->graphs_ready;

@@ -23,8 +23,14 @@ enum : int {
 // device flag slots (int)
 enum : int {
   F_DONE = 0, F_ITERS, F_AA_SUCCESS, F_AA_ITER, F_AA_ACCEPT, F_AA_REJ_LAPACK, F_AA_REJ_RANK0, F_AA_REJ_NONFINITE,
-  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_PERSIST_ERR, F_COUNT = 32
+  F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_PERSIST_ERR, F_STALL, F_COUNT = 32
 };
+
+// F_STALL (run-ahead mode of the ADMM loop, scs_hip.hip): the host enqueues a whole iteration — head, a chunk of
+// CG steps, tau / cones / v update — and the next one before it looks at the CG flags.  If the chunk was too short
+// (F_DONE still 0 when the first kernel after it runs) that kernel raises F_STALL and F_DONE, and every kernel
+// queued behind it returns at once (the CG-step kernels through F_DONE, the others through F_STALL), so nothing is
+// computed from an unconverged linear solve; the host then lowers both flags and resumes from the intact CG state.
 
 // per-iteration host scalars, kept in mapped pinned memory so that captured hipGraphs stay static
 enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_COUNT = 8 };
@@ -78,7 +84,9 @@ __global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict_
 __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *ws,
                                                       const double *__restrict__ u, const double *__restrict__ g,
                                                       const double *__restrict__ diag_r, int n, int m, const double *params,
-                                                      const double *vpart, int nvp, double *sc, double *part) {
+                                                      const double *vpart, int nvp, double *sc, double *part,
+                                                      const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc;
   const long l = (long)n + m + 1;
@@ -195,7 +203,9 @@ __global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n,
 // single-workgroup launch after the fused CG start (the two SpMVs of the start do not depend on the tolerance).
 //   prep_part = k_prep's [max |ws| (np_p) | max |rhs| (np_p)],  r0_part = EpiR0's [sum r0'M r0 (np_r) | max |r0| (np_r)]
 __global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_part, int np_p, const double *r0_part, int np_r,
-                                                          const double *params, double *sc, int *fl, double *ut, long nm) {
+                                                          const double *params, double *sc, int *fl, double *ut, long nm,
+                                                          const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   __shared__ int zero_rhs;
   const double ws = part_max(prep_part, np_p, sm);
@@ -304,7 +314,16 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double 
 // R-weighted dots for the tau quadratic (root_plus): [p'Rg, p'Rp, p'Rmu, mu'Rg] over the first l-1 entries
 __global__ __launch_bounds__(kVecThreads) void k_tau_dots(const double *__restrict__ p, const double *__restrict__ mu,
                                                           const double *__restrict__ g, const double *__restrict__ diag_r,
-                                                          long n, double *part) {
+                                                          long n, double *part, int *stall_fl) {
+  // first kernel behind a CG chunk: in run-ahead mode (stall_fl = the flag array) an unconverged solve stalls the queue
+  if (stall_fl) {
+    if (stall_fl[F_STALL]) return;
+    if (!stall_fl[F_DONE]) {
+      __syncthreads();  // every lane of this workgroup has read the flags before they change
+      if (threadIdx.x == 0) atomicExch(&stall_fl[F_STALL], 1);  // F_DONE is raised by k_stall_latch behind this kernel
+      return;
+    }
+  }
   __shared__ double sm[kVecThreads / 64];
   double a = 0., b = 0., c = 0., d = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
@@ -359,7 +378,11 @@ __device__ __forceinline__ double tau_root(double pg, double pp, double pmu, dou
 __global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
                                                           const double *__restrict__ g, int n, int m, int nz, int nl,
                                                           const double *params, double *sc, const double *tau_part, int np,
-                                                          const double *__restrict__ diag_r) {
+                                                          const double *__restrict__ diag_r, int *stall_fl) {
+  if (stall_fl && stall_fl[F_STALL]) {  // queue stalled by k_tau_dots: also park the CG-step kernels queued behind
+    if (blockIdx.x == 0 && threadIdx.x == 0) stall_fl[F_DONE] = 1;
+    return;
+  }
   const long l = (long)n + m + 1;
   const int first_iter = params[P_FIRST] != 0.;
   __shared__ double sm[kVecThreads / 64];
@@ -400,7 +423,8 @@ __global__ __launch_bounds__(kVecThreads) void k_rsk(double *rsk, const double *
 // v += alpha (u - u_t); vpart[block] = partial ||v_new||^2 — same partition and order as k_sumsq, so the next
 // iteration's k_prep normalises with the same bits as if k_sumsq had run
 __global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const double *__restrict__ u, const double *__restrict__ ut,
-                                                          double alpha, long l, double *vpart) {
+                                                          double alpha, long l, double *vpart, const int *stall) {
+  SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   double s = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {

@@ -431,3 +431,36 @@ def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
     assert sols["0"]["info"]["iter"] == sols["1"]["info"]["iter"]
     for key in ("x", "y", "s"):
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
+
+
+# ---- run-ahead ADMM loop (whole iterations enqueued ahead of the host) vs one host look per iteration ----
+@pytest.mark.parametrize("case", ["lp_soc", "qp_mixed", "sdp", "long_cg"])
+def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):
+    """Same kernels in the same order; a too-short CG chunk stalls the queue and is finished synchronously.
+    Iterates, iteration counts and CG step counts must not depend on the mode."""
+    proj = lambda z, K: oracle.proj_cone(z, K, dual=True)
+    stg = dict(STG)
+    stg.update(eps_abs=1e-7, eps_rel=1e-7, max_iters=600)
+    if case == "lp_soc":
+        K, n, k, seed = pg.workload("small_lp_soc")
+        data, _, _ = pg.gen_feasible(K, n, k, seed, proj)
+    elif case == "qp_mixed":
+        K = {"z": 10, "l": 600, "q": [30, 12, 5], "s": [6, 3], "ep": 4, "ed": 3, "p": [0.4, -0.7], "bu": [1.0] * 5, "bl": [-1.0] * 5}
+        data, _, _ = pg.gen_feasible_qp(K, 420, 7, 5, proj)
+    elif case == "sdp":
+        K = {"l": 30, "s": [40, 12], "cs": [5]}
+        data, _, _ = pg.gen_feasible_qp(K, pg.cone_dims(K) + 2, 6, 21, proj)
+    else:  # a badly scaled problem: CG step counts jump around, chunks are often too short (stall + recovery path)
+        K = {"z": 150, "l": 300}
+        data, _, _ = pg.gen_feasible(K, 200, 12, 9, proj)
+        stg.update(scale=25.0, adaptive_scale=False, acceleration_lookback=0)
+    args = helpers.raw_args(data, K)
+    sols = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_PIPELINE", mode)
+        sols[mode] = hip.SCS(*args, **stg).solve(False, None, None, None)
+    a, b = sols["0"]["info"], sols["1"]["info"]
+    assert (a["iter"], a["cg_iters"], a["status"]) == (b["iter"], b["cg_iters"], b["status"])
+    assert a["accepted_accel_steps"] == b["accepted_accel_steps"] and a["rejected_accel_steps"] == b["rejected_accel_steps"]
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)

@@ -26,6 +26,7 @@
 #include "normalize_dev.hpp"
 #include "psd.hpp"
 #include "cg_persist.hpp"
+#include "setup_dev.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
 
@@ -53,31 +54,112 @@ struct DeviceCsr {
   DevBuf<unsigned short> s_roff;
   DevBuf<double> s_val;
   int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
+  static bool host_setup() {  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
+    const char *e = getenv("SCS_HIP_SETUP");
+    return e && e[0] == 'h';
+  }
+  void set_rowblocks(const int *rp_host, hipStream_t s) {
+    std::vector<int4> rb = build_rowblocks(rp_host, rows);
+    nblk = (int)rb.size();
+    rowblk.upload(rb.data(), rb.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));  // rb is a local
+  }
   void upload(int rows_, int cols_, const int *rp, const int *ci, const double *v, hipStream_t s, bool allow_slab = true) {
     rows = rows_; cols = cols_; nnz = rp[rows_];
-    std::vector<int4> rb = build_rowblocks(rp, rows);
-    nblk = (int)rb.size();
     rowptr.upload(rp, rows + 1, s);
     col.upload(ci, nnz, s);
     val.upload(v, nnz, s);
-    rowblk.upload(rb.data(), rb.size(), s);
+    set_rowblocks(rp, s);
     has_slab = false;
     const char *env = getenv("SCS_HIP_SLAB");  // "0" forces the plain CSR-stream kernel (A/B measurements)
     if (allow_slab && slab_wanted(rows, cols) && !(env && env[0] == '0')) {
-      HostSlab hs;
-      std::vector<int> src;
-      if (build_slab(rp, ci, v, rows, cols, hs, &src)) {
-        s_perm.upload(src.data(), src.size(), s);
-        s_segptr.upload(hs.segptr.data(), hs.segptr.size(), s);
-        s_roff.upload(hs.roff.data(), hs.roff.size(), s);
-        s_col.upload(hs.col.data(), hs.col.size(), s);
-        s_val.upload(hs.val.data(), hs.val.size(), s);
-        s_nchunks = hs.nchunks; s_S = hs.S; s_R = hs.R; s_max_seg = hs.max_seg;
-        has_slab = true;
-        HIP_CHECK(hipStreamSynchronize(s));  // hs is a local
+      if (!host_setup()) {
+        build_slab_dev(s);
+      } else {
+        HostSlab hs;
+        std::vector<int> src;
+        if (build_slab(rp, ci, v, rows, cols, hs, &src)) {
+          s_perm.upload(src.data(), src.size(), s);
+          s_segptr.upload(hs.segptr.data(), hs.segptr.size(), s);
+          s_roff.upload(hs.roff.data(), hs.roff.size(), s);
+          s_col.upload(hs.col.data(), hs.col.size(), s);
+          s_val.upload(hs.val.data(), hs.val.size(), s);
+          s_nchunks = hs.nchunks; s_S = hs.S; s_R = hs.R; s_max_seg = hs.max_seg;
+          has_slab = true;
+          HIP_CHECK(hipStreamSynchronize(s));  // hs is a local
+        }
       }
     }
-    HIP_CHECK(hipStreamSynchronize(s));  // rb is a local
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  // this = src' on the device (setup_dev.hpp).  false: a row is too long for the one-lane sort (caller falls back).
+  bool transpose_from(const DeviceCsr &src, hipStream_t s) {
+    rows = src.cols; cols = src.rows; nnz = src.nnz;
+    rowptr.alloc_zero((size_t)rows + 1, s);
+    col.alloc_zero((size_t)std::max(nnz, 1L), s);
+    val.alloc_zero((size_t)std::max(nnz, 1L), s);
+    DevBuf<int> cursor, perm, tmp, flag;
+    cursor.alloc_zero((size_t)rows + 1, s);
+    perm.alloc_zero((size_t)std::max(nnz, 1L), s);
+    tmp.alloc_zero((size_t)(rows / kScanTile + 4), s);
+    flag.alloc_zero(1, s);
+    if (nnz > 0) hipLaunchKernelGGL(k_count_index, dim3(vec_blocks(nnz)), dim3(kVecThreads), 0, s, src.col.p, nnz, cursor.p);
+    device_exclusive_scan(cursor.p, rowptr.p, rows, tmp.p, s);
+    HIP_CHECK(hipMemcpyAsync(cursor.p, rowptr.p, sizeof(int) * rows, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_transpose_scatter, dim3(vec_blocks(src.rows)), dim3(kVecThreads), 0, s, src.rowptr.p, src.col.p, src.rows,
+                       cursor.p, col.p, perm.p);
+    hipLaunchKernelGGL(k_sort_rows, dim3(vec_blocks(rows)), dim3(kVecThreads), 0, s, rowptr.p, col.p, perm.p, rows, flag.p);
+    if (nnz > 0) hipLaunchKernelGGL(k_gather_f64, dim3(vec_blocks(nnz)), dim3(kVecThreads), 0, s, val.p, src.val.p, perm.p, nnz);
+    int too_long = 0;
+    std::vector<int> rp((size_t)rows + 1);
+    HIP_CHECK(hipMemcpyAsync(&too_long, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    rowptr.download(rp.data(), rp.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (too_long) return false;
+    set_rowblocks(rp.data(), s);
+    has_slab = false;
+    return true;
+  }
+  // L2-blocked copy of the CURRENT csr arrays, built on the device (same layout as spmv.hpp build_slab)
+  void build_slab_dev(hipStream_t s) {
+    has_slab = false;
+    const char *env = getenv("SCS_HIP_SLAB");
+    if (!slab_wanted(rows, cols) || (env && env[0] == '0')) return;
+    SlabGeom g;
+    g.rows = rows; g.cols = cols; g.R = slab_pick_rows(rows); g.shift = slab_shift();
+    g.S = (int)(((long)cols + (1L << g.shift) - 1) >> g.shift);
+    g.nchunks = (rows + g.R - 1) / g.R;
+    const long nseg = (long)g.nchunks * g.S;
+    DevBuf<int> seg_size, tmp, flag;
+    seg_size.alloc_zero((size_t)nseg + 1, s);
+    tmp.alloc_zero((size_t)(nseg / kScanTile + 4), s);
+    flag.alloc_zero(1, s);
+    s_roff.alloc_zero((size_t)nseg * (g.R + kSlabRoffPad), s);
+    s_segptr.alloc_zero((size_t)nseg + 1, s);
+    hipLaunchKernelGGL(k_slab_count, dim3(vec_blocks(rows)), dim3(kVecThreads), 0, s, rowptr.p, col.p, g, s_roff.p, flag.p);
+    hipLaunchKernelGGL(k_slab_scan, dim3((unsigned)nseg), dim3(kScanThreads), 0, s, g, s_roff.p, seg_size.p, flag.p);
+    device_exclusive_scan(seg_size.p, s_segptr.p, nseg, tmp.p, s);
+    std::vector<int> sizes((size_t)nseg);
+    int total = 0, overflow = 0;
+    HIP_CHECK(hipMemcpyAsync(sizes.data(), seg_size.p, sizeof(int) * nseg, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&total, s_segptr.p + nseg, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&overflow, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    long check = 0;
+    int max_seg = 0;
+    for (int v : sizes) { check += v; max_seg = std::max(max_seg, v); }
+    if (overflow || check != (long)total || check > 2000000000L) {  // uint16 offsets or int32 positions do not fit: no slab copy
+      s_roff.release(); s_segptr.release();
+      return;
+    }
+    s_col.alloc_zero((size_t)std::max(total, 1), s);
+    s_val.alloc_zero((size_t)std::max(total, 1), s);
+    hipLaunchKernelGGL(k_slab_fill, dim3(vec_blocks(rows)), dim3(kVecThreads), 0, s, rowptr.p, col.p, val.p, g, s_roff.p, s_segptr.p,
+                       s_col.p, s_val.p);
+    hipLaunchKernelGGL(k_slab_pad, dim3(vec_blocks(nseg)), dim3(kVecThreads), 0, s, g, s_roff.p, s_segptr.p, s_col.p, s_val.p);
+    HIP_CHECK(hipStreamSynchronize(s));
+    s_nchunks = g.nchunks; s_S = g.S; s_R = g.R; s_max_seg = max_seg;
+    has_slab = true;
   }
   SpmvMat view() const {
     SpmvMat M;
@@ -89,7 +171,7 @@ struct DeviceCsr {
   int nwg() const { return has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
-    if (!has_slab) return;
+    if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)
     const long cnt = (long)s_val.n;
     hipLaunchKernelGGL(k_gather_vals, dim3(vec_blocks(cnt)), dim3(kVecThreads), 0, s, s_val.p, val.p, s_perm.p, cnt);
     if (drop_perm) {
@@ -1127,20 +1209,41 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     if (const char *envc = getenv("SCS_HIP_PIPE_CHUNK")) w->pipe_chunk_override = std::max(0, atoi(envc));
   }
   hipStream_t s = w->stream;
+  const bool setup_timing = getenv("SCS_HIP_SETUP_TIMING") != nullptr;  // diagnostics: where does scs_init spend its time
+  double t_mark = now_ms();
+  auto mark = [&](const char *what) {
+    if (!setup_timing) return;
+    HIP_CHECK(hipStreamSynchronize(s));
+    const double t = now_ms();
+    std::fprintf(stderr, "[scs-hip setup] %-34s %8.1f ms\n", what, t - t_mark);
+    t_mark = t;
+  };
+  mark("validation, cone, host copies");
 
   // ---- matrices to HBM (raw): CSC(A) as CSR(A'), explicit CSR(A), full CSR(P) ----
   w->normalized = stgs->normalize != 0;
-  w->At.upload(n, m, d->A->p, d->A->i, d->A->x, s);
-  {
+  // Device path (default): upload the caller's CSC once, transpose and (after the equilibration) build the
+  // L2-blocked copies on the device; the host builders remain for SCS_HIP_SETUP=host and for rows too long to sort.
+  const bool host_build = DeviceCsr::host_setup();
+  bool slabs_pending = false;
+  w->At.upload(n, m, d->A->p, d->A->i, d->A->x, s, /*allow_slab=*/host_build);
+  mark("A' upload (+ slab build on the host)");
+  if (host_build || !w->Ar.transpose_from(w->At, s)) {
     HostCsr ar;
     csc_to_csr(m, n, d->A->p, d->A->i, d->A->x, ar);
-    w->Ar.upload(m, n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s);
+    mark("CSC -> CSR on the host");
+    w->Ar.upload(m, n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/host_build);
+    mark("A upload (+ slab build on the host)");
+    slabs_pending = !host_build;
+  } else {
+    mark("CSC -> CSR on the device");
+    slabs_pending = true;
   }
   if (w->has_P) {
     HostCsr pf;
     std::vector<double> pdiag;
     sym_expand(n, d->P->p, d->P->i, d->P->x, pf, pdiag);
-    w->Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s);
+    w->Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s, /*allow_slab=*/host_build);
     w->px.alloc_zero(n, s);
   }
   // ---- K12: equilibrate on the device, in place in all resident layouts ----
@@ -1159,7 +1262,14 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
       }
     }
   }
+  mark("equilibration (device)");
   for (DeviceCsr *M : {&w->At, &w->Ar, &w->Pf}) M->refresh_slab(s, true);
+  if (slabs_pending) {
+    w->At.build_slab_dev(s);
+    w->Ar.build_slab_dev(s);
+    if (w->has_P) w->Pf.build_slab_dev(s);
+  }
+  mark("L2-blocked copies (device) / value refresh");
   if (w->has_P) {  // diagonal of the (scaled) P for the Jacobi preconditioner
     w->Pdiag.alloc_zero(n, s);
     hipLaunchKernelGGL(k_csr_diag, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w->Pf.rowptr.p, w->Pf.col.p, w->Pf.val.p, n,
@@ -1232,10 +1342,12 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     w->aa_npart.alloc_zero(kMaxVecBlocks, s);
     w->aa_M.assign((size_t)w->aa_mem * w->aa_mem, 0.0);
   }
+  mark("vectors, b/c scaling, cones, AA workspace");
   // ---- R, preconditioner, pre-solved g ----
   w->set_diag_r();
   w->update_work_cache();
   HIP_CHECK(hipStreamSynchronize(s));
+  mark("R, preconditioner, g = KKT^-1 h");
   w->setup_time = now_ms() - t0;
   return w.release();
 }

@@ -464,3 +464,45 @@ def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):
     assert a["accepted_accel_steps"] == b["accepted_accel_steps"] and a["rejected_accel_steps"] == b["rejected_accel_steps"]
     for key in ("x", "y", "s"):
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
+
+
+# ---- scs_init's matrix work on the device (setup_dev.hpp) vs the host builders ----
+def test_device_setup_matches_host_setup(hip, oracle, monkeypatch):
+    """CSC -> CSR transposition and the L2-blocked slab layout built on the device must give the same matrices,
+    entry for entry, as the host builders: identical SpMV bits and identical solves."""
+    rng = np.random.default_rng(5)
+    A = pg.random_sparse(300000, 270000, 7, rng)  # wide enough for the slab layout in both orientations
+    x = rng.standard_normal(A.shape[1])
+    y = rng.standard_normal(A.shape[0])
+    res = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("SCS_HIP_SETUP", mode)
+        res[mode] = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
+    np.testing.assert_array_equal(res["host"][0], res["device"][0])
+    np.testing.assert_array_equal(res["host"][1], res["device"][1])
+    np.testing.assert_array_equal(res["device"][0], oracle.spmv(A, x))
+    # full solves: small (CSR-stream layouts) with P, and one large enough for slabs
+    K = {"z": 10, "l": 600, "q": [30, 12, 5], "s": [6, 3]}
+    data, _, _ = pg.gen_feasible_qp(K, 400, 7, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    K2 = {"l": 400000}
+    data2, _, _ = pg.gen_feasible(K2, 300000, 6, 8, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    for dat, cone, iters in ((data, K, 200), (data2, K2, 40)):
+        sols = {}
+        for mode in ("host", "device"):
+            monkeypatch.setenv("SCS_HIP_SETUP", mode)
+            sols[mode] = hip.SCS(*helpers.raw_args(dat, cone), eps_abs=1e-9, eps_rel=1e-9, verbose=False,
+                                 max_iters=iters).solve(False, None, None, None)
+        for key in ("x", "y", "s"):
+            np.testing.assert_array_equal(sols["host"][key], sols["device"][key], err_msg=key)
+
+
+def test_device_setup_long_rows_fall_back(hip, oracle):
+    A = _rand_csc(3000, 2500, 0.002, 3, long_rows=True).tolil()  # a dense row: longer than the one-lane sort takes
+    A = sparse.csc_matrix(A)
+    A.sort_indices()
+    x = np.random.RandomState(1).randn(A.shape[1])
+    np.testing.assert_allclose(hip.spmv(A, x), oracle.spmv(A, x), rtol=1e-12, atol=1e-12)
+    rng = np.random.RandomState(2)
+    data = {"A": A, "b": np.abs(rng.randn(A.shape[0])) + 1.0, "c": rng.randn(A.shape[1])}
+    sol = hip.SCS(*helpers.raw_args(data, {"l": A.shape[0]}), verbose=False, max_iters=50).solve(False, None, None, None)
+    assert sol["info"]["iter"] == 50 and np.isfinite(sol["x"]).all()

@@ -46,14 +46,14 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < x.size(); ++i) x[i] = x0[i] * (1.0 + pert * call) + pert * call * nd(g);
     HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipEventRecord(e0));
-    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1);
+    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, nullptr);
     else if (split) {
       for (int round = 0; round < 3; ++round) {
-        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round);
-        hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr);
+        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
+        hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
-      hipLaunchKernelGGL(k_psd_recon, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1);
-    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0);
+      hipLaunchKernelGGL(k_psd_recon, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, nullptr);
+    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
     HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     double st[8];

@@ -382,6 +382,9 @@ struct ScsHipWork {
   int n_log_scale_factor = 0, last_scale_update_iter = 0, scale_updates = 0;
   long tot_cg_iters = 0;
   int last_cg_iters = 8;
+  int cg_hist[8] = {8, 8, 8, 8, 8, 8, 8, 8}, cg_hist_pos = 0;  // CG steps of the last 8 linear solves (chunk sizing)
+  void note_cg_iters(int it) { cg_hist[cg_hist_pos++ & 7] = it; }
+  int recent_cg_max() const { int mx = 1; for (int v : cg_hist) mx = std::max(mx, v); return mx; }
   double cg_res_min = 0;
   // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
   bool profile = false;
@@ -477,6 +480,7 @@ struct ScsHipWork {
       done_iters = h_flags[F_ITERS];
       if (h_flags[F_DONE] || done_iters >= max_its) {
         last_cg_iters = done_iters;
+        if (xout == ut.p) note_cg_iters(done_iters);
         tot_cg_iters += done_iters;
         return done_iters;
       }
@@ -524,6 +528,7 @@ struct ScsHipWork {
       chunk = std::max(2, std::min(std::max(done_iters / 2, 4), 64));
     }
     last_cg_iters = done_iters;
+    if (xout == ut.p) note_cg_iters(done_iters);  // (not the cold KKT solves of init / scale updates)
     tot_cg_iters += done_iters;
     return done_iters;
   }
@@ -607,6 +612,7 @@ struct ScsHipWork {
     sync_flags();
     if (h_flags[F_PERSIST_ERR]) throw std::runtime_error("persistent CG kernel: grid barrier timed out");
     last_cg_iters = h_flags[F_ITERS];
+    note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
   }
   // tau (the y block is already in ut_y: it was carried along the CG recurrence)
@@ -633,7 +639,9 @@ struct ScsHipWork {
     stall = fl.p + F_STALL;
     stall_fl = fl.p;
     enqueue_lin_sys_head();
-    int chunk = std::max(2, last_cg_iters + 3);  // the count is one iteration stale here (is_plain caps it)
+    // the largest step count of the last 8 solves + 1 (the newest count is one iteration stale here; is_plain caps it):
+    // an unused step costs four ~1-2 us launches, a stall a drained queue and a host round trip (~100 us)
+    int chunk = std::max(2, recent_cg_max() + 1);
     if (pipe_chunk_override > 0) chunk = pipe_chunk_override;
     for (int k = 0; k < chunk; ++k) enqueue_cg_step(ut.p, ut.p + n);
     enqueue_lin_sys_tail();
@@ -654,6 +662,7 @@ struct ScsHipWork {
     std::memcpy(h_flags, hf, sizeof(int) * F_COUNT);
     process_pending_flags();  // e.g. the verdict of the Anderson safeguard enqueued in the iteration before
     last_cg_iters = hf[F_ITERS];
+    note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
     return true;
   }

@@ -199,14 +199,26 @@ __device__ __forceinline__ int pq_index(int i, int p, int q) { return (i < 8 ? p
 // 128-byte lines).  The a-operand is shared by the kPsdNJ output tiles (1.25 loads per MFMA instead of 2).
 // Tiles beyond `tjmax` are computed on a clamped tile and must be ignored by the caller.
 constexpr int kPsdNJ = 4;
+// FMAP: the B operand is F = Pi_+(D + E) formed on the fly from the nearly diagonal A (see the reconstruction):
+// F_jk = max(d_k, 0) on the diagonal, A_jk * (f(d_j) - f(d_k)) / (d_j - d_k) elsewhere; d = lam[] (eigenvalue estimates).
+__device__ __forceinline__ double psd_fmap(double a, double dj, double dk, bool diag) {
+  const double hi = fmax(dj, dk), lo = fmin(dj, dk);
+  const double gdd = lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo));
+  return diag ? fmax(dk, 0.) : a * gdd;
+}
+template <bool FMAP = false>
 __device__ __forceinline__ void mma_row(const double *__restrict__ Aop, const double *__restrict__ Bop, int ld, int NP, int ti,
-                                        int tj0, int tjmax, int li, int lk, f64x4 (&acc)[kPsdNJ]) {
+                                        int tj0, int tjmax, int li, int lk, f64x4 (&acc)[kPsdNJ], const double *lam = nullptr) {
   const double *pa = Aop + (ti * 16 + li) + (size_t)ld * lk;
   const double *pb[kPsdNJ];
+  int rowj[kPsdNJ];
+  double dj[kPsdNJ];
 #pragma unroll
   for (int j = 0; j < kPsdNJ; ++j) {
     acc[j] = f64x4{0., 0., 0., 0.};
-    pb[j] = Bop + (min(tj0 + j, tjmax) * 16 + li) + (size_t)ld * lk;
+    rowj[j] = min(tj0 + j, tjmax) * 16 + li;
+    pb[j] = Bop + rowj[j] + (size_t)ld * lk;
+    dj[j] = FMAP ? lam[rowj[j]] : 0.;
   }
 
   for (int k0 = 0; k0 < NP; k0 += 4) {
@@ -214,18 +226,115 @@ __device__ __forceinline__ void mma_row(const double *__restrict__ Aop, const do
     double b[kPsdNJ];
 #pragma unroll
     for (int j = 0; j < kPsdNJ; ++j) b[j] = pb[j][(size_t)ld * k0];
+    if (FMAP) {
+      const double dk = lam[k0 + lk];
+#pragma unroll
+      for (int j = 0; j < kPsdNJ; ++j) b[j] = psd_fmap(b[j], dj[j], dk, rowj[j] == k0 + lk);
+    }
 #pragma unroll
     for (int j = 0; j < kPsdNJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[j], 0, 0, 0);
   }
 }
 
+// ---- wave-level GEMM tasks shared by the one-workgroup kernels (task = wave, wave + 16, ...) and the multi-workgroup
+// ---- k_psd_gemm (task = global wave index): `Sw` is the calling wave's private 16x17 LDS scratch ----
+// G1: Tt = Vt A  (A exactly symmetric: A[k][i] is read as A[i][k]); output tiles (tj, ti0 .. ti0+3) of Tt = (A V)'
+__device__ __forceinline__ void psd_task_g1(int task, int NP, const double *A, const double *Vt, double *Tm, double *Sw, int li, int lk) {
+  const int ld = NP, ntile = NP / 16;
+  const int tj = task % ntile, ti0 = (task / ntile) * kPsdNJ;
+  f64x4 acc[kPsdNJ];
+  mma_row(Vt, A, ld, NP, tj, ti0, ntile - 1, li, lk, acc);
+#pragma unroll
+  for (int j = 0; j < kPsdNJ; ++j) {
+    const int ti = ti0 + j;
+    if (ti >= ntile) break;
+    // lane holds Tt[row = tj*16 + lk + 4t][col = ti*16 + li]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Tm[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+    wave_sync();
+  }
+}
+// G2: A0[i][j] = sum_k Vt[i][k] Tt[j][k], lower-triangular tiles, mirrored; diagonal tiles symmetrised (average of
+// the two triangles) so that A0 is exactly symmetric
+__device__ __forceinline__ void psd_task_g2(int task, int NP, double *A, const double *Vt, const double *Tm, double *Sw, int li, int lk) {
+  const int ld = NP, ntile = NP / 16;
+  const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+  if (tj0 > ti) return;
+  f64x4 acc[kPsdNJ];
+  mma_row(Vt, Tm, ld, NP, ti, tj0, ti, li, lk, acc);
+#pragma unroll
+  for (int j = 0; j < kPsdNJ; ++j) {
+    const int tj = tj0 + j;
+    if (tj > ti) break;
+    // lane holds R[row = lk + 4t][col = li] of tile (ti, tj)
+    if (ti != tj) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = acc[j][t];  // mirror
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = li, c = lk + 4 * t;  // element (r, c) of the tile = Sw[r + 17 c]
+      double v = Sw[r + 17 * c];
+      if (ti == tj && r != c) v = 0.5 * ((r > c ? v : Sw[c + 17 * r]) + (r > c ? Sw[c + 17 * r] : v));
+      A[(ti * 16 + r) + (size_t)ld * (tj * 16 + c)] = v;
+    }
+    wave_sync();
+  }
+}
+// R1: T = V F  (F symmetric, formed on the fly from the diagonalised A and lam = its diagonal)
+__device__ __forceinline__ void psd_task_r1(int task, int NP, const double *A, const double *V, double *Tm, const double *lam,
+                                            double *Sw, int li, int lk) {
+  const int ld = NP, ntile = NP / 16;
+  const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+  f64x4 acc[kPsdNJ];
+  mma_row<true>(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc, lam);
+#pragma unroll
+  for (int j = 0; j < kPsdNJ; ++j) {
+    const int tj = tj0 + j;
+    if (tj >= ntile) break;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+    wave_sync();
+  }
+}
+// R2: X+ = T V', lower-triangular output tiles straight into the packed vector
+__device__ __forceinline__ void psd_task_r2(int task, int n, int NP, const double *Tm, const double *V, double *X, int li, int lk) {
+  const int ld = NP, ntile = NP / 16;
+  const double sq2 = 1.41421356237309504880;
+  const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
+  if (tj0 > ti) return;
+  f64x4 acc[kPsdNJ];
+  mma_row(Tm, V, ld, NP, ti, tj0, ti, li, lk, acc);
+#pragma unroll
+  for (int jj = 0; jj < kPsdNJ; ++jj) {
+    const int tj = tj0 + jj;
+    if (tj > ti) break;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
+      if (i < n && j <= i) {
+        const long base = (long)j * n - (long)j * (j - 1) / 2;
+        X[base + (i - j)] = (i == j) ? acc[jj][t] : acc[jj][t] * sq2;
+      }
+    }
+  }
+}
+
 // ---- X+ = V F V' with F = Pi_+(D + E) to second order in the remaining off-diagonal part E of A = D + E ----
-// (one 1024-lane workgroup; A is overwritten by F, Tm by V F; Sw = this wave's 16x17 LDS scratch)
+// (one 1024-lane workgroup; Tm is overwritten by V F; Sw = this wave's 16x17 LDS scratch)
 __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double *A, const double *V, double *Tm, double *lam,
                                                 double *Sw) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int ld = NP, ntile = NP / 16;
-  const double sq2 = 1.41421356237309504880;
   // The sweeps stop at ||E||_F <= 1e-8 ||A||_F, one sweep earlier than a plain V max(D,0) V' would allow
   // (its error is first order in E).  For a matrix function f applied to a nearly diagonal matrix,
   //   f(D + E)_ij = f(d_i) delta_ij + E_ij (f(d_i) - f(d_j)) / (d_i - d_j) + O(|E|^2 / gap)      (Daleckii-Krein),
@@ -234,67 +343,23 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
   // themselves second-order accurate, so the result is good to ~|E|^2 = 1e-16 relative.
   for (int j = tid; j < NP; j += kPsdThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
   __syncthreads();
-  for (int e = tid; e < NP * NP; e += kPsdThreads) {
-    const int i = e % NP, j = e / NP;
-    const double di = lam[i], dj = lam[j];
-    if (i == j) {
-      A[e] = fmax(di, 0.);
-    } else {
-      const double hi = fmax(di, dj), lo = fmin(di, dj);
-      const double gdd = lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo));
-      A[e] *= gdd;
-    }
-  }
+  const int ntask = ntile * ((ntile + kPsdNJ - 1) / kPsdNJ);
+  for (int task = wave; task < ntask; task += kPsdWaves) psd_task_r1(task, NP, A, V, Tm, lam, Sw, li, lk);
   __syncthreads();
-  // T = V F  (F symmetric: read by rows; stored through the 16x17 LDS transpose so that li runs down the columns of Tm)
-  const int ngrp_r = (ntile + kPsdNJ - 1) / kPsdNJ;
-  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
-    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
-    f64x4 acc[kPsdNJ];
-    mma_row(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc);
-#pragma unroll
-    for (int j = 0; j < kPsdNJ; ++j) {
-      const int tj = tj0 + j;
-      if (tj >= ntile) break;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
-      wave_sync();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-      wave_sync();
-    }
-  }
-  __syncthreads();
-
-  // ---- X+ = T V' : lower-triangular 16x16 output tiles ----
-  for (int task = wave; task < ntile * ngrp_r; task += kPsdWaves) {
-    const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
-    if (tj0 > ti) continue;
-    f64x4 acc[kPsdNJ];
-    mma_row(Tm, V, ld, NP, ti, tj0, ti, li, lk, acc);
-#pragma unroll
-    for (int jj = 0; jj < kPsdNJ; ++jj) {
-      const int tj = tj0 + jj;
-      if (tj > ti) break;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = ti * 16 + lk + 4 * t, j = tj * 16 + li;
-        if (i < n && j <= i) {
-          const long base = (long)j * n - (long)j * (j - 1) / 2;
-          X[base + (i - j)] = (i == j) ? acc[jj][t] : acc[jj][t] * sq2;
-        }
-      }
-    }
-  }
+  for (int task = wave; task < ntask; task += kPsdWaves) psd_task_r2(task, n, NP, Tm, V, X, li, lk);
 }
 
 // MODE 0: the whole projection in one launch (one workgroup = one CU per matrix; right when the batch fills the GPU).
-// MODE 1: split mode for small batches of large matrices (config 4: 50 matrices on 256 CUs).  This kernel then only
-//   diagonalises A (pivots + A updates) and LOGS every pivot's 16x16 rotation; k_psd_apply_v applies the logged
-//   rotations to V with one workgroup per 16-row strip of V (13 x 50 workgroups instead of 50: the V update is 2/3
-//   of the update work) and k_psd_recon forms X+.  A round logs at most kPsdLogSweeps sweeps; the host enqueues
-//   [sweep, apply] rounds back to back, later rounds return at once when the matrix has already converged
-//   (state[1]).  Same rotations, same MFMA sequences on V: bit-identical to MODE 0.
+// Split mode for small batches of large matrices (config 4: 50 matrices on 256 CUs), everything that parallelises
+// beyond one CU per matrix in its own multi-workgroup launch:
+//   MODE 2  front: unpack, V' (and the periodic re-orthogonalisation of V)           1 workgroup / matrix
+//   k_psd_gemm<G1>, <G2>: warm start A0 = V'AV                                        13 workgroups / matrix at order 200
+//   MODE 1  sweeps: diagonalise A (pivots + A updates), LOG every pivot's 16x16 rotation; a round logs at most
+//           kPsdLogSweeps sweeps, the host enqueues [sweep, apply] rounds back to back and later rounds return at
+//           once when the matrix has already converged (state[1])                     1 workgroup / matrix
+//   k_psd_apply_v: V <- V W_1 W_2 ... per 16-row strip (the V update is 2/3 of the update work)   13 / matrix
+//   k_psd_gemm<R1>, <R2>: X+ = V F V'                                                 13 / matrix
+// Same rotations, same MFMA sequences: bit-identical to MODE 0.
 template <int MODE>
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall) {
   SCS_STALL_GUARD(stall);
@@ -339,8 +404,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   // them in) stays at machine precision for arbitrarily long solves.
   const bool warm = allow_warm && state[0] >= 1.;
   const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
-  const bool resumed = MODE == 1 && round > 0;  // a later round of the split mode: A is already being diagonalised
-  const bool finished = resumed && state[1] != 0.;
+  const bool resumed = MODE == 1;  // split mode: the front and the warm-start GEMMs ran in their own launches
+  const bool finished = MODE == 1 && round > 0 && state[1] != 0.;
   __syncthreads();  // everyone has read state[]
   if (MODE == 1) {
     if (tid == 0) {
@@ -348,6 +413,9 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       if (round == 0) state[1] = 0.;
     }
     if (finished) return;  // converged in an earlier round: nothing to log, k_psd_apply_v has nothing to do
+  }
+  if (MODE == 2 && n >= 2) {
+    // (orders 0 and 1 were finished above; nothing else to prepare)
   }
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int li = lane & 15, lk = lane >> 4;
@@ -448,64 +516,18 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       for (int e = tid; e < NP * NP; e += kPsdThreads) Vt[e] = Tm[e];
       __syncthreads();
     }
-    for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
-      const int tj = task % ntile, ti0 = (task / ntile) * kPsdNJ;  // output tiles (tj, ti0 .. ti0+3) of Tt
-      f64x4 acc[kPsdNJ];
-      mma_row(Vt, A, ld, NP, tj, ti0, ntile - 1, li, lk, acc);
-#pragma unroll
-      for (int j = 0; j < kPsdNJ; ++j) {
-        const int ti = ti0 + j;
-        if (ti >= ntile) break;
-        // lane holds Tt[row = tj*16 + lk + 4t][col = ti*16 + li]
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
-        wave_sync();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Tm[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-        wave_sync();
-      }
+    if (MODE != 2) {
+      for (int task = wave; task < ntile * ngrp; task += kPsdWaves) psd_task_g1(task, NP, A, Vt, Tm, Sw, li, lk);
+      __syncthreads();
+      for (int task = wave; task < ntile * ngrp; task += kPsdWaves) psd_task_g2(task, NP, A, Vt, Tm, Sw, li, lk);
+      __syncthreads();
     }
-    __syncthreads();
-    // lower-triangular tiles of A0, mirrored: A stays exactly symmetric
-    for (int task = wave; task < ntile * ngrp; task += kPsdWaves) {
-      const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
-      if (tj0 > ti) continue;
-      f64x4 acc[kPsdNJ];
-      mma_row(Vt, Tm, ld, NP, ti, tj0, ti, li, lk, acc);
-#pragma unroll
-      for (int j = 0; j < kPsdNJ; ++j) {
-        const int tj = tj0 + j;
-        if (tj > ti) break;
-        // lane holds R[row = lk + 4t][col = li] of tile (ti, tj)
-        if (ti != tj) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = acc[j][t];  // mirror
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = acc[j][t];
-        wave_sync();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) A[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-        wave_sync();
-      }
-    }
-    __syncthreads();
-    // diagonal tiles were written un-symmetrised: average the two triangles inside them
-    for (int e = tid; e < ntile * 256; e += kPsdThreads) {
-      const int t = e >> 8, i = e & 15, j = (e >> 4) & 15;
-      if (i > j) {
-        const size_t a = (size_t)(t * 16 + i) + (size_t)ld * (t * 16 + j), b = (size_t)(t * 16 + j) + (size_t)ld * (t * 16 + i);
-        const double m = 0.5 * (A[a] + A[b]);
-        A[a] = m;
-        A[b] = m;
-      }
-    }
-    __syncthreads();
   }
 
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
   }  // !resumed
+  if (MODE == 2) return;
   int nlog = 0;  // split mode: steps logged in this round
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_sw0);
@@ -729,23 +751,39 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, do
   for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)] = strip[e];
 }
 
-// Split mode, last kernel: X+ from the diagonalised A and the updated V (one workgroup per matrix).
-__global__ __launch_bounds__(kPsdThreads) void k_psd_recon(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+// Split mode: the four GEMM phases as multi-workgroup launches — grid (workgroups per matrix, matrices), 4 wavefronts per
+// workgroup, wave-level tasks of psd_task_* (one row tile x up to 4 column tiles each).
+enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2 };
+constexpr int kPsdGemmThreads = 256;
+template <int KIND>
+__global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
   SCS_STALL_GUARD(stall);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *lds = reinterpret_cast<double *>(smem_raw);
-  const int n = B.order[blockIdx.x];
-  if (n < 2) return;  // orders 0 and 1 were finished by the sweep kernel
-  const int NP = (int)psd_np(n), H = NP / kPsdB / 2;
-  double *A = scratch + B.woff[blockIdx.x];
+  __shared__ double Sws[kPsdGemmThreads / 64][16 * 17];
+  const int n = B.order[blockIdx.y];
+  if (n < 2) return;  // orders 0 and 1 were finished by the front kernel
+  const int NP = (int)psd_np(n), ntile = NP / 16, H = NP / kPsdB / 2, ld = NP;
+  double *A = scratch + B.woff[blockIdx.y];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;
-  double *lam = Tm + 2 * (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n);
+  double *Vt = Tm + (size_t)NP * NP;
+  double *lam = Vt + (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n);
   double *state = lam + NP;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const bool warm = allow_warm && state[0] >= 1.;
-  __syncthreads();
-  if (threadIdx.x == 0) state[0] = warm ? state[0] + 1. : 1.;
-  psd_reconstruct(x + B.off[blockIdx.x], n, NP, A, V, Tm, lam, lds + (threadIdx.x >> 6) * kPsdWaveLds);
+  if ((KIND == PSD_G1 || KIND == PSD_G2) && !warm) return;  // cold start: A0 = A
+  const int ntask = ntile * ((ntile + kPsdNJ - 1) / kPsdNJ);
+  double *Sw = Sws[wave];
+  if (KIND == PSD_R1) {  // eigenvalue estimates: every workgroup of the matrix writes the same values
+    for (int j = tid; j < NP; j += kPsdGemmThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
+    __syncthreads();
+  }
+  for (int task = blockIdx.x * (kPsdGemmThreads / 64) + wave; task < ntask; task += gridDim.x * (kPsdGemmThreads / 64)) {
+    if (KIND == PSD_G1) psd_task_g1(task, NP, A, Vt, Tm, Sw, li, lk);
+    else if (KIND == PSD_G2) psd_task_g2(task, NP, A, Vt, Tm, Sw, li, lk);
+    else if (KIND == PSD_R1) psd_task_r1(task, NP, A, V, Tm, lam, Sw, li, lk);
+    else psd_task_r2(task, n, NP, Tm, V, x + B.off[blockIdx.y], li, lk);
+  }
+  if (KIND == PSD_R2 && blockIdx.x == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;
 }
 
 // ---------------------------------------------------------------------------

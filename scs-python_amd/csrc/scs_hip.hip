@@ -350,12 +350,17 @@ struct ScsHipWork {
       PsdBatch B{off, order, woff, big};
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
+        const dim3 gg((unsigned)((psd_max_tiles * ((psd_max_tiles + kPsdNJ - 1) / kPsdNJ) + 3) / 4), (unsigned)big), gb(kPsdGemmThreads);
+        hipLaunchKernelGGL(k_proj_psd<2>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         for (int round = 0; round < kPsdSplitRounds; ++round) {
           hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
         }
-        hipLaunchKernelGGL(k_psd_recon, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
       } else {
         hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
       }

@@ -48,11 +48,17 @@ int main(int argc, char **argv) {
     HIP_CHECK(hipEventRecord(e0));
     if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, nullptr);
     else if (split) {
+      const int ntile = (int)np / 16;
+      const dim3 gg((unsigned)((ntile * ((ntile + kPsdNJ - 1) / kPsdNJ) + 3) / 4), (unsigned)cnt), gb(kPsdGemmThreads);
+      hipLaunchKernelGGL(k_proj_psd<2>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       for (int round = 0; round < 3; ++round) {
         hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
         hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
-      hipLaunchKernelGGL(k_psd_recon, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, nullptr);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
     } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
     HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

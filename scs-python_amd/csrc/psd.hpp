@@ -65,7 +65,7 @@ constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
 #define PSD_OFFTOL2 1e-16
 #endif
 constexpr double kPsdOffTol2 = PSD_OFFTOL2;  // sweeps stop at ||offdiag||_F^2 <= this * ||A||_F^2 (see the reconstruction)
-constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int) + 256;
+constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int);
 
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
@@ -364,13 +364,11 @@ template <int MODE>
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall) {
   SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints) |
-  //      inner N=16 schedule (15*16 bytes)
+  // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints)
   double *lds = reinterpret_cast<double *>(smem_raw);
   double *red = lds + kPsdWaves * kPsdWaveLds;
   double *bc = red + 16;
   int *osch = reinterpret_cast<int *>(bc + 2);
-  unsigned char *isch = reinterpret_cast<unsigned char *>(osch + 2 * kPsdMaxH);
   const int cidx = blockIdx.x;
   const int n = B.order[cidx];
   double *X = x + B.off[cidx];
@@ -414,9 +412,6 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     }
     if (finished) return;  // converged in an earlier round: nothing to log, k_psd_apply_v has nothing to do
   }
-  if (MODE == 2 && n >= 2) {
-    // (orders 0 and 1 were finished above; nothing else to prepare)
-  }
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int li = lane & 15, lk = lane >> 4;
   const int nblk = H * (H + 1) / 2, ntile = NP / 16;
@@ -427,12 +422,6 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     const int i = e % NP, j = e / NP;
     A[e] = 0.;
     if (!warm) V[e] = (i == j) ? 1. : 0.;
-  }
-  if (tid < 15 * 8) {
-    int p, q;
-    rr_pair(tid >> 3, tid & 7, 16, p, q);
-    isch[2 * tid] = (unsigned char)p;
-    isch[2 * tid + 1] = (unsigned char)q;
   }
   __syncthreads();
   for (int e = tid; e < n * n; e += kPsdThreads) {  // one flat pass: independent loads, i runs down packed column j

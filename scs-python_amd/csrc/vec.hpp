@@ -3,10 +3,13 @@
 //
 // Plays the role of scs_source/src/linalg.c (named at R:meson.build:191; absent)
 // and replaces the cuBLAS level-1 calls of GPU_INDIRECT (R:legacy_setup.py:263).
-// Every kernel is one pass over its vectors (HBM-bound); scalars such as alpha,
-// beta, tau are produced by single-workgroup "finalize" kernels that reduce the
-// per-block partials in a fixed order and are consumed from device memory by
-// the next kernel — no host round trip per CG step (SURVEY §7 "hard parts").
+// Every kernel is one pass over its vectors (HBM-bound).  Reductions are two-stage
+// and fixed-order: a kernel leaves per-block partials, and the CONSUMER kernel
+// re-reduces them in its prologue (every workgroup, same order => same scalar
+// everywhere): alpha, beta, tau, the iterate norm and the CG tolerance never
+// cost a separate launch, and never a host round trip (SURVEY §7 "hard parts").
+// Single-workgroup finalize kernels remain only off the per-iteration path
+// (cold KKT solves at init / scale updates, residual checks, AA).
 #pragma once
 #include "common.hpp"
 
@@ -191,12 +194,6 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part,
     sc[((fl[F_STEP] + 1) & 1) ? S_ZTR_B : S_ZTR] = ztr;  // the first CG step bumps F_STEP, then reads this slot
     if (rn < fmax(sc[S_TOL], 1e-12)) fl[F_DONE] = 1;
   }
-}
-
-// zero right-hand side => zero solution (both blocks)
-__global__ __launch_bounds__(kVecThreads) void k_zero_if_flag(double *x, long n, const int *fl) {
-  if (!fl[F_ZERO_RHS]) return;
-  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) x[i] = 0.;
 }
 
 // ADMM path: k_fin_tol + k_fin_cg_init + the CG step counter reset + the zero-rhs short circuit in ONE
@@ -500,15 +497,6 @@ __global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__res
       s[k] = rsk[i] / (D ? D[k] * sigma : 1.0) * fs;
     }
   }
-}
-
-// s.y partial (comp_slack)
-__global__ __launch_bounds__(kVecThreads) void k_dot(const double *__restrict__ a, const double *__restrict__ b, long n, double *part) {
-  __shared__ double sm[kVecThreads / 64];
-  double s = 0.;
-  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += a[i] * b[i];
-  s = block_sum<kVecThreads>(s, sm);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
 // per-iteration CSV diagnostics: [||u-u_t||_2^2, ||v-v_prev||_2^2, ||u-u_t||_inf, ||v-v_prev||_inf]

@@ -15,6 +15,7 @@
 // (except the l2-pass contribution of P and the mean over large cone blocks: ~1 ulp).
 #pragma once
 #include "common.hpp"
+#include "spmv.hpp"
 #include "vec.hpp"
 
 namespace scship {
@@ -29,6 +30,70 @@ __global__ __launch_bounds__(kVecThreads) void k_row_norm(const int *__restrict_
       acc = l2 ? __dadd_rn(acc, __dmul_rn(v, v)) : fmax(acc, v);  // no FMA contraction: same bits as the CPU restatement
     }
     out[r] = acc;
+  }
+}
+
+// One equilibration sweep over a CSR matrix, coalesced (row blocks of spmv.hpp: lanes stream the nonzeros, the
+// row phases work on LDS):  val[p] <- val[p] * (rs[row] * cs[col[p]])  (skipped when rs == nullptr), then
+// out[r] = max |val| (l2 = 0) or sum val^2 (l2 = 1) over the UPDATED row r (skipped when l2 < 0).
+// Fusing the norm of the next pass into the rescale of this one halves the passes over the matrices; per-row
+// order is ascending p as in k_row_norm / k_rescale, so D and E keep their bits (rows longer than a block:
+// workgroup reduction, ~1 ulp in the l2 pass).
+__global__ __launch_bounds__(kSpmvThreads) void k_rescale_norm(CsrView A, double *val, const double *__restrict__ rs,
+                                                               const double *__restrict__ cs, int l2, double *out) {
+  __shared__ double buf[kNnzPerWg];
+  __shared__ double red[kSpmvThreads / 64];
+  const int tid = threadIdx.x;
+  const int4 bi = A.blk[blockIdx.x];
+  const int r0 = bi.x, r1 = bi.y, p0 = bi.z, p1 = bi.w, nnz = p1 - p0;
+  if (nnz <= kNnzPerWg) {
+    int ra[kRowsPerLane], re[kRowsPerLane];
+#pragma unroll
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      const int r = r0 + tid + j * kSpmvThreads;
+      ra[j] = r < r1 ? A.rowptr[r] - p0 : 0;
+      re[j] = r < r1 ? A.rowptr[r + 1] - p0 : 0;
+      if (rs && r < r1) {
+        const double f = rs[r];
+        for (int k = ra[j]; k < re[j]; ++k) buf[k] = f;  // row factor of every nonzero of the row
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < nnz; k += kSpmvThreads) {
+      double v = val[p0 + k];
+      if (rs) {
+        v = __dmul_rn(v, __dmul_rn(buf[k], cs[A.col[p0 + k]]));
+        val[p0 + k] = v;
+      }
+      v = fabs(v);
+      buf[k] = l2 > 0 ? __dmul_rn(v, v) : v;
+    }
+    if (l2 < 0) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      const int r = r0 + tid + j * kSpmvThreads;
+      if (r < r1) {
+        double acc = 0.;
+        for (int k = ra[j]; k < re[j]; ++k) acc = l2 > 0 ? __dadd_rn(acc, buf[k]) : fmax(acc, buf[k]);
+        out[r] = acc;
+      }
+    }
+  } else {  // one long row
+    const double f = rs ? rs[r0] : 1.0;
+    double acc = 0.;
+    for (int p = p0 + tid; p < p1; p += kSpmvThreads) {
+      double v = val[p];
+      if (rs) {
+        v = __dmul_rn(v, __dmul_rn(f, cs[A.col[p]]));
+        val[p] = v;
+      }
+      v = fabs(v);
+      acc = l2 > 0 ? __dadd_rn(acc, __dmul_rn(v, v)) : fmax(acc, v);
+    }
+    if (l2 < 0) return;
+    acc = l2 > 0 ? block_sum<kSpmvThreads>(acc, red) : block_max<kSpmvThreads>(acc, red);
+    if (tid == 0) out[r0] = acc;
   }
 }
 

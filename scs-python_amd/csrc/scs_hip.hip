@@ -203,14 +203,21 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
   DevBuf<int> dboff, dblen;
   const int nblocks = (int)boff.size();
   if (nblocks) { dboff.upload(boff.data(), boff.size(), s); dblen.upload(blen.data(), blen.size(), s); }
+  // norms of pass p+1 come out of the rescale sweep of pass p (k_rescale_norm); the very first norms need their own sweep
+  DevBuf<double> Dn, En;
+  Dn.alloc(m);
+  En.alloc(n);
+  auto sweep = [&](DeviceCsr &M, const double *rs, const double *cs, int l2, double *out) {
+    if (M.nblk > 0)
+      hipLaunchKernelGGL(k_rescale_norm, dim3(M.nblk), dim3(kSpmvThreads), 0, s, M.view().csr, M.val.p, rs, cs, l2, out);
+  };
+  sweep(Ar, nullptr, nullptr, 0, Dt.p);
+  sweep(At, nullptr, nullptr, 0, Et.p);
+  if (Pf) sweep(*Pf, nullptr, nullptr, 0, Ep.p);
   for (int pass = 0; pass < 26; ++pass) {
     const int l2 = pass >= 25 ? 1 : 0;
-    hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Ar.rowptr.p, Ar.val.p, m, l2, Dt.p);
-    hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, At.rowptr.p, At.val.p, n, l2, Et.p);
-    if (Pf) {
-      hipLaunchKernelGGL(k_row_norm, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Pf->rowptr.p, Pf->val.p, n, l2, Ep.p);
-      hipLaunchKernelGGL(k_combine, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, Ep.p, n, l2);
-    }
+    const int l2_next = pass + 1 >= 26 ? -1 : (pass + 1 >= 25 ? 1 : 0);
+    if (Pf) hipLaunchKernelGGL(k_combine, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, Ep.p, n, l2);
     if (l2) {
       hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, m);
       hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, n);
@@ -220,11 +227,11 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
                          dblen.p, nblocks, l2);
     hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, D.p, m);
     hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, E.p, n);
-    hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Ar.rowptr.p, Ar.col.p, Ar.val.p, m, Dt.p, Et.p);
-    hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, At.rowptr.p, At.col.p, At.val.p, n, Et.p, Dt.p);
-    if (Pf)
-      hipLaunchKernelGGL(k_rescale, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Pf->rowptr.p, Pf->col.p, Pf->val.p, n, Et.p,
-                         Et.p);
+    sweep(Ar, Dt.p, Et.p, l2_next, Dn.p);
+    sweep(At, Et.p, Dt.p, l2_next, En.p);
+    if (Pf) sweep(*Pf, Et.p, Et.p, l2_next, Ep.p);
+    std::swap(Dt.p, Dn.p);
+    std::swap(Et.p, En.p);
   }
   HIP_CHECK(hipStreamSynchronize(s));  // Dt/Et/Ep and the block arrays are locals
 }

@@ -213,6 +213,52 @@ __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const
   }
 }
 
+
+// ------------------------------------------------------------------ experiment: scalar-cache prefetcher
+// A separate tiny kernel (one wave per workgroup) on a second stream touches the val / col / roff lines of the
+// slab format with SCALAR loads (s_load_dword: scalar data cache -> L2 -> HBM; not the TA/TCP path the compute
+// waves gather through), in the order the compute workgroups consume them, so that their streaming loads hit
+// L2 / Infinity Cache instead of waiting for HBM in the in-order vector-memory return queue.
+__device__ __forceinline__ void s_touch16(const char *p) {  // 15 lines (128 B apart) in flight, then wait
+  unsigned d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14;
+  asm volatile(
+      "s_load_dword %0, %15, 0x0\n s_load_dword %1, %15, 0x80\n s_load_dword %2, %15, 0x100\n s_load_dword %3, %15, 0x180\n"
+      "s_load_dword %4, %15, 0x200\n s_load_dword %5, %15, 0x280\n s_load_dword %6, %15, 0x300\n s_load_dword %7, %15, 0x380\n"
+      "s_load_dword %8, %15, 0x400\n s_load_dword %9, %15, 0x480\n s_load_dword %10, %15, 0x500\n s_load_dword %11, %15, 0x580\n"
+      "s_load_dword %12, %15, 0x600\n s_load_dword %13, %15, 0x680\n s_load_dword %14, %15, 0x700\n s_waitcnt lgkmcnt(0)"
+      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
+        "=&s"(d10), "=&s"(d11), "=&s"(d12), "=&s"(d13), "=&s"(d14)
+      : "s"(p)
+      : "memory");
+}
+__device__ __forceinline__ void s_touch_range(const void *base, long bytes, int part, int nparts) {
+  // lines [0, nl) of the range split into nparts contiguous shares; batches of 15 lines (tail over-reads < 2 KB:
+  // callers pad their buffers)
+  const char *b = reinterpret_cast<const char *>(base);
+  const long nl = (bytes + 127) >> 7;
+  const long per = (nl + nparts - 1) / nparts;
+  long l0 = per * part, l1 = l0 + per < nl ? l0 + per : nl;
+  for (long l = l0; l < l1; l += 15) {
+    const char *p = b + (l << 7);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) >> 32));
+    s_touch16(reinterpret_cast<const char *>(((unsigned long)hi << 32) | lo));
+  }
+}
+// workgroup w (one wave): XCD x = w % 8, k = w / 8; chunk c = 8 * (k / WPC) + x, share k % WPC of every segment of c
+__global__ __launch_bounds__(64) void k_pf_scalar(SlabView A, int WPC, int what) {
+  const int w = blockIdx.x, xcd = w & 7, k = w >> 3;
+  const int c = 8 * (k / WPC) + xcd, part = k % WPC;
+  if (c >= A.nchunks) return;
+  const size_t sg = (size_t)c * A.S;
+  for (int s = 0; s < A.S; ++s) {
+    const int q0 = A.segptr[sg + s], q1 = A.segptr[sg + s + 1];
+    if (what & 1) s_touch_range(A.val + q0, (long)(q1 - q0) * 8, part, WPC);
+    if (what & 2) s_touch_range(A.col + q0, (long)(q1 - q0) * 4, part, WPC);
+    if (what & 4) s_touch_range(A.roff + (sg + s) * (A.R + kSlabRoffPad), (long)(A.R + 1) * 2, part, WPC);
+  }
+}
+
 // ------------------------------------------------------------------ host side
 struct Csr {
   int rows, cols;
@@ -305,6 +351,44 @@ static void run_base(const char *tag, int rpt, const Csr &M, const double *dx, d
   free_slab(d);
 }
 
+
+static void run_base_pf(const char *tag, int rpt, int wpc, int what, const Csr &M, const double *dx, double *dy,
+                        const std::vector<double> &ref) {
+  HostSlab hs;
+  const bool ok = build_slab(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hs, nullptr, 256 * rpt);
+  if (!ok) { std::printf("  %-34s build failed\n", tag); return; }
+  for (int i = 0; i < 1024; ++i) { hs.col.push_back(0); hs.val.push_back(0.); hs.roff.push_back(0); }  // over-read pad
+  DevSlab d = upload_slab(hs);
+  SpmvMat mat; mat.slab = d.v; mat.use_slab = true;
+  HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+  hipStream_t s1, s2;
+  HIP_CHECK(hipStreamCreate(&s1)); HIP_CHECK(hipStreamCreate(&s2));
+  const int reps = 20, npf = ((hs.nchunks + 7) / 8) * 8 * wpc;
+  std::vector<hipEvent_t> ev(reps + 4);
+  for (auto &e : ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+  auto one = [&](int i) {
+    if (i > 0) HIP_CHECK(hipStreamWaitEvent(s2, ev[i - 1], 0));
+    hipLaunchKernelGGL(k_pf_scalar, dim3(npf), dim3(64), 0, s2, d.v, wpc, what);
+    launch_spmv(mat, dx, EpiStore{dy, 0}, nullptr, s1);
+    HIP_CHECK(hipEventRecord(ev[i], s1));
+  };
+  for (int i = 0; i < 3; ++i) one(i);
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipEventRecord(a, s1));
+  for (int i = 0; i < reps; ++i) one(i);
+  HIP_CHECK(hipEventRecord(b, s1));
+  HIP_CHECK(hipDeviceSynchronize());
+  float ms; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  // the prefetcher alone
+  const double pf_us = time_us([&] { hipLaunchKernelGGL(k_pf_scalar, dim3(npf), dim3(64), 0, 0, d.v, wpc, what); }, 10);
+  std::printf("  %-34s R=%5d S=%2d wgs=%4d pf_wgs=%5d : %7.1f us  (prefetcher alone %7.1f us)  mismatches %ld\n", tag, hs.R, hs.S,
+              hs.nchunks, npf, ms * 1e3 / reps, pf_us, mismatches(dy, ref));
+  HIP_CHECK(hipStreamDestroy(s1)); HIP_CHECK(hipStreamDestroy(s2));
+  free_slab(d);
+}
+
 static void bench_matrix(const char *name, const Csr &M) {
   std::printf("%s: %d x %d, nnz %d\n", name, M.rows, M.cols, M.rowptr[M.rows]);
   std::vector<double> x(M.cols), ref(M.rows);
@@ -320,6 +404,17 @@ static void bench_matrix(const char *name, const Csr &M) {
   HIP_CHECK(hipMalloc(&dy, M.rows * sizeof(double)));
   run_base("shipped k_spmv_slab rpt16", 16, M, dx, dy, ref);
   run_base("shipped k_spmv_slab rpt8", 8, M, dx, dy, ref);
+  if (getenv("LAB_PF")) {
+    for (int rpt : {16, 8}) {
+      run_base_pf("shipped + scalar pf x2 val+col", rpt, 2, 3, M, dx, dy, ref);
+      run_base_pf("shipped + scalar pf x4 val+col", rpt, 4, 3, M, dx, dy, ref);
+      run_base_pf("shipped + scalar pf x4 all", rpt, 4, 7, M, dx, dy, ref);
+      run_base_pf("shipped + scalar pf x8 all", rpt, 8, 7, M, dx, dy, ref);
+      run_base_pf("shipped + scalar pf x4 val", rpt, 4, 1, M, dx, dy, ref);
+    }
+    hipFree(dx); hipFree(dy);
+    return;
+  }
   run_ga<256, 16, 6>("gather-ahead 256x16 nq6", M, dx, dy, ref);
   run_ga<256, 8, 3>("gather-ahead 256x8 nq3", M, dx, dy, ref);
   run_ga<512, 4, 2>("gather-ahead 512x4 nq2", M, dx, dy, ref);

@@ -27,6 +27,7 @@
 #include "psd.hpp"
 #include "cg_persist.hpp"
 #include "setup_dev.hpp"
+#include "setup_cs_dev.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
 
@@ -54,6 +55,28 @@ struct DeviceCsr {
   DevBuf<unsigned short> s_roff;
   DevBuf<double> s_val;
   int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
+  // optional column-sorted pass copy (spmv_cs.hpp); preferred over the slab copy when both could be built
+  DeviceCs cs;
+  static bool cs_enabled() {  // SCS_HIP_CS=0: keep the slab kernel (A/B measurements)
+    const char *e = getenv("SCS_HIP_CS");
+    return !(e && e[0] == '0');
+  }
+  // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays
+  bool build_cs_dev(const DeviceCsr &T, hipStream_t s) {
+    cs.release();
+    const char *env = getenv("SCS_HIP_SLAB");
+    if (!cs_enabled() || !slab_wanted(rows, cols) || (env && env[0] == '0')) return false;
+    return cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s);
+  }
+  bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s) {
+    cs.release();
+    const char *env = getenv("SCS_HIP_SLAB");
+    if (!cs_enabled() || !slab_wanted(rows, cols) || (env && env[0] == '0')) return false;
+    HostCs h;
+    if (!build_cs(rp, ci, v, rows, cols, h)) return false;
+    cs.from_host(h, s);
+    return true;
+  }
   static bool host_setup() {  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
     const char *e = getenv("SCS_HIP_SETUP");
     return e && e[0] == 'h';
@@ -166,9 +189,11 @@ struct DeviceCsr {
     M.csr = CsrView{rowptr.p, col.p, val.p, rowblk.p, rows, cols, nblk, nnz};
     M.use_slab = has_slab;
     if (has_slab) M.slab = SlabView{s_segptr.p, s_roff.p, s_col.p, s_val.p, rows, cols, s_nchunks, s_S, s_R, s_max_seg};
+    M.use_cs = cs.ok;
+    if (cs.ok) M.cs = cs.view();
     return M;
   }
-  int nwg() const { return has_slab ? s_nchunks : nblk; }
+  int nwg() const { return cs.ok ? cs.nchunks : has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
     if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)
@@ -1249,8 +1274,8 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   bool slabs_pending = false;
   w->At.upload(n, m, d->A->p, d->A->i, d->A->x, s, /*allow_slab=*/host_build);
   mark("A' upload (+ slab build on the host)");
+  HostCsr ar, pf;  // host copies of the index arrays: only filled on the host paths
   if (host_build || !w->Ar.transpose_from(w->At, s)) {
-    HostCsr ar;
     csc_to_csr(m, n, d->A->p, d->A->i, d->A->x, ar);
     mark("CSC -> CSR on the host");
     w->Ar.upload(m, n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/host_build);
@@ -1261,7 +1286,6 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     slabs_pending = true;
   }
   if (w->has_P) {
-    HostCsr pf;
     std::vector<double> pdiag;
     sym_expand(n, d->P->p, d->P->i, d->P->x, pf, pdiag);
     w->Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s, /*allow_slab=*/host_build);
@@ -1286,11 +1310,26 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   mark("equilibration (device)");
   for (DeviceCsr *M : {&w->At, &w->Ar, &w->Pf}) M->refresh_slab(s, true);
   if (slabs_pending) {
-    w->At.build_slab_dev(s);
-    w->Ar.build_slab_dev(s);
-    if (w->has_P) w->Pf.build_slab_dev(s);
+    // large matrices: column-sorted pass copy (spmv_cs.hpp), each built from the other orientation's CSR;
+    // the L2-blocked slab copy only where the pattern does not fit that format
+    if (!w->At.build_cs_dev(w->Ar, s)) w->At.build_slab_dev(s);
+    if (!w->Ar.build_cs_dev(w->At, s)) w->Ar.build_slab_dev(s);
+    if (w->has_P && !w->Pf.build_cs_dev(w->Pf, s)) w->Pf.build_slab_dev(s);
   }
-  mark("L2-blocked copies (device) / value refresh");
+  if (host_build) {  // SCS_HIP_SETUP=host: the column-sorted copies from the host builder, on the equilibrated values
+    std::vector<double> hv;
+    auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci) {
+      if (!slab_wanted(M.rows, M.cols)) return;
+      hv.resize((size_t)M.nnz);
+      M.val.download(hv.data(), (size_t)M.nnz, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      M.build_cs_host(rp, ci, hv.data(), s);
+    };
+    host_cs(w->At, d->A->p, d->A->i);
+    host_cs(w->Ar, ar.rowptr.data(), ar.col.data());
+    if (w->has_P) host_cs(w->Pf, pf.rowptr.data(), pf.col.data());
+  }
+  mark("column-sorted / L2-blocked copies, value refresh");
   if (w->has_P) {  // diagonal of the (scaled) P for the Jacobi preconditioner
     w->Pdiag.alloc_zero(n, s);
     hipLaunchKernelGGL(k_csr_diag, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w->Pf.rowptr.p, w->Pf.col.p, w->Pf.val.p, n,
@@ -1316,7 +1355,8 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     // this GPU (a grid barrier costs what a kernel boundary costs: the L2 invalidate + the dependent-load chain
     // of the next phase; measured r01: 0.22 ms/iter either way on a config-5 problem with 16 workgroups, 2x slower
     // with one) => off unless asked for.  SCS_HIP_PERSIST = "W" or "WxG": W workgroups of G (1, 2, 4) 256-lane groups.
-    const bool eligible = !w->At.has_slab && !w->Ar.has_slab && (!w->has_P || !w->Pf.has_slab) &&
+    const bool eligible = !w->At.has_slab && !w->Ar.has_slab && (!w->has_P || !w->Pf.has_slab) && !w->At.cs.ok && !w->Ar.cs.ok &&
+                          (!w->has_P || !w->Pf.cs.ok) &&
                           2 * vec_blocks(l) + 2 * vec_blocks(std::max(n, m)) <= 2 * kMaxVecBlocks;
     int wgs = 0, ng = 2;
     if (const char *env = getenv("SCS_HIP_PERSIST")) {
@@ -1392,7 +1432,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
                   w->persist_wgs, 4 * w->persist_ng);
   else
     std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV, PCG)",
-                  w->At.has_slab ? "L2-blocked slab" : "CSR-stream");
+                  w->At.cs.ok ? "column-sorted pass" : w->At.has_slab ? "L2-blocked slab" : "CSR-stream");
   // per-solve state
   w->sum_log_scale_factor = 0; w->n_log_scale_factor = 0; w->last_scale_update_iter = 0; w->scale_updates = 0;
   w->rejected_accel = 0; w->accepted_accel = 0; w->aa_iter = 0; w->aa_success = 0; w->aa_pending_safeguard = false;
@@ -1793,13 +1833,22 @@ struct TmpStream {
 };
 
 static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hipStream_t s) {
+  HostCsr ar;
+  csc_to_csr(A->m, A->n, A->p, A->i, A->x, ar);
+  const bool host = DeviceCsr::host_setup();
+  DeviceCsr T;  // the other orientation: what the device builder of the column-sorted copy reads
   if (transpose) {
     M.upload(A->n, A->m, A->p, A->i, A->x, s);
+    if (host) { M.build_cs_host(A->p, A->i, A->x, s); return; }
+    if (!slab_wanted(M.rows, M.cols)) return;
+    T.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/false);
   } else {
-    HostCsr ar;
-    csc_to_csr(A->m, A->n, A->p, A->i, A->x, ar);
     M.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s);
+    if (host) { M.build_cs_host(ar.rowptr.data(), ar.col.data(), ar.val.data(), s); return; }
+    if (!slab_wanted(M.rows, M.cols)) return;
+    T.upload(A->n, A->m, A->p, A->i, A->x, s, /*allow_slab=*/false);
   }
+  M.build_cs_dev(T, s);
 }
 
 int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose) {
@@ -1907,6 +1956,11 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
       sym_expand(n, P->p, P->i, P->x, pf, pdiag);
       w.Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s);
       w.Pdiag.upload(pdiag.data(), n, s);
+    }
+    if (!DeviceCsr::host_setup()) {
+      w.At.build_cs_dev(w.Ar, s);
+      w.Ar.build_cs_dev(w.At, s);
+      if (P) w.Pf.build_cs_dev(w.Pf, s);
     }
     std::vector<double> dr(w.l, 10.0);
     std::copy(diag_r, diag_r + n + m, dr.begin());

@@ -1,0 +1,269 @@
+// setup_cs_dev.hpp — the column-sorted pass layout of spmv_cs.hpp built on the device at scs_init.
+//
+// Input: T = CSR of the TRANSPOSE of the matrix M the layout is for (for M = A that is the caller's CSC(A) as it
+// arrived, for M = A' the CSR(A) built by setup_dev.hpp, for the symmetric P itself).  T's nonzero array is M's
+// nonzeros in (column, row) order, so the (column, row)-sorted stream of every row chunk of M is a STABLE
+// partition of that array by chunk = row / R:
+//   1. k_cs_hist     per block of 4096 consecutive nonzeros: how many fall into each chunk (LDS integer atomics);
+//   2. exclusive scan over (chunk, block)  -> where each block's share of each chunk starts;
+//   3. k_cs_scatter  per block: bitonic sort of (chunk << 12 | position) in LDS gives the stable rank inside the
+//                    block; entries go to their place in the chunk streams {row, column, source position};
+//   4. k_cs_cut      per chunk: greedy cut into passes (<= 8192 nonzeros, < 2^19 columns wide);
+//   5. k_cs_fill     per pass: bitonic sort of (owner-lane-major row key << 13 | position) = the LDS slot of every
+//                    nonzero; writes val / idx in the lane-major quad order and the per-lane run descriptors.
+// Integer work only; the result is identical, entry for entry, to spmv_cs.hpp build_cs (the host builder).
+#pragma once
+#include "common.hpp"
+#include "setup_dev.hpp"
+#include "spmv_cs.hpp"
+
+namespace scship {
+
+constexpr int kCsBlock = 4096;     // nonzeros per partition block
+constexpr int kCsMaxChunks = 4096;
+
+// ascending bitonic sort of N (power of two) keys in LDS by the whole workgroup
+template <int N>
+__device__ __forceinline__ void bitonic_sort_lds(unsigned *k) {
+  for (int size = 2; size <= N; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < N / 2; t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned a = k[lo], b = k[hi];
+        if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+      }
+    }
+  __syncthreads();
+}
+
+// hist[chunk * nblocks + block]
+__global__ __launch_bounds__(1024) void k_cs_hist(const int *__restrict__ trow, long nnz, int R, int nchunks, int nblocks, int *hist) {
+  __shared__ int cnt[kCsMaxChunks];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < nchunks; c += blockDim.x) cnt[c] = 0;
+  __syncthreads();
+  for (int l = threadIdx.x; l < kCsBlock; l += blockDim.x) {
+    const long p = (long)b * kCsBlock + l;
+    if (p < nnz) atomicAdd(&cnt[trow[p] / R], 1);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < nchunks; c += blockDim.x) hist[(size_t)c * nblocks + b] = cnt[c];
+}
+
+__global__ __launch_bounds__(1024) void k_cs_scatter(const int *__restrict__ tptr, const int *__restrict__ trow, int trows, long nnz, int R,
+                                                     int nchunks, int nblocks, const int *__restrict__ hoff, int *s_row, int *s_col,
+                                                     int *s_src) {
+  __shared__ unsigned key[kCsBlock];
+  __shared__ int first[kCsMaxChunks];
+  const int b = blockIdx.x;
+  for (int l = threadIdx.x; l < kCsBlock; l += blockDim.x) {
+    const long p = (long)b * kCsBlock + l;
+    key[l] = p < nnz ? ((unsigned)(trow[p] / R) << 12) | (unsigned)l : 0xffffffffu;
+  }
+  bitonic_sort_lds<kCsBlock>(key);
+  for (int i = threadIdx.x; i < kCsBlock; i += blockDim.x) {
+    const unsigned k = key[i];
+    if (k != 0xffffffffu && (i == 0 || (key[i - 1] >> 12) != (k >> 12))) first[k >> 12] = i;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kCsBlock; i += blockDim.x) {
+    const unsigned k = key[i];
+    if (k == 0xffffffffu) continue;
+    const int c = (int)(k >> 12);
+    const long p = (long)b * kCsBlock + (k & 4095);
+    const int dst = hoff[(size_t)c * nblocks + b] + (i - first[c]);
+    // the row of T holding position p: largest j with tptr[j] <= p
+    int lo = 0, hi = trows;  // invariant tptr[lo] <= p < tptr[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    s_row[dst] = trow[p];
+    s_col[dst] = lo;
+    s_src[dst] = (int)p;
+  }
+}
+
+// one workgroup: passes of every chunk.  pass_info = {first stream position, nonzeros, first column, chunk}
+__global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, int nblocks, int nchunks, long nnz,
+                                                 const int *__restrict__ s_col, int max_pass, int *passptr, int4 *pass_info, int *fail) {
+  __shared__ int sm[kScanThreads / 64];
+  __shared__ int carry_sm;
+  auto cut = [&](int c, int4 *out) {  // passes of chunk c (written from out[0] on when out != nullptr)
+    const long e_begin = hoff[(size_t)c * nblocks], e_end = c + 1 < nchunks ? hoff[(size_t)(c + 1) * nblocks] : nnz;
+    int np = 0;
+    long e0 = e_begin;
+    while (e0 < e_end) {
+      long e1 = e0 + kCsPass < e_end ? e0 + kCsPass : e_end;
+      const int base = s_col[e0];
+      if ((long)s_col[e1 - 1] - base >= (1L << kCsColBits)) {
+        long lo = e0, hi = e1 - 1;  // s_col[lo] - base fits, s_col[hi] - base does not
+        while (hi - lo > 1) {
+          const long mid = (lo + hi) >> 1;
+          if ((long)s_col[mid] - base >= (1L << kCsColBits)) hi = mid; else lo = mid;
+        }
+        e1 = hi;
+      }
+      if (out) out[np] = int4{(int)e0, (int)(e1 - e0), base, c};
+      ++np;
+      e0 = e1;
+    }
+    return np;
+  };
+  if (threadIdx.x == 0) carry_sm = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nchunks; c0 += kScanThreads) {
+    const int c = c0 + threadIdx.x;
+    const int np = c < nchunks ? cut(c, nullptr) : 0;
+    int total;
+    const int off = block_excl_scan(np, sm, total);
+    const int start = carry_sm + off;
+    if (c < nchunks) {
+      passptr[c] = start;
+      if (start + np <= max_pass) cut(c, pass_info + start);
+      else atomicExch(fail, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_sm += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) passptr[nchunks] = carry_sm;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_info, const int *__restrict__ s_row,
+                                                  const int *__restrict__ s_col, const int *__restrict__ s_src,
+                                                  const double *__restrict__ tval, int R, unsigned *idx, double *val,
+                                                  unsigned long long *meta, int2 *pinfo, int *fail) {
+  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr int RR = kCsThreads * RPT;
+  __shared__ unsigned key[kCsPass];
+  __shared__ int cnt[RR];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int4 pi = pass_info[g];
+  const int begin = pi.x, len = pi.y, base = pi.z, r0 = pi.w * R;
+  for (int k = tid; k < RR; k += kCsThreads) cnt[k] = 0;
+  __syncthreads();
+  for (int q = tid; q < kCsPass; q += kCsThreads) {
+    unsigned k = (unsigned)RR;
+    if (q < len) {
+      const int rl = s_row[begin + q] - r0;
+      k = (unsigned)((rl % kCsThreads) * RPT + rl / kCsThreads);
+      atomicAdd(&cnt[k], 1);
+    }
+    key[q] = (k << kCsSlotBits) | (unsigned)q;
+  }
+  bitonic_sort_lds<kCsPass>(key);
+  const size_t o = (size_t)g * kCsPass;
+  for (int i = tid; i < kCsPass; i += kCsThreads) {
+    const int q = (int)(key[i] & (kCsPass - 1)), sp = cs_store_pos(q);
+    if (q < len) {
+      const int e = begin + q;
+      idx[o + sp] = ((unsigned)(s_col[e] - base) << kCsSlotBits) | (unsigned)i;
+      val[o + sp] = tval[s_src[e]];
+    } else {
+      idx[o + sp] = (unsigned)i;
+      val[o + sp] = 0.0;
+    }
+  }
+  // run descriptor of lane tid: slots before its first row = entries with key < tid * RPT
+  const unsigned want = (unsigned)(tid * RPT) << kCsSlotBits;
+  int lo = -1, hi = kCsPass;  // key[lo] < want <= key[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (key[mid] < want) lo = mid; else hi = mid;
+  }
+  unsigned long long w = (unsigned long long)hi;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int n = cnt[tid * RPT + j];
+    if (n > (1 << CB) - 1) atomicExch(fail, 1);
+    w |= (unsigned long long)(n & ((1 << CB) - 1)) << (16 + CB * j);
+  }
+  meta[(size_t)g * kCsThreads + tid] = w;
+  if (tid == 0) pinfo[g] = int2{base, len};
+}
+
+// Owning device copy of one matrix in the column-sorted pass layout
+struct DeviceCs {
+  DevBuf<int> passptr;
+  DevBuf<int2> pinfo;
+  DevBuf<unsigned> idx;
+  DevBuf<double> val;
+  DevBuf<unsigned long long> meta;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0;
+  bool ok = false;
+  void release() {
+    passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release();
+    ok = false;
+  }
+  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass}; }
+  void from_host(const HostCs &h, hipStream_t s) {
+    rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass;
+    passptr.upload(h.passptr.data(), h.passptr.size(), s);
+    pinfo.upload(h.pinfo.data(), h.pinfo.size(), s);
+    idx.upload(h.idx.data(), h.idx.size(), s);
+    val.upload(h.val.data(), h.val.size(), s);
+    meta.upload(h.meta.data(), h.meta.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    ok = true;
+  }
+  // layout for the matrix M (rows_ x cols_) whose TRANSPOSE is the CSR (tptr, trow, tval) with cols_ rows.
+  // false (and nothing kept) when the pattern does not fit the format: the caller keeps its other layouts.
+  bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s) {
+    release();
+    rows = rows_; cols = cols_;
+    const int rpt = cs_pick_rpt(rows);
+    R = kCsThreads * rpt;
+    nchunks = (rows + R - 1) / R;
+    const int nblocks = (int)((nnz + kCsBlock - 1) / kCsBlock);
+    if (nnz <= 0 || nchunks > kCsMaxChunks || (long)nchunks * nblocks > (long)kScanTile * kScanTile || nnz > 2000000000L) return false;
+    const long nh = (long)nchunks * nblocks;
+    DevBuf<int> hist, hoff, tmp, s_row, s_col, s_src, flag;
+    DevBuf<int4> pass_info;
+    hist.alloc((size_t)nh);
+    hoff.alloc((size_t)nh + 1);
+    tmp.alloc_zero((size_t)(nh / kScanTile + 4), s);
+    flag.alloc_zero(1, s);
+    s_row.alloc((size_t)nnz); s_col.alloc((size_t)nnz); s_src.alloc((size_t)nnz);
+    hipLaunchKernelGGL(k_cs_hist, dim3(nblocks), dim3(1024), 0, s, trow, nnz, R, nchunks, nblocks, hist.p);
+    device_exclusive_scan(hist.p, hoff.p, nh, tmp.p, s);
+    hipLaunchKernelGGL(k_cs_scatter, dim3(nblocks), dim3(1024), 0, s, tptr, trow, cols, nnz, R, nchunks, nblocks, hoff.p, s_row.p,
+                       s_col.p, s_src.p);
+    // acceptance bound of build_cs: more passes than this means too much padding
+    const long max_pass_l = (nnz + nnz / 4) / kCsPass + nchunks + 1;
+    const int max_pass = (int)std::min<long>(max_pass_l, 2000000000L / kCsPass);
+    pass_info.alloc((size_t)max_pass);
+    passptr.alloc((size_t)nchunks + 1);
+    hipLaunchKernelGGL(k_cs_cut, dim3(1), dim3(kScanThreads), 0, s, hoff.p, nblocks, nchunks, nnz, s_col.p, max_pass, passptr.p,
+                       pass_info.p, flag.p);
+    int failed = 0;
+    HIP_CHECK(hipMemcpyAsync(&npass, passptr.p + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&failed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failed || (long)npass * kCsPass > nnz + nnz / 4 + (long)nchunks * kCsPass) { release(); return false; }
+    idx.alloc((size_t)npass * kCsPass);
+    val.alloc((size_t)npass * kCsPass);
+    meta.alloc((size_t)npass * kCsThreads);
+    pinfo.alloc((size_t)npass);
+    const dim3 gr(npass), bl(kCsThreads);
+#define SCS_CS_FILL(RPT_) hipLaunchKernelGGL((k_cs_fill<RPT_>), gr, bl, 0, s, pass_info.p, s_row.p, s_col.p, s_src.p, tval, R, idx.p, val.p, meta.p, pinfo.p, flag.p)
+    switch (rpt) {
+      case 1: SCS_CS_FILL(1); break;
+      case 2: SCS_CS_FILL(2); break;
+      case 4: SCS_CS_FILL(4); break;
+      case 8: SCS_CS_FILL(8); break;
+      default: SCS_CS_FILL(16); break;
+    }
+#undef SCS_CS_FILL
+    HIP_CHECK(hipMemcpyAsync(&failed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failed) { release(); return false; }
+    ok = true;
+    return true;
+  }
+};
+
+}  // namespace scship

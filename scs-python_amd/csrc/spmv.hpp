@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "spmv_cs.hpp"
 
 namespace scship {
 
@@ -559,13 +560,18 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
 struct SpmvMat {
   CsrView csr{};
   SlabView slab{};
-  bool use_slab = false;
-  int nblk() const { return use_slab ? slab.nchunks : csr.nblk; }
+  CsView cs{};
+  bool use_slab = false, use_cs = false;  // use_cs wins (spmv_cs.hpp: column-sorted passes)
+  int nblk() const { return use_cs ? cs.nchunks : use_slab ? slab.nchunks : csr.nblk; }
 };
 
 template <class Epi>
 inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                         int *step_counter = nullptr) {
+  if (M.use_cs) {
+    launch_spmv_cs(M.cs, x, epi, done_flag, s, step_counter);
+    return;
+  }
   if (M.use_slab) {
     if (M.slab.nchunks <= 0) return;
     const dim3 g(M.slab.nchunks), b(kSpmvThreads);

@@ -1,0 +1,256 @@
+// spmv_cs.hpp — K1/K2 for large matrices: column-sorted passes with LDS-staged row partials.
+//
+// Same role as the slab kernel of spmv.hpp (scs_source/linsys/scs_matrix.c accum_by_a / accum_by_atrans, named at
+// R:meson.build:199-202), different data layout.  What bounds a random-pattern SpMV on MI355X is the L2 -> L1 fill
+// port of a CU: every 8-byte gather moves a 128-byte line (~2 clk); a wave instruction whose 64 lanes touch 64
+// different lines costs 85 us per 2e7 gathers, one touching 24 lines 40 us (tools/gather_flavours.hip).  Lanes that
+// own ROWS always gather 64 unrelated columns.  Here the lanes of an instruction take 64 CONSECUTIVE nonzeros of a
+// column-sorted stream, so they share lines: the expected number of distinct lines is 64 * (1 - exp(-d)) / d with
+// d = (nonzeros of the workgroup's rows per 128-byte line of x) = R * nnz_per_row * 16 / cols — it only depends on
+// the number of rows R a workgroup owns, hence ONE workgroup of 1024 lanes per CU owning R = 1024 * RPT rows.
+//
+// Layout: rows are cut into chunks of R; the nonzeros of a chunk, sorted by (column, row), are cut into passes of
+// kCsPass = 8192.  A pass stores  val[8192] (fp64),  idx[8192] (uint32 = column relative to the pass's first column
+// << 13 | slot)  and  meta[1024] (uint64 per lane: first slot of the lane's run | RPT counts).  `slot` is the rank of
+// the nonzero in (owner lane, row, column) order: products are scattered to LDS by slot, then every lane sums the
+// LDS runs of its RPT rows (row = chunk * R + j * 1024 + lane: epilogue accesses are coalesced) into REGISTER
+// accumulators that live across the passes.  Passes are ascending column ranges and a run is in ascending column
+// order, so every row is summed in ascending-column order from 0.0 — bit-identical to the CSR-stream kernel, the
+// slab kernel and the oracle's loops.  The LDS product buffer is double-buffered: one barrier per pass.
+// Inside a block of 256 consecutive sorted nonzeros the storage order is lane-major (lane l holds sorted positions
+// l, 64 + l, 128 + l, 192 + l as one 16-byte quad), so a lane reads 16-byte pieces while each of its four gather
+// instructions still covers 64 consecutive sorted nonzeros.
+// Bytes streamed per nonzero: 8 + 4 + 1 (meta) = 13 (slab kernel: 12 + ~1.6 of row offsets).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+
+#include "common.hpp"
+
+namespace scship {
+
+constexpr int kCsThreads = 1024;
+constexpr int kCsPass = 8192;                 // nonzeros per pass = LDS products per buffer (64 KiB)
+constexpr int kCsQuads = kCsPass / 4 / kCsThreads;  // 16-byte quads per lane and pass
+constexpr int kCsSlotBits = 13;
+constexpr int kCsColBits = 32 - kCsSlotBits;  // a pass may span 2^19 columns
+constexpr int kCsTargetWgs = 256;             // one resident workgroup per CU
+
+struct CsView {
+  const int *passptr;          // nchunks + 1: first pass of every chunk
+  const int2 *pinfo;           // per pass {first column, nonzeros (the rest of the kCsPass entries is padding)}
+  const unsigned *idx;         // npass * kCsPass
+  const double *val;           // npass * kCsPass
+  const unsigned long long *meta;  // npass * kCsThreads
+  int rows, cols, nchunks, R, npass;
+};
+
+__host__ __device__ inline int cs_count_bits(int rpt) { return 48 / rpt < 13 ? 48 / rpt : 13; }
+
+inline int cs_pick_rpt(int rows) {
+  const char *e = getenv("SCS_HIP_CS_RPT");  // experiments only
+  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
+  int rpt = 1;
+  while (rpt < 16 && (long)kCsTargetWgs * kCsThreads * rpt < rows) rpt *= 2;
+  return rpt;
+}
+
+struct HostCs {
+  std::vector<int> passptr;
+  std::vector<int2> pinfo;
+  std::vector<unsigned> idx;
+  std::vector<double> val;
+  std::vector<unsigned long long> meta;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0;
+};
+
+// storage position of sorted position q inside a pass (lane-major quads inside blocks of 256)
+__host__ __device__ inline int cs_store_pos(int q) {
+  const int blk = q >> 8, k = (q >> 6) & 3, lane = q & 63;
+  return (blk << 8) | (lane << 2) | k;
+}
+
+// Host builder (tests, lab, fallback): CSR -> column-sorted passes.  false when the pattern does not fit the
+// format's bit fields (a pass wider than 2^19 columns, or more nonzeros of one row in one pass than the count
+// field holds): the caller keeps the slab / CSR-stream layout.
+inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0) {
+  const int rpt = force_rpt > 0 ? force_rpt : cs_pick_rpt(rows);
+  const int R = kCsThreads * rpt, nchunks = (rows + R - 1) / R;
+  const int cb = cs_count_bits(rpt);
+  const unsigned maxcnt = (1u << cb) - 1;
+  out.rows = rows; out.cols = cols; out.R = R; out.nchunks = nchunks;
+  out.passptr.assign(nchunks + 1, 0);
+  out.pinfo.clear(); out.idx.clear(); out.val.clear(); out.meta.clear();
+  std::vector<int> cnt(R), start(R), run(R);
+  out.passptr[0] = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int r0 = c * R, r1 = std::min(rows, r0 + R);
+    struct Ent { int col, rl, p; };
+    std::vector<Ent> ents;
+    ents.reserve((size_t)(rowptr[r1] - rowptr[r0]));
+    for (int r = r0; r < r1; ++r)
+      for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ents.push_back(Ent{col[p], r - r0, p});
+    std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.col != b.col ? a.col < b.col : a.rl < b.rl; });
+    const long n = (long)ents.size();
+    int np = 0;
+    for (long e0 = 0, e1; e0 < n; e0 = e1, ++np) {
+      // a pass = up to kCsPass consecutive sorted nonzeros spanning fewer than 2^kCsColBits columns
+      e1 = std::min(n, e0 + kCsPass);
+      const int base = ents[e0].col;
+      while ((long)ents[e1 - 1].col - base >= (1L << kCsColBits)) --e1;
+      std::fill(cnt.begin(), cnt.end(), 0);
+      // key of a row: owner lane major, then its j-th row
+      auto keyof = [&](int rl) { return (rl % kCsThreads) * rpt + rl / kCsThreads; };
+      for (long e = e0; e < e1; ++e) cnt[keyof(ents[e].rl)]++;
+      int acc = 0;
+      for (int k = 0; k < R; ++k) { start[k] = acc; acc += cnt[k]; run[k] = 0; if ((unsigned)cnt[k] > maxcnt) return false; }
+      const size_t o = out.val.size();
+      out.val.resize(o + kCsPass, 0.0);
+      out.idx.resize(o + kCsPass, 0u);
+      out.pinfo.push_back(int2{base, (int)(e1 - e0)});
+      for (long e = e0; e < e0 + kCsPass; ++e) {
+        const int q = (int)(e - e0), sp = cs_store_pos(q);
+        if (e < e1) {
+          const int k = keyof(ents[e].rl);
+          const unsigned slot = (unsigned)(start[k] + run[k]++);
+          out.val[o + sp] = val[ents[e].p];
+          out.idx[o + sp] = ((unsigned)(ents[e].col - base) << kCsSlotBits) | slot;
+        } else {
+          out.idx[o + sp] = (unsigned)q;  // padding: zero value, its own slot beyond every run
+        }
+      }
+      for (int t = 0; t < kCsThreads; ++t) {
+        unsigned long long w = (unsigned long long)start[t * rpt];
+        for (int j = 0; j < rpt; ++j) w |= (unsigned long long)cnt[t * rpt + j] << (16 + cb * j);
+        out.meta.push_back(w);
+      }
+    }
+    out.passptr[c + 1] = out.passptr[c] + np;
+  }
+  out.npass = out.passptr[nchunks];
+  // too many short passes (very wide, very sparse chunks): the padding would be streamed on every product
+  if ((long)out.npass * kCsPass > rowptr[rows] + rowptr[rows] / 4 + (long)nchunks * kCsPass) return false;
+  return true;
+}
+
+template <class Epi, int RPT>
+__global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *__restrict__ x, Epi epi, const int *done_flag,
+                                                         int *step_counter) {
+  if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
+  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr unsigned CM = (1u << CB) - 1;
+  constexpr int NQ = kCsQuads;
+  __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
+  __shared__ double red[kCsThreads / 64];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM], acc[RPT];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sums[i] = 0.;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) maxs[i] = 0.;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) acc[j] = 0.;
+
+  const int g0 = A.passptr[c], g1 = A.passptr[c + 1];
+  uint4 ic[NQ], in[NQ];
+  double2 va[NQ], vb[NQ], na[NQ], nb[NQ];
+  unsigned long long mc = 0, mn = 0;
+  int2 pc{0, 0}, pn{0, 0};
+  // a lane's i-th quad belongs to the block of 256 sorted nonzeros (tid >> 6) + 16 i: blocks beyond the pass's
+  // nonzero count hold only padding and are skipped (wave-uniform)
+  auto load = [&](int g, uint4(&ii)[NQ], double2(&a)[NQ], double2(&b)[NQ], unsigned long long &m, int2 &pi) {
+    const uint4 *i4 = reinterpret_cast<const uint4 *>(A.idx + (size_t)g * kCsPass);
+    const double2 *v2 = reinterpret_cast<const double2 *>(A.val + (size_t)g * kCsPass);
+    pi = A.pinfo[g];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * kCsThreads;
+      if (((q >> 6) << 8) < pi.y) {
+        ii[i] = i4[q];
+        a[i] = v2[2 * q];
+        b[i] = v2[2 * q + 1];
+      }
+    }
+    m = A.meta[(size_t)g * kCsThreads + tid];
+  };
+  if (g0 < g1) load(g0, ic, va, vb, mc, pc);
+  int buf = 0;
+  for (int g = g0; g < g1; ++g) {
+    // gathers of this pass first, then the streaming loads of the next one: the in-order return queue hands the
+    // gathered x back without waiting for the HBM latency of the stream
+    const double *xb = x + pc.x;
+    double xg[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if ((((tid + i * kCsThreads) >> 6) << 8) < pc.y) {
+        xg[i][0] = xb[ic[i].x >> kCsSlotBits];
+        xg[i][1] = xb[ic[i].y >> kCsSlotBits];
+        xg[i][2] = xb[ic[i].z >> kCsSlotBits];
+        xg[i][3] = xb[ic[i].w >> kCsSlotBits];
+      }
+    }
+    if (g + 1 < g1) load(g + 1, in, na, nb, mn, pn);
+    double *pb = prod[buf];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if ((((tid + i * kCsThreads) >> 6) << 8) < pc.y) {
+        pb[ic[i].x & (kCsPass - 1)] = va[i].x * xg[i][0];
+        pb[ic[i].y & (kCsPass - 1)] = va[i].y * xg[i][1];
+        pb[ic[i].z & (kCsPass - 1)] = vb[i].x * xg[i][2];
+        pb[ic[i].w & (kCsPass - 1)] = vb[i].y * xg[i][3];
+      }
+    }
+    __syncthreads();
+    int o = (int)(mc & 0xffff);
+    unsigned long long w = mc >> 16;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int n = (int)((unsigned)w & CM);
+      w >>= CB;
+      double t = acc[j];
+      for (int k = 0; k < n; ++k) t += pb[o + k];
+      acc[j] = t;
+      o += n;
+    }
+    buf ^= 1;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { ic[i] = in[i]; va[i] = na[i]; vb[i] = nb[i]; }
+    mc = mn;
+    pc = pn;
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = c * A.R + j * kCsThreads + tid;
+    if (r < A.rows) epi(r, acc[j], sums, maxs);
+  }
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+#pragma unroll
+    for (int i = 0; i < Epi::kSums; ++i) {
+      const double t = block_sum<kCsThreads>(sums[i], red);
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + c] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < Epi::kMaxs; ++i) {
+      const double t = block_max<kCsThreads>(maxs[i], red);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + c] = t;
+    }
+  }
+}
+
+template <class Epi>
+inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
+                           int *step_counter) {
+  if (A.nchunks <= 0) return;
+  const dim3 g(A.nchunks), b(kCsThreads);
+  switch (A.R / kCsThreads) {
+    case 1: hipLaunchKernelGGL((k_spmv_cs<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    case 2: hipLaunchKernelGGL((k_spmv_cs<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    case 4: hipLaunchKernelGGL((k_spmv_cs<Epi, 4>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    case 8: hipLaunchKernelGGL((k_spmv_cs<Epi, 8>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    default: hipLaunchKernelGGL((k_spmv_cs<Epi, 16>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+  }
+}
+
+}  // namespace scship

@@ -61,9 +61,12 @@ def test_spmv_bit_exact(hip, oracle, m, n, density, long_rows):
         np.testing.assert_allclose(got[~short], ref[~short], rtol=1e-12, atol=1e-12)
 
 
-def test_spmv_slab_layout_bit_exact(hip, oracle):
-    """large gather vector (> 2 MiB) + many rows => the L2-blocked slab kernel is selected; it must
-    reproduce the CSR-stream / oracle summation order bit for bit (incl. a dense-ish row and column)."""
+@pytest.mark.parametrize("cs", ["1", "0"], ids=["column-sorted", "slab"])
+def test_spmv_slab_layout_bit_exact(hip, oracle, monkeypatch, cs):
+    """large gather vector (> 2 MiB) + many rows => the column-sorted pass kernel (or, SCS_HIP_CS=0, the L2-blocked
+    slab kernel) is selected; it must reproduce the CSR-stream / oracle summation order bit for bit (incl. a
+    dense-ish row and column)."""
+    monkeypatch.setenv("SCS_HIP_CS", cs)
     rng = np.random.default_rng(17)
     m, n = 70000, 300000
     A = pg.random_sparse(m, n, 4, rng).tolil()
@@ -121,6 +124,31 @@ def test_kkt_solve_vs_direct_ldl(hip, oracle, with_P):
     got, its = hip.kkt_solve(A, P, diag_r, rhs, tol=1e-13)
     assert its > 0
     np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
+
+
+def test_kkt_solve_large_layouts_agree(hip, monkeypatch):
+    """the fused CG epilogues (K1/K2/K1'/K2' + P) on the three matrix layouts: column-sorted passes, L2-blocked
+    slabs and plain CSR-stream solve the same KKT system to the same answer (the CSR-stream path is the one
+    checked against the oracle's LDL above; partial sums are partitioned differently => tolerance, not bits)"""
+    rng = np.random.default_rng(31)
+    m, n = 330000, 280000
+    A = pg.random_sparse(m, n, 6, rng)
+    B = pg.random_sparse(n, n, 2, rng)
+    P = sparse.triu(B + B.T + sparse.eye(n) * 12.0, format="csc")  # diagonally dominant => PSD
+    P.sort_indices()
+    diag_r = np.concatenate([np.full(n, 1e-2), np.full(1000, 0.05), np.full(m - 1000, 8.0)])
+    rhs = rng.standard_normal(n + m)
+    sols = {}
+    for name, env in (("cs", {}), ("slab", {"SCS_HIP_CS": "0"}), ("stream", {"SCS_HIP_SLAB": "0"})):
+        for k in ("SCS_HIP_CS", "SCS_HIP_SLAB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sols[name], its = hip.kkt_solve(A, P, diag_r, rhs, tol=1e-12)
+        assert its > 0
+    scl = np.abs(sols["stream"]).max()
+    np.testing.assert_allclose(sols["cs"], sols["stream"], rtol=0, atol=1e-9 * scl)
+    np.testing.assert_allclose(sols["slab"], sols["stream"], rtol=0, atol=1e-9 * scl)
 
 
 STG = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False)
@@ -467,9 +495,12 @@ def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):
 
 
 # ---- scs_init's matrix work on the device (setup_dev.hpp) vs the host builders ----
-def test_device_setup_matches_host_setup(hip, oracle, monkeypatch):
-    """CSC -> CSR transposition and the L2-blocked slab layout built on the device must give the same matrices,
-    entry for entry, as the host builders: identical SpMV bits and identical solves."""
+@pytest.mark.parametrize("cs", ["1", "0"], ids=["column-sorted", "slab"])
+def test_device_setup_matches_host_setup(hip, oracle, monkeypatch, cs):
+    """CSC -> CSR transposition and the large-matrix layouts (column-sorted passes; SCS_HIP_CS=0: L2-blocked slabs)
+    built on the device must give the same matrices, entry for entry, as the host builders: identical SpMV bits and
+    identical solves."""
+    monkeypatch.setenv("SCS_HIP_CS", cs)
     rng = np.random.default_rng(5)
     A = pg.random_sparse(300000, 270000, 7, rng)  # wide enough for the slab layout in both orientations
     x = rng.standard_normal(A.shape[1])
@@ -494,6 +525,29 @@ def test_device_setup_matches_host_setup(hip, oracle, monkeypatch):
                                  max_iters=iters).solve(False, None, None, None)
         for key in ("x", "y", "s"):
             np.testing.assert_array_equal(sols["host"][key], sols["device"][key], err_msg=key)
+
+
+@pytest.mark.parametrize("shape,per_col,rpt,dense", [((300000, 270000), 7, None, False), ((1100000, 400000), 3, None, False),
+                                                     ((270000, 300000), 9, "2", False), ((400000, 300000), 5, "16", False),
+                                                     ((400000, 300000), 5, "16", True)])
+def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt, dense):
+    """spmv_cs.hpp: every chunk size (rows per lane 1 .. 16), both orientations, device and host builders, against the
+    oracle's sequential loops — bit for bit.  A pattern that does not fit the format's count fields (16 rows per
+    lane: 3-bit counts; here a dense block) must fall back to the slab kernel with the same bits."""
+    rng = np.random.default_rng(23)
+    A = pg.random_sparse(*shape, per_col, rng)
+    if dense:  # 40 nonzeros of one row inside one pass: more than a 3-bit count holds
+        ii, jj = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
+        A = (A + sparse.csc_matrix((rng.standard_normal(1600), (ii.ravel(), jj.ravel())), shape=shape)).tocsc()
+        A.sort_indices()
+    if rpt:
+        monkeypatch.setenv("SCS_HIP_CS_RPT", rpt)
+    x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
+    ref = (oracle.spmv(A, x), oracle.spmv(A, y, trans=True))
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SCS_HIP_SETUP", mode)
+        np.testing.assert_array_equal(hip.spmv(A, x), ref[0], err_msg=mode)
+        np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), ref[1], err_msg=mode)
 
 
 def test_device_setup_long_rows_fall_back(hip, oracle):

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../scs-python_amd/csrc/spmv.hpp"
+#include "../scs-python_amd/csrc/spmv_cs.hpp"
 
 using namespace scship;
 typedef int nt_i4 __attribute__((ext_vector_type(4)));
@@ -44,7 +45,39 @@ __device__ __forceinline__ int touch_lines(const void *base, long bytes, int lan
   return acc;
 }
 
-template <int THREADS, int RPT, int NQ, class Epi, int ABL = 0, int PF = 0>
+// ------------------------------------------------------------------ experiment: scalar-cache prefetcher
+// A separate tiny kernel (one wave per workgroup) on a second stream touches the val / col / roff lines of the
+// slab format with SCALAR loads (s_load_dword: scalar data cache -> L2 -> HBM; not the TA/TCP path the compute
+// waves gather through), in the order the compute workgroups consume them, so that their streaming loads hit
+// L2 / Infinity Cache instead of waiting for HBM in the in-order vector-memory return queue.
+__device__ __forceinline__ void s_touch16(const char *p) {  // 15 lines (128 B apart) in flight, then wait
+  unsigned d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14;
+  asm volatile(
+      "s_load_dword %0, %15, 0x0\n s_load_dword %1, %15, 0x80\n s_load_dword %2, %15, 0x100\n s_load_dword %3, %15, 0x180\n"
+      "s_load_dword %4, %15, 0x200\n s_load_dword %5, %15, 0x280\n s_load_dword %6, %15, 0x300\n s_load_dword %7, %15, 0x380\n"
+      "s_load_dword %8, %15, 0x400\n s_load_dword %9, %15, 0x480\n s_load_dword %10, %15, 0x500\n s_load_dword %11, %15, 0x580\n"
+      "s_load_dword %12, %15, 0x600\n s_load_dword %13, %15, 0x680\n s_load_dword %14, %15, 0x700\n s_waitcnt lgkmcnt(0)"
+      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
+        "=&s"(d10), "=&s"(d11), "=&s"(d12), "=&s"(d13), "=&s"(d14)
+      : "s"(p)
+      : "memory");
+}
+__device__ __forceinline__ void s_touch_range(const void *base, long bytes, int part, int nparts) {
+  // lines [0, nl) of the range split into nparts contiguous shares; batches of 15 lines (tail over-reads < 2 KB:
+  // callers pad their buffers)
+  const char *b = reinterpret_cast<const char *>(base);
+  const long nl = (bytes + 127) >> 7;
+  const long per = (nl + nparts - 1) / nparts;
+  long l0 = per * part, l1 = l0 + per < nl ? l0 + per : nl;
+  for (long l = l0; l < l1; l += 15) {
+    const char *p = b + (l << 7);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) & 0xffffffffu));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) >> 32));
+    s_touch16(reinterpret_cast<const char *>(((unsigned long)hi << 32) | lo));
+  }
+}
+
+template <int THREADS, int RPT, int NQ, class Epi, int ABL = 0, int PF = 0, bool SPF = false>
 __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const double *__restrict__ x, Epi epi) {
   constexpr int R = THREADS * RPT;
   constexpr int STAGE = 4 * NQ * THREADS;
@@ -58,12 +91,23 @@ __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const
     int sink = 0;
     for (int s = -1; s < A.S; ++s) {
       int t0 = 0, t1 = 0, t2 = 0;
-      if (s + 2 < A.S) {
+      if (SPF) {
+        const int part = lane >> 6;
+        if (s + 2 < A.S) {
+          const int q0 = A.segptr[sg + s + 2], q1 = A.segptr[sg + s + 3];
+          s_touch_range(A.val + q0, (long)(q1 - q0) * 8, part, PF);
+          s_touch_range(A.roff + (sg + s + 2) * (R + kSlabRoffPad), (long)(R + 1) * 2, part, PF);
+        }
+        if (s + 3 < A.S) {
+          const int q0 = A.segptr[sg + s + 3], q1 = A.segptr[sg + s + 4];
+          s_touch_range(A.col + q0, (long)(q1 - q0) * 4, part, PF);
+        }
+      } else if (s + 2 < A.S) {
         const int q0 = A.segptr[sg + s + 2], q1 = A.segptr[sg + s + 3];
         t0 = touch_lines(A.val + q0, (long)(q1 - q0) * 8, lane, 64 * PF);
         t1 = touch_lines(A.roff + (sg + s + 2) * (R + kSlabRoffPad), (long)(R + 1) * 2, lane, 64 * PF);
       }
-      if (s + 3 < A.S) {
+      if (!SPF && s + 3 < A.S) {
         const int q0 = A.segptr[sg + s + 3], q1 = A.segptr[sg + s + 4];
         t2 = touch_lines(A.col + q0, (long)(q1 - q0) * 4, lane, 64 * PF);
       }
@@ -214,37 +258,6 @@ __global__ __launch_bounds__(THREADS + 64 * PF) void k_slab_ga(SlabView A, const
 }
 
 
-// ------------------------------------------------------------------ experiment: scalar-cache prefetcher
-// A separate tiny kernel (one wave per workgroup) on a second stream touches the val / col / roff lines of the
-// slab format with SCALAR loads (s_load_dword: scalar data cache -> L2 -> HBM; not the TA/TCP path the compute
-// waves gather through), in the order the compute workgroups consume them, so that their streaming loads hit
-// L2 / Infinity Cache instead of waiting for HBM in the in-order vector-memory return queue.
-__device__ __forceinline__ void s_touch16(const char *p) {  // 15 lines (128 B apart) in flight, then wait
-  unsigned d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14;
-  asm volatile(
-      "s_load_dword %0, %15, 0x0\n s_load_dword %1, %15, 0x80\n s_load_dword %2, %15, 0x100\n s_load_dword %3, %15, 0x180\n"
-      "s_load_dword %4, %15, 0x200\n s_load_dword %5, %15, 0x280\n s_load_dword %6, %15, 0x300\n s_load_dword %7, %15, 0x380\n"
-      "s_load_dword %8, %15, 0x400\n s_load_dword %9, %15, 0x480\n s_load_dword %10, %15, 0x500\n s_load_dword %11, %15, 0x580\n"
-      "s_load_dword %12, %15, 0x600\n s_load_dword %13, %15, 0x680\n s_load_dword %14, %15, 0x700\n s_waitcnt lgkmcnt(0)"
-      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
-        "=&s"(d10), "=&s"(d11), "=&s"(d12), "=&s"(d13), "=&s"(d14)
-      : "s"(p)
-      : "memory");
-}
-__device__ __forceinline__ void s_touch_range(const void *base, long bytes, int part, int nparts) {
-  // lines [0, nl) of the range split into nparts contiguous shares; batches of 15 lines (tail over-reads < 2 KB:
-  // callers pad their buffers)
-  const char *b = reinterpret_cast<const char *>(base);
-  const long nl = (bytes + 127) >> 7;
-  const long per = (nl + nparts - 1) / nparts;
-  long l0 = per * part, l1 = l0 + per < nl ? l0 + per : nl;
-  for (long l = l0; l < l1; l += 15) {
-    const char *p = b + (l << 7);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) & 0xffffffffu));
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<unsigned long>(p) >> 32));
-    s_touch16(reinterpret_cast<const char *>(((unsigned long)hi << 32) | lo));
-  }
-}
 // workgroup w (one wave): XCD x = w % 8, k = w / 8; chunk c = 8 * (k / WPC) + x, share k % WPC of every segment of c
 __global__ __launch_bounds__(64) void k_pf_scalar(SlabView A, int WPC, int what) {
   const int w = blockIdx.x, xcd = w & 7, k = w >> 3;
@@ -321,16 +334,16 @@ static long mismatches(const double *dy, const std::vector<double> &ref) {
   return bad;
 }
 
-template <int THREADS, int RPT, int NQ, int ABL = 0, int PF = 0>
+template <int THREADS, int RPT, int NQ, int ABL = 0, int PF = 0, bool SPF = false>
 static void run_ga(const char *tag, const Csr &M, const double *dx, double *dy, const std::vector<double> &ref) {
   HostSlab hs;
   if (!build_slab(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hs, nullptr, THREADS * RPT)) { std::printf("  %-34s build failed\n", tag); return; }
   if (hs.R != THREADS * RPT) { std::printf("  %-34s R mismatch %d\n", tag, hs.R); return; }
   if (hs.max_seg > 4 * NQ * THREADS) { std::printf("  %-34s max_seg %d > stage %d\n", tag, hs.max_seg, 4 * NQ * THREADS); return; }
-  hs.roff.push_back(0);  // the dword read of the very last row's {start,end} pair stays in bounds
+  for (int i = 0; i < 1024; ++i) { hs.col.push_back(0); hs.val.push_back(0.); hs.roff.push_back(0); }  // over-read pad; the dword read of the very last row's {start,end} pair stays in bounds
   DevSlab d = upload_slab(hs);
   HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
-  auto launch = [&] { hipLaunchKernelGGL((k_slab_ga<THREADS, RPT, NQ, EpiStore, ABL, PF>), dim3(hs.nchunks), dim3(THREADS + 64 * PF), 0, 0, d.v, dx, EpiStore{dy, 0}); };
+  auto launch = [&] { hipLaunchKernelGGL((k_slab_ga<THREADS, RPT, NQ, EpiStore, ABL, PF, SPF>), dim3(hs.nchunks), dim3(THREADS + 64 * PF), 0, 0, d.v, dx, EpiStore{dy, 0}); };
   const double us = time_us(launch, 20);
   std::printf("  %-34s R=%5d S=%2d wgs=%4d max_seg=%5d : %7.1f us  mismatches %ld\n", tag, hs.R, hs.S, hs.nchunks, hs.max_seg, us,
               mismatches(dy, ref));
@@ -389,6 +402,23 @@ static void run_base_pf(const char *tag, int rpt, int wpc, int what, const Csr &
   free_slab(d);
 }
 
+static void run_cs(const char *tag, int rpt, const Csr &M, const double *dx, double *dy, const std::vector<double> &ref) {
+  HostCs hc;
+  if (!build_cs(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hc, rpt)) { std::printf("  %-34s build failed\n", tag); return; }
+  int *passptr = to_dev(hc.passptr);
+  int2 *pinfo = to_dev(hc.pinfo);
+  unsigned *idx = to_dev(hc.idx);
+  double *val = to_dev(hc.val);
+  unsigned long long *meta = to_dev(hc.meta);
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass};
+  HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+  auto launch = [&] { launch_spmv_cs(v, dx, EpiStore{dy, 0}, nullptr, 0, nullptr); };
+  const double us = time_us(launch, 20);
+  std::printf("  %-34s R=%5d wgs=%4d passes=%5d (%.1f%% padding) : %7.1f us  mismatches %ld\n", tag, hc.R, hc.nchunks, hc.npass,
+              100. * ((double)hc.npass * kCsPass / M.rowptr[M.rows] - 1.), us, mismatches(dy, ref));
+  hipFree(passptr); hipFree(pinfo); hipFree(idx); hipFree(val); hipFree(meta);
+}
+
 static void bench_matrix(const char *name, const Csr &M) {
   std::printf("%s: %d x %d, nnz %d\n", name, M.rows, M.cols, M.rowptr[M.rows]);
   std::vector<double> x(M.cols), ref(M.rows);
@@ -404,6 +434,24 @@ static void bench_matrix(const char *name, const Csr &M) {
   HIP_CHECK(hipMalloc(&dy, M.rows * sizeof(double)));
   run_base("shipped k_spmv_slab rpt16", 16, M, dx, dy, ref);
   run_base("shipped k_spmv_slab rpt8", 8, M, dx, dy, ref);
+  if (getenv("LAB_CS")) {
+    for (int rpt : {2, 4, 8, 16}) run_cs("column-sorted passes", rpt, M, dx, dy, ref);
+    hipFree(dx); hipFree(dy);
+    return;
+  }
+  if (getenv("LAB_SPF")) {
+    run_ga<256, 8, 3>("gather-ahead 256x8 nq3", M, dx, dy, ref);
+    run_ga<256, 8, 3, 0, 2, true>("  + 2 scalar pf waves", M, dx, dy, ref);
+    run_ga<256, 8, 3, 0, 4, true>("  + 4 scalar pf waves", M, dx, dy, ref);
+    run_ga<512, 4, 2>("gather-ahead 512x4 nq2", M, dx, dy, ref);
+    run_ga<512, 4, 2, 0, 2, true>("  + 2 scalar pf waves", M, dx, dy, ref);
+    run_ga<512, 4, 2, 0, 4, true>("  + 4 scalar pf waves", M, dx, dy, ref);
+    run_ga<512, 4, 2, 0, 8, true>("  + 8 scalar pf waves", M, dx, dy, ref);
+    run_ga<256, 16, 6>("gather-ahead 256x16 nq6", M, dx, dy, ref);
+    run_ga<256, 16, 6, 0, 2, true>("  + 2 scalar pf waves", M, dx, dy, ref);
+    hipFree(dx); hipFree(dy);
+    return;
+  }
   if (getenv("LAB_PF")) {
     for (int rpt : {16, 8}) {
       run_base_pf("shipped + scalar pf x2 val+col", rpt, 2, 3, M, dx, dy, ref);

@@ -9,7 +9,7 @@
 //   3. k_cs_scatter  per block: bitonic sort of (chunk << 12 | position) in LDS gives the stable rank inside the
 //                    block; entries go to their place in the chunk streams {row, column, source position};
 //   4. k_cs_cut      per chunk: greedy cut into passes (<= 8192 nonzeros, < 2^19 columns wide);
-//   5. k_cs_fill     per pass: bitonic sort of (owner-lane-major row key << 13 | position) = the LDS slot of every
+//   5. k_cs_fill     per pass: bitonic sort of (cs_row_key << 13 | position) = the LDS slot of every
 //                    nonzero; writes val / idx in the lane-major quad order and the per-lane run descriptors.
 // Integer work only; the result is identical, entry for entry, to spmv_cs.hpp build_cs (the host builder).
 #pragma once
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
     unsigned k = (unsigned)RR;
     if (q < len) {
       const int rl = s_row[begin + q] - r0;
-      k = (unsigned)((rl % kCsThreads) * RPT + rl / kCsThreads);
+      k = (unsigned)cs_row_key(rl, RPT);
       atomicAdd(&cnt[k], 1);
     }
     key[q] = (k << kCsSlotBits) | (unsigned)q;
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
       val[o + sp] = 0.0;
     }
   }
-  // run descriptor of lane tid: slots before its first row = entries with key < tid * RPT
-  const unsigned want = (unsigned)(tid * RPT) << kCsSlotBits;
+  // run descriptor of lane tid: first slot of its run = entries with key < that of its first row
+  const unsigned want = (unsigned)cs_row_key(tid, RPT) << kCsSlotBits;
   int lo = -1, hi = kCsPass;  // key[lo] < want <= key[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
   unsigned long long w = (unsigned long long)hi;
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int n = cnt[tid * RPT + j];
+    const int n = cnt[cs_row_key(j * kCsThreads + tid, RPT)];
     if (n > (1 << CB) - 1) atomicExch(fail, 1);
     w |= (unsigned long long)(n & ((1 << CB) - 1)) << (16 + CB * j);
   }

@@ -12,9 +12,9 @@
 // Layout: rows are cut into chunks of R; the nonzeros of a chunk, sorted by (column, row), are cut into passes of
 // kCsPass = 8192.  A pass stores  val[8192] (fp64),  idx[8192] (uint32 = column relative to the pass's first column
 // << 13 | slot)  and  meta[1024] (uint64 per lane: first slot of the lane's run | RPT counts).  `slot` is the rank of
-// the nonzero in (owner lane, row, column) order: products are scattered to LDS by slot, then every lane sums the
-// LDS runs of its RPT rows (row = chunk * R + j * 1024 + lane: epilogue accesses are coalesced) into REGISTER
-// accumulators that live across the passes.  Passes are ascending column ranges and a run is in ascending column
+// the nonzero in (owner lane, row-of-lane j, column) order (cs_row_key): products are scattered to LDS by slot,
+// then every lane sums the LDS runs of its RPT rows (row = chunk * R + j * 1024 + lane: epilogue accesses are
+// coalesced) into REGISTER accumulators that live across the passes.  Passes are ascending column ranges and a run is in ascending column
 // order, so every row is summed in ascending-column order from 0.0 — bit-identical to the CSR-stream kernel, the
 // slab kernel and the oracle's loops.  The LDS product buffer is double-buffered: one barrier per pass.
 // Inside a block of 256 consecutive sorted nonzeros the storage order is lane-major (lane l holds sorted positions
@@ -64,6 +64,11 @@ struct HostCs {
   int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0;
 };
 
+// Slot order inside a pass: (owner lane, the lane's j-th row, column); row-local index rl = j * 1024 + lane.
+// (Measured alternative: rows of a wave interleaved — (wave, j, lane) — with a DPP prefix sum per row so that the
+// row-sum reads of neighbouring lanes are bank-conflict free: not faster, 104 vs 99 us on the K1 shape.)
+__host__ __device__ inline int cs_row_key(int rl, int rpt) { return (rl & (kCsThreads - 1)) * rpt + rl / kCsThreads; }
+
 // storage position of sorted position q inside a pass (lane-major quads inside blocks of 256)
 __host__ __device__ inline int cs_store_pos(int q) {
   const int blk = q >> 8, k = (q >> 6) & 3, lane = q & 63;
@@ -99,8 +104,7 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
       const int base = ents[e0].col;
       while ((long)ents[e1 - 1].col - base >= (1L << kCsColBits)) --e1;
       std::fill(cnt.begin(), cnt.end(), 0);
-      // key of a row: owner lane major, then its j-th row
-      auto keyof = [&](int rl) { return (rl % kCsThreads) * rpt + rl / kCsThreads; };
+      auto keyof = [&](int rl) { return cs_row_key(rl, rpt); };
       for (long e = e0; e < e1; ++e) cnt[keyof(ents[e].rl)]++;
       int acc = 0;
       for (int k = 0; k < R; ++k) { start[k] = acc; acc += cnt[k]; run[k] = 0; if ((unsigned)cnt[k] > maxcnt) return false; }
@@ -120,8 +124,8 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
         }
       }
       for (int t = 0; t < kCsThreads; ++t) {
-        unsigned long long w = (unsigned long long)start[t * rpt];
-        for (int j = 0; j < rpt; ++j) w |= (unsigned long long)cnt[t * rpt + j] << (16 + cb * j);
+        unsigned long long w = (unsigned long long)start[cs_row_key(t, rpt)];  // first slot of the lane's run
+        for (int j = 0; j < rpt; ++j) w |= (unsigned long long)cnt[cs_row_key(j * kCsThreads + t, rpt)] << (16 + cb * j);
         out.meta.push_back(w);
       }
     }
@@ -133,13 +137,32 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
   return true;
 }
 
+
+// Row sums of one pass from the LDS product buffer: m = {first slot of the lane's run | the lane's RPT counts}.
+// (Measured alternative: level by level — the L-th product of several rows as one batch of independent LDS reads,
+// +0.0 for rows without one — is not faster than the plain per-row loops: 100-102 vs 99 us on the K1 shape.)
+template <int RPT>
+__device__ __forceinline__ void cs_row_sums(const double *__restrict__ pb, unsigned long long m, double (&acc)[RPT]) {
+  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr unsigned CM = (1u << CB) - 1;
+  int o = (int)(m & 0xffff);
+  unsigned long long w = m >> 16;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int n = (int)((unsigned)w & CM);
+    w >>= CB;
+    double t = acc[j];
+    for (int k = 0; k < n; ++k) t += pb[o + k];
+    acc[j] = t;
+    o += n;
+  }
+}
+
 template <class Epi, int RPT>
 __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *__restrict__ x, Epi epi, const int *done_flag,
                                                          int *step_counter) {
   if (done_flag && *done_flag) return;
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
-  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
-  constexpr unsigned CM = (1u << CB) - 1;
   constexpr int NQ = kCsQuads;
   __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
   __shared__ double red[kCsThreads / 64];
@@ -203,17 +226,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
       }
     }
     __syncthreads();
-    int o = (int)(mc & 0xffff);
-    unsigned long long w = mc >> 16;
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-      const int n = (int)((unsigned)w & CM);
-      w >>= CB;
-      double t = acc[j];
-      for (int k = 0; k < n; ++k) t += pb[o + k];
-      acc[j] = t;
-      o += n;
-    }
+    cs_row_sums<RPT>(pb, mc, acc);
     buf ^= 1;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) { ic[i] = in[i]; va[i] = na[i]; vb[i] = nb[i]; }
@@ -239,11 +252,140 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
   }
 }
 
+
+// Gather-ahead schedule of the same pass loop (same data, same per-row order => same bits): the gathers of pass
+// g + 1 are issued right after the barrier of pass g, BEFORE its LDS row sums, and the streaming loads of pass g + 2
+// behind them, so the vector-memory pipe works through the LDS / barrier phase and every streamed pass has a whole
+// pass of time to arrive.  Two register sets alternate (the loop is unrolled by two: no copies of in-flight loads).
+template <int NQ>
+struct CsSet {
+  uint4 ic[NQ];
+  double2 va[NQ], vb[NQ];
+  unsigned long long meta;
+  int2 pi;
+};
+
+// ABL (tools/slab_lab.hip ablations, results intentionally wrong): 1 = gathers folded into a 2 KB table,
+// 2 = no LDS row sums, 3 = no LDS traffic at all, 4 = no streamed values (idx only)
+template <class Epi, int RPT, int ABL = 0>
+__global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const double *__restrict__ x, Epi epi, const int *done_flag,
+                                                            int *step_counter) {
+  if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
+  constexpr int NQ = kCsQuads;
+  __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
+  __shared__ double red[kCsThreads / 64];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM], acc[RPT];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sums[i] = 0.;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) maxs[i] = 0.;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) acc[j] = 0.;
+  const int g0 = A.passptr[c], g1 = A.passptr[c + 1];
+  CsSet<NQ> S0, S1;
+  double xg[NQ][4];
+  auto load = [&](int g, CsSet<NQ> &S) {
+    const uint4 *i4 = reinterpret_cast<const uint4 *>(A.idx + (size_t)g * kCsPass);
+    const double2 *v2 = reinterpret_cast<const double2 *>(A.val + (size_t)g * kCsPass);
+    S.pi = A.pinfo[g];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * kCsThreads;
+      if (((q >> 6) << 8) < S.pi.y) {
+        S.ic[i] = i4[q];
+        if (ABL == 4) { S.va[i] = double2{1., 1.}; S.vb[i] = double2{1., 1.}; }
+        else { S.va[i] = v2[2 * q]; S.vb[i] = v2[2 * q + 1]; }
+      }
+    }
+    S.meta = A.meta[(size_t)g * kCsThreads + tid];
+  };
+  auto gather = [&](const CsSet<NQ> &S) {
+    const double *xb = x + S.pi.x;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if ((((tid + i * kCsThreads) >> 6) << 8) < S.pi.y) {
+        constexpr unsigned GM = ABL == 1 ? 255u : 0xffffffffu;
+        xg[i][0] = xb[(S.ic[i].x >> kCsSlotBits) & GM];
+        xg[i][1] = xb[(S.ic[i].y >> kCsSlotBits) & GM];
+        xg[i][2] = xb[(S.ic[i].z >> kCsSlotBits) & GM];
+        xg[i][3] = xb[(S.ic[i].w >> kCsSlotBits) & GM];
+      }
+    }
+  };
+  // pass g lives in X (its gathers are in flight), pass g + 1 streams into Y
+  auto step = [&](int g, CsSet<NQ> &X, CsSet<NQ> &Y, int buf) {
+    double *pb = prod[buf];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if ((((tid + i * kCsThreads) >> 6) << 8) < X.pi.y) {
+        if (ABL == 3) {
+          acc[0] += X.va[i].x * xg[i][0] + X.va[i].y * xg[i][1] + X.vb[i].x * xg[i][2] + X.vb[i].y * xg[i][3];
+        } else {
+          pb[X.ic[i].x & (kCsPass - 1)] = X.va[i].x * xg[i][0];
+          pb[X.ic[i].y & (kCsPass - 1)] = X.va[i].y * xg[i][1];
+          pb[X.ic[i].z & (kCsPass - 1)] = X.vb[i].x * xg[i][2];
+          pb[X.ic[i].w & (kCsPass - 1)] = X.vb[i].y * xg[i][3];
+        }
+      }
+    }
+    const unsigned long long mc = X.meta;
+    __syncthreads();
+    if (g + 1 < g1) gather(Y);
+    if (g + 2 < g1) load(g + 2, X);
+    if (ABL == 2 || ABL == 3) { acc[0] += (double)(mc & 0xffffff); return; }
+    cs_row_sums<RPT>(pb, mc, acc);
+  };
+  if (g0 < g1) {
+    load(g0, S0);
+    gather(S0);
+    if (g0 + 1 < g1) load(g0 + 1, S1);
+  }
+  for (int g = g0; g < g1; g += 2) {
+    step(g, S0, S1, 0);
+    if (g + 1 < g1) step(g + 1, S1, S0, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = c * A.R + j * kCsThreads + tid;
+    if (r < A.rows) epi(r, acc[j], sums, maxs);
+  }
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+#pragma unroll
+    for (int i = 0; i < Epi::kSums; ++i) {
+      const double t = block_sum<kCsThreads>(sums[i], red);
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + c] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < Epi::kMaxs; ++i) {
+      const double t = block_max<kCsThreads>(maxs[i], red);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + c] = t;
+    }
+  }
+}
+
+inline int cs_schedule() {  // 1 (default) = gather-ahead (k_spmv_cs_ga); 0 = gathers, then next pass's stream (k_spmv_cs)
+  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 template <class Epi>
 inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                            int *step_counter) {
   if (A.nchunks <= 0) return;
   const dim3 g(A.nchunks), b(kCsThreads);
+  if (cs_schedule() == 1) {
+    switch (A.R / kCsThreads) {
+      case 1: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 2: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 4: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 4>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 8: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 8>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      default: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 16>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    }
+    return;
+  }
   switch (A.R / kCsThreads) {
     case 1: hipLaunchKernelGGL((k_spmv_cs<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
     case 2: hipLaunchKernelGGL((k_spmv_cs<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

@@ -402,6 +402,22 @@ static void run_base_pf(const char *tag, int rpt, int wpc, int what, const Csr &
   free_slab(d);
 }
 
+template <int RPT, int ABL>
+static void run_cs_abl(const char *tag, const Csr &M, const double *dx, double *dy) {
+  HostCs hc;
+  if (!build_cs(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hc, RPT)) { std::printf("  %-34s build failed\n", tag); return; }
+  int *passptr = to_dev(hc.passptr);
+  int2 *pinfo = to_dev(hc.pinfo);
+  unsigned *idx = to_dev(hc.idx);
+  double *val = to_dev(hc.val);
+  unsigned long long *meta = to_dev(hc.meta);
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass};
+  auto launch = [&] { hipLaunchKernelGGL((k_spmv_cs_ga<EpiStore, RPT, ABL>), dim3(hc.nchunks), dim3(kCsThreads), 0, 0, v, dx, EpiStore{dy, 0}, nullptr, nullptr); };
+  const double us = time_us(launch, 20);
+  std::printf("  %-44s R=%5d : %7.1f us\n", tag, hc.R, us);
+  hipFree(passptr); hipFree(pinfo); hipFree(idx); hipFree(val); hipFree(meta);
+}
+
 static void run_cs(const char *tag, int rpt, const Csr &M, const double *dx, double *dy, const std::vector<double> &ref) {
   HostCs hc;
   if (!build_cs(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hc, rpt)) { std::printf("  %-34s build failed\n", tag); return; }
@@ -434,8 +450,25 @@ static void bench_matrix(const char *name, const Csr &M) {
   HIP_CHECK(hipMalloc(&dy, M.rows * sizeof(double)));
   run_base("shipped k_spmv_slab rpt16", 16, M, dx, dy, ref);
   run_base("shipped k_spmv_slab rpt8", 8, M, dx, dy, ref);
+  if (getenv("LAB_CS_ABL")) {
+    if (M.rows > M.cols) {
+      run_cs_abl<8, 0>("cs gather-ahead rpt8", M, dx, dy);
+      run_cs_abl<8, 1>("  abl1: gathers from a 2 KB table", M, dx, dy);
+      run_cs_abl<8, 2>("  abl2: no LDS row sums", M, dx, dy);
+      run_cs_abl<8, 3>("  abl3: no LDS traffic", M, dx, dy);
+      run_cs_abl<8, 4>("  abl4: values not streamed", M, dx, dy);
+    } else {
+      run_cs_abl<4, 0>("cs gather-ahead rpt4", M, dx, dy);
+      run_cs_abl<4, 1>("  abl1: gathers from a 2 KB table", M, dx, dy);
+      run_cs_abl<4, 2>("  abl2: no LDS row sums", M, dx, dy);
+      run_cs_abl<4, 3>("  abl3: no LDS traffic", M, dx, dy);
+      run_cs_abl<4, 4>("  abl4: values not streamed", M, dx, dy);
+    }
+    hipFree(dx); hipFree(dy);
+    return;
+  }
   if (getenv("LAB_CS")) {
-    for (int rpt : {2, 4, 8, 16}) run_cs("column-sorted passes", rpt, M, dx, dy, ref);
+    for (int rpt : {4, 8}) run_cs(cs_schedule() ? "column-sorted passes, gather-ahead" : "column-sorted passes", rpt, M, dx, dy, ref);
     hipFree(dx); hipFree(dy);
     return;
   }

@@ -148,8 +148,10 @@ def main():
     b2 = spmv_bytes(nnz, n, m) + 16 * n     # + R_x, p reads fused in the epilogue
     gb1 = b1 / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
     gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
-    dom = ("K1 k_spmv_slab<EpiDivR> (z = R_y^-1 A p)", b1, k1_avg, gb1) if k1_avg >= k2_avg else \
-          ("K2 k_spmv_slab<EpiGp> (Gp = A'z + R_x p)", b2, k2_avg, gb2)
+    lss = info.get("lin_sys_solver", "")
+    kname = "k_spmv_cs_ga" if "column-sorted" in lss else "k_spmv_slab" if "slab" in lss else "k_spmv_stream"
+    dom = ("K1 %s<EpiDivR> (z = R_y^-1 A p)" % kname, b1, k1_avg, gb1) if k1_avg >= k2_avg else \
+          ("K2 %s<EpiGp> (Gp = A'z + R_x p)" % kname, b2, k2_avg, gb2)
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the
     # committed rocprofv3 --pmc passes on the same matrix shape are used when the workload matches.
     traffic = None

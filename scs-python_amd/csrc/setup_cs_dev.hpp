@@ -193,15 +193,15 @@ struct DeviceCs {
   DevBuf<unsigned> idx;
   DevBuf<double> val;
   DevBuf<unsigned long long> meta;
-  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0;
   bool ok = false;
   void release() {
     passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release();
     ok = false;
   }
-  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass}; }
+  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt}; }
   void from_host(const HostCs &h, hipStream_t s) {
-    rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass;
+    rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass; rpt = h.rpt;
     passptr.upload(h.passptr.data(), h.passptr.size(), s);
     pinfo.upload(h.pinfo.data(), h.pinfo.size(), s);
     idx.upload(h.idx.data(), h.idx.size(), s);
@@ -215,8 +215,7 @@ struct DeviceCs {
   bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s) {
     release();
     rows = rows_; cols = cols_;
-    const int rpt = cs_pick_rpt(rows);
-    R = kCsThreads * rpt;
+    cs_pick_geometry(rows, R, rpt);
     nchunks = (rows + R - 1) / R;
     const int nblocks = (int)((nnz + kCsBlock - 1) / kCsBlock);
     if (nnz <= 0 || nchunks > kCsMaxChunks || (long)nchunks * nblocks > (long)kScanTile * kScanTile || nnz > 2000000000L) return false;

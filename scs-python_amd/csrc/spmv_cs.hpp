@@ -42,17 +42,23 @@ struct CsView {
   const unsigned *idx;         // npass * kCsPass
   const double *val;           // npass * kCsPass
   const unsigned long long *meta;  // npass * kCsThreads
-  int rows, cols, nchunks, R, npass;
+  int rows, cols, nchunks, R, npass, rpt;  // R rows per chunk (<= 1024 * rpt), rpt = accumulators per lane (1, 2, 4, 8, 16)
 };
 
 __host__ __device__ inline int cs_count_bits(int rpt) { return 48 / rpt < 13 ? 48 / rpt : 13; }
 
-inline int cs_pick_rpt(int rows) {
-  const char *e = getenv("SCS_HIP_CS_RPT");  // experiments only
-  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return v; }
-  int rpt = 1;
-  while (rpt < 16 && (long)kCsTargetWgs * kCsThreads * rpt < rows) rpt *= 2;
-  return rpt;
+// Chunk geometry: R rows per workgroup so that the launch is ONE wave of workgroups on the 256 CUs (every CU busy,
+// as many rows per CU as possible: the distinct lines per gather instruction fall with R), R a multiple of 64;
+// rpt = the power of two >= R / 1024.  More than 256 * 16384 rows: R = 16384 and several rounds of workgroups.
+inline void cs_pick_geometry(int rows, int &R, int &rpt) {
+  const char *e = getenv("SCS_HIP_CS_RPT");  // experiments / tests: full chunks of 1024 * rpt rows
+  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { rpt = v; R = kCsThreads * v; return; } }
+  long r = ((long)rows + kCsTargetWgs - 1) / kCsTargetWgs;
+  r = std::max(64L, (r + 63) / 64 * 64);
+  r = std::min<long>(r, 16L * kCsThreads);
+  rpt = 1;
+  while ((long)kCsThreads * rpt < r) rpt *= 2;
+  R = (int)r;
 }
 
 struct HostCs {
@@ -61,7 +67,7 @@ struct HostCs {
   std::vector<unsigned> idx;
   std::vector<double> val;
   std::vector<unsigned long long> meta;
-  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0;
 };
 
 // Slot order inside a pass: (owner lane, the lane's j-th row, column); row-local index rl = j * 1024 + lane.
@@ -79,14 +85,17 @@ __host__ __device__ inline int cs_store_pos(int q) {
 // format's bit fields (a pass wider than 2^19 columns, or more nonzeros of one row in one pass than the count
 // field holds): the caller keeps the slab / CSR-stream layout.
 inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0) {
-  const int rpt = force_rpt > 0 ? force_rpt : cs_pick_rpt(rows);
-  const int R = kCsThreads * rpt, nchunks = (rows + R - 1) / R;
+  int R, rpt;
+  cs_pick_geometry(rows, R, rpt);
+  if (force_rpt > 0) { rpt = force_rpt; R = kCsThreads * rpt; }
+  const int nchunks = (rows + R - 1) / R;
   const int cb = cs_count_bits(rpt);
   const unsigned maxcnt = (1u << cb) - 1;
-  out.rows = rows; out.cols = cols; out.R = R; out.nchunks = nchunks;
+  out.rows = rows; out.cols = cols; out.R = R; out.rpt = rpt; out.nchunks = nchunks;
   out.passptr.assign(nchunks + 1, 0);
   out.pinfo.clear(); out.idx.clear(); out.val.clear(); out.meta.clear();
-  std::vector<int> cnt(R), start(R), run(R);
+  const int RK = kCsThreads * rpt;  // row keys: lane * rpt + j
+  std::vector<int> cnt(RK), start(RK), run(RK);
   out.passptr[0] = 0;
   for (int c = 0; c < nchunks; ++c) {
     const int r0 = c * R, r1 = std::min(rows, r0 + R);
@@ -107,7 +116,7 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
       auto keyof = [&](int rl) { return cs_row_key(rl, rpt); };
       for (long e = e0; e < e1; ++e) cnt[keyof(ents[e].rl)]++;
       int acc = 0;
-      for (int k = 0; k < R; ++k) { start[k] = acc; acc += cnt[k]; run[k] = 0; if ((unsigned)cnt[k] > maxcnt) return false; }
+      for (int k = 0; k < RK; ++k) { start[k] = acc; acc += cnt[k]; run[k] = 0; if ((unsigned)cnt[k] > maxcnt) return false; }
       const size_t o = out.val.size();
       out.val.resize(o + kCsPass, 0.0);
       out.idx.resize(o + kCsPass, 0u);
@@ -235,8 +244,8 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int r = c * A.R + j * kCsThreads + tid;
-    if (r < A.rows) epi(r, acc[j], sums, maxs);
+    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
+    if (rl < A.R && r < A.rows) epi(r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
@@ -349,8 +358,8 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int r = c * A.R + j * kCsThreads + tid;
-    if (r < A.rows) epi(r, acc[j], sums, maxs);
+    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
+    if (rl < A.R && r < A.rows) epi(r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
@@ -377,7 +386,7 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
   if (A.nchunks <= 0) return;
   const dim3 g(A.nchunks), b(kCsThreads);
   if (cs_schedule() == 1) {
-    switch (A.R / kCsThreads) {
+    switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
       case 2: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
       case 4: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 4>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
@@ -386,7 +395,7 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
     }
     return;
   }
-  switch (A.R / kCsThreads) {
+  switch (A.rpt) {
     case 1: hipLaunchKernelGGL((k_spmv_cs<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
     case 2: hipLaunchKernelGGL((k_spmv_cs<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
     case 4: hipLaunchKernelGGL((k_spmv_cs<Epi, 4>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

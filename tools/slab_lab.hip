@@ -411,7 +411,7 @@ static void run_cs_abl(const char *tag, const Csr &M, const double *dx, double *
   unsigned *idx = to_dev(hc.idx);
   double *val = to_dev(hc.val);
   unsigned long long *meta = to_dev(hc.meta);
-  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass};
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt};
   auto launch = [&] { hipLaunchKernelGGL((k_spmv_cs_ga<EpiStore, RPT, ABL>), dim3(hc.nchunks), dim3(kCsThreads), 0, 0, v, dx, EpiStore{dy, 0}, nullptr, nullptr); };
   const double us = time_us(launch, 20);
   std::printf("  %-44s R=%5d : %7.1f us\n", tag, hc.R, us);
@@ -426,7 +426,7 @@ static void run_cs(const char *tag, int rpt, const Csr &M, const double *dx, dou
   unsigned *idx = to_dev(hc.idx);
   double *val = to_dev(hc.val);
   unsigned long long *meta = to_dev(hc.meta);
-  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass};
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt};
   HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
   auto launch = [&] { launch_spmv_cs(v, dx, EpiStore{dy, 0}, nullptr, 0, nullptr); };
   const double us = time_us(launch, 20);
@@ -468,7 +468,7 @@ static void bench_matrix(const char *name, const Csr &M) {
     return;
   }
   if (getenv("LAB_CS")) {
-    for (int rpt : {4, 8}) run_cs(cs_schedule() ? "column-sorted passes, gather-ahead" : "column-sorted passes", rpt, M, dx, dy, ref);
+    for (int rpt : {4, 8, 0}) run_cs(cs_schedule() ? "column-sorted passes, gather-ahead" : "column-sorted passes", rpt, M, dx, dy, ref);
     hipFree(dx); hipFree(dy);
     return;
   }

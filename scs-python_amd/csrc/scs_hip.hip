@@ -65,13 +65,13 @@ struct DeviceCsr {
   bool build_cs_dev(const DeviceCsr &T, hipStream_t s) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
-    if (!cs_enabled() || !slab_wanted(rows, cols) || (env && env[0] == '0')) return false;
+    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     return cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s);
   }
   bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
-    if (!cs_enabled() || !slab_wanted(rows, cols) || (env && env[0] == '0')) return false;
+    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
     if (!build_cs(rp, ci, v, rows, cols, h)) return false;
     cs.from_host(h, s);
@@ -1319,7 +1319,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   if (host_build) {  // SCS_HIP_SETUP=host: the column-sorted copies from the host builder, on the equilibrated values
     std::vector<double> hv;
     auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci) {
-      if (!slab_wanted(M.rows, M.cols)) return;
+      if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
       hv.resize((size_t)M.nnz);
       M.val.download(hv.data(), (size_t)M.nnz, s);
       HIP_CHECK(hipStreamSynchronize(s));
@@ -1840,12 +1840,12 @@ static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hip
   if (transpose) {
     M.upload(A->n, A->m, A->p, A->i, A->x, s);
     if (host) { M.build_cs_host(A->p, A->i, A->x, s); return; }
-    if (!slab_wanted(M.rows, M.cols)) return;
+    if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/false);
   } else {
     M.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s);
     if (host) { M.build_cs_host(ar.rowptr.data(), ar.col.data(), ar.val.data(), s); return; }
-    if (!slab_wanted(M.rows, M.cols)) return;
+    if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->n, A->m, A->p, A->i, A->x, s, /*allow_slab=*/false);
   }
   M.build_cs_dev(T, s);

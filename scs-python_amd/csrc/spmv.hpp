@@ -318,6 +318,14 @@ inline int slab_pick_rows(int rows) {
   return 256 * rpt;
 }
 inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20) && rows >= 65536; }
+// The column-sorted pass layout (spmv_cs.hpp) pays as soon as there is a pass of nonzeros for most CUs — whether or
+// not the gather vector fits L2 (what it saves is L2 -> L1 line traffic): measured crossover on LP+SOC problems with
+// 10 nonzeros per row at nnz ~ 1e6 (0.240 vs 0.245 ms/iter), -10 % per iteration at nnz = 2e6, -12 % at 4e6.
+inline bool cs_wanted(int rows, int cols, long nnz) {
+  static const long min_nnz = [] { const char *e = getenv("SCS_HIP_CS_MIN_NNZ"); return e ? atol(e) : (1L << 20); }();  // experiments
+  (void)cols;
+  return rows >= 16384 && nnz >= min_nnz;
+}
 
 // CSR -> slab format; false when a (chunk, slab) segment would overflow the uint16 offsets
 inline bool build_slab(const int *rowptr, const int *col, const double *val, int rows, int cols, HostSlab &out,

@@ -61,6 +61,12 @@ int scs_hip_set_device(int dev);
  * A is CSC with int32 indices; x,y are host pointers.  Returns 0 on success. */
 int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose);
 
+/* HOST-ONLY check of the column-sorted pass layout the large-matrix SpMV kernels read (spmv_cs.hpp): builds the
+ * layout of A (transpose=0) or A' (transpose=1) with the host builder (rows per lane `rpt` = 1, 2, 4, 8, 16, or 0 =
+ * the geometry scs_init would pick) and evaluates y += M x by walking it exactly as the kernel does (slot scatter,
+ * per-lane runs, pass order).  No GPU needed.  Returns 0, 1 if the pattern does not fit the format, -1 on error. */
+int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt);
+
 /* Time `reps` launches of the A (transpose=0) or A' (transpose=1) SpMV kernel
  * with HIP events on the launch stream; inputs already resident in HBM.
  * Returns average milliseconds per launch, <0 on error.  (bench.py roofline leg) */

@@ -1871,6 +1871,59 @@ int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans
   }
 }
 
+int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt) {
+  try {
+    set_last_error("");
+    if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid matrix");
+    HostCsr ar;
+    const int *rp = A->p, *ci = A->i;
+    const double *v = A->x;
+    int rows = A->n, cols = A->m;
+    if (!transpose) {
+      csc_to_csr(A->m, A->n, A->p, A->i, A->x, ar);
+      rp = ar.rowptr.data(); ci = ar.col.data(); v = ar.val.data();
+      rows = A->m; cols = A->n;
+    }
+    HostCs h;
+    if (!build_cs(rp, ci, v, rows, cols, h, rpt)) return 1;
+    const int cb = cs_count_bits(h.rpt);
+    std::vector<double> prod(kCsPass), acc((size_t)kCsThreads * h.rpt);
+    for (int c = 0; c < h.nchunks; ++c) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int g = h.passptr[c]; g < h.passptr[c + 1]; ++g) {
+        const int2 pi = h.pinfo[g];
+        const size_t o = (size_t)g * kCsPass;
+        for (int sp = 0; sp < kCsPass; ++sp) {
+          if ((((sp >> 2) >> 6) << 8) >= pi.y) continue;  // a block of 256 holding only padding
+          const unsigned id = h.idx[o + sp];
+          prod[id & (kCsPass - 1)] = h.val[o + sp] * x[pi.x + (int)(id >> kCsSlotBits)];
+        }
+        for (int t = 0; t < kCsThreads; ++t) {
+          const unsigned long long mw = h.meta[(size_t)g * kCsThreads + t];
+          int off = (int)(mw & 0xffff);
+          unsigned long long w = mw >> 16;
+          for (int j = 0; j < h.rpt; ++j) {
+            const int n = (int)(w & ((1ull << cb) - 1));
+            w >>= cb;
+            double s = acc[(size_t)j * kCsThreads + t];
+            for (int k = 0; k < n; ++k) s += prod[off + k];
+            acc[(size_t)j * kCsThreads + t] = s;
+            off += n;
+          }
+        }
+      }
+      for (int rl = 0; rl < h.R; ++rl) {
+        const long r = (long)c * h.R + rl;
+        if (r < rows) y[r] += acc[rl];
+      }
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
 double scs_hip_spmv_bench(const ScsMatrix *A, int transpose, int reps) {
   try {
     set_last_error("");

@@ -1,0 +1,66 @@
+"""CPU tests of the column-sorted pass layout (scs-python_amd/csrc/spmv_cs.hpp) that the large-matrix SpMV kernels
+K1/K2 read: the host builder + a host walk of the layout in the kernel's order (scs_hip_cs_layout_host_spmv, no GPU)
+must reproduce the oracle's sequential per-row sums bit for bit — every chunk geometry, ragged and empty rows,
+padding passes, patterns the bit fields cannot hold."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import problem_gen as pg
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from scs import _scs_hip
+    return _scs_hip
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import scs_oracle
+    return scs_oracle
+
+
+@pytest.mark.parametrize("shape,per_col,rpt", [
+    ((3000, 1700), 6, 0), ((3000, 1700), 6, 1), ((70000, 20000), 5, 0), ((70000, 20000), 5, 2),
+    ((40000, 90000), 3, 4), ((20000, 30000), 9, 8), ((33000, 9000), 4, 16), ((100, 5), 2, 0),
+])
+def test_layout_walk_matches_oracle_bits(hip, oracle, shape, per_col, rpt):
+    rng = np.random.default_rng(41)
+    A = pg.random_sparse(*shape, per_col, rng)
+    x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
+    got = hip.cs_layout_host_spmv(A, x, rpt=rpt)
+    assert got is not None
+    np.testing.assert_array_equal(got, oracle.spmv(A, x))
+    got_t = hip.cs_layout_host_spmv(A, y, transpose=True, rpt=rpt)
+    assert got_t is not None
+    np.testing.assert_array_equal(got_t, oracle.spmv(A, y, trans=True))
+
+
+def test_layout_empty_rows_and_columns(hip, oracle):
+    rng = np.random.default_rng(3)
+    A = pg.random_sparse(5000, 4000, 2, rng).tolil()
+    A[100:900, :] = 0.0      # empty rows
+    A[:, 50:700] = 0.0       # empty columns
+    A = sparse.csc_matrix(A)
+    A.eliminate_zeros()
+    A.sort_indices()
+    x, y = rng.standard_normal(4000), rng.standard_normal(5000)
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(A, x), oracle.spmv(A, x))
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(A, y, transpose=True), oracle.spmv(A, y, trans=True))
+    Z = sparse.csc_matrix((300, 200))
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(Z, np.ones(200)), np.zeros(300))
+
+
+def test_layout_rejects_what_its_bit_fields_cannot_hold(hip):
+    rng = np.random.default_rng(5)
+    # 16 rows per lane: 3-bit counts per (row, pass) — a dense 40 x 40 block puts 40 nonzeros of a row into one pass
+    A = pg.random_sparse(40000, 30000, 4, rng)
+    ii, jj = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
+    B = (A + sparse.csc_matrix((rng.standard_normal(1600), (ii.ravel(), jj.ravel())), shape=A.shape)).tocsc()
+    B.sort_indices()
+    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=16) is None
+    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=4) is not None      # 12-bit counts hold it
+    # very wide and very sparse: every pass is cut at 2^19 columns => mostly padding => rejected
+    W = pg.random_sparse(20000, 3000000, 1, rng)
+    assert hip.cs_layout_host_spmv(W, np.ones(W.shape[1]), rpt=0) is None

@@ -63,9 +63,10 @@ int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans
 
 /* HOST-ONLY check of the column-sorted pass layout the large-matrix SpMV kernels read (spmv_cs.hpp): builds the
  * layout of A (transpose=0) or A' (transpose=1) with the host builder (rows per lane `rpt` = 1, 2, 4, 8, 16, or 0 =
- * the geometry scs_init would pick) and evaluates y += M x by walking it exactly as the kernel does (slot scatter,
- * per-lane runs, pass order).  No GPU needed.  Returns 0, 1 if the pattern does not fit the format, -1 on error. */
-int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt);
+ * the geometry scs_init would pick; `split` = 1, or 2 workgroups per row chunk as scs_init uses for A') and
+ * evaluates y += M x by walking it exactly as the kernel does (slot scatter, per-lane runs, pass order, partial sums).
+ * No GPU needed.  Returns 0, 1 if the pattern does not fit the format, -1 on error. */
+int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split);
 
 /* Time `reps` launches of the A (transpose=0) or A' (transpose=1) SpMV kernel
  * with HIP events on the launch stream; inputs already resident in HBM.

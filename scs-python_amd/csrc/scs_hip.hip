@@ -61,20 +61,44 @@ struct DeviceCsr {
     const char *e = getenv("SCS_HIP_CS");
     return !(e && e[0] == '0');
   }
-  // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays
-  bool build_cs_dev(const DeviceCsr &T, hipStream_t s) {
+  DevBuf<double> cs_part0, cs_part1;  // cs.split == 2: partial row sums (spmv.hpp EpiPartial / EpiGp::split)
+  static bool cs_split_enabled() {  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (A/B measurements)
+    const char *e = getenv("SCS_HIP_CS_SPLIT");
+    return !(e && e[0] == '0');
+  }
+  // two workgroups per row chunk pay when the chunk can be twice as tall within 8 rows per lane (6-bit counts)
+  bool cs_split_possible() const {
+    int R, rpt;
+    cs_pick_geometry(rows, R, rpt, 2);
+    return cs_split_enabled() && rpt <= 8 && !getenv("SCS_HIP_CS_RPT");
+  }
+  void cs_alloc_parts(hipStream_t s) {
+    if (cs.ok && cs.split > 1) { cs_part0.alloc_zero((size_t)rows, s); cs_part1.alloc_zero((size_t)rows, s); }
+    else { cs_part0.release(); cs_part1.release(); }
+  }
+  // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays.
+  // want_split: try two workgroups per chunk first (only for matrices whose products tolerate partial sums: A')
+  bool build_cs_dev(const DeviceCsr &T, hipStream_t s, bool want_split = false) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
-    return cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s);
+    bool ok = false;
+    if (want_split && cs_split_possible()) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 2);
+    if (!ok) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1);
+    cs_alloc_parts(s);
+    return ok;
   }
-  bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s) {
+  bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, bool want_split = false) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
-    if (!build_cs(rp, ci, v, rows, cols, h)) return false;
+    bool ok = false;
+    if (want_split && cs_split_possible()) ok = build_cs(rp, ci, v, rows, cols, h, 0, 2);
+    if (!ok) ok = build_cs(rp, ci, v, rows, cols, h, 0, 1);
+    if (!ok) return false;
     cs.from_host(h, s);
+    cs_alloc_parts(s);
     return true;
   }
   static bool host_setup() {  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
@@ -190,10 +214,10 @@ struct DeviceCsr {
     M.use_slab = has_slab;
     if (has_slab) M.slab = SlabView{s_segptr.p, s_roff.p, s_col.p, s_val.p, rows, cols, s_nchunks, s_S, s_R, s_max_seg};
     M.use_cs = cs.ok;
-    if (cs.ok) M.cs = cs.view();
+    if (cs.ok) { M.cs = cs.view(); M.part0 = cs_part0.p; M.part1 = cs_part1.p; }
     return M;
   }
-  int nwg() const { return cs.ok ? cs.nchunks : has_slab ? s_nchunks : nblk; }
+  int nwg() const { return cs.ok ? cs.nchunks * cs.split : has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
     if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)
@@ -453,10 +477,12 @@ struct ScsHipWork {
 
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
   // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
+  // second half of Gp when A' has the split layout (EpiGp::split): Gp = cg_Gp + gp2()
+  double *gp2() const { return At.cs.ok && At.cs.split > 1 ? At.cs_part1.p : nullptr; }
   void matvec(const double *x, const int *done, int *step_counter = nullptr) {
     launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, diag_r.p + n}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
-    launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, x, diag_r.p, has_P ? 1 : 0, part.p}, done, stream);
+    launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, x, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, done, stream);
   }
 
   void read_flags() {
@@ -483,7 +509,7 @@ struct ScsHipWork {
     const int nb = vb(n);
     if (warm) matvec(warm, nullptr);
     hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(kVecThreads), 0, stream, cg_b.p, cg_Gp.p, warm, cg_M.p, xout, cg_r.p, cg_p.p,
-                       n, warm ? 1 : 0, fl.p, part.p);
+                       n, warm ? 1 : 0, fl.p, part.p, (const double *)gp2());
     hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, 0, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
   }
@@ -492,7 +518,7 @@ struct ScsHipWork {
     const int nb = vb(std::max(n, yacc ? m : 0));
     matvec(cg_p.p, fl.p + F_DONE, fl.p + F_STEP);
     hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, yacc,
-                       tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p);
+                       tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
     hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
   }
   void enqueue_flag_readback() {
@@ -540,11 +566,11 @@ struct ScsHipWork {
             launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream, fl.p + F_STEP);
             HIP_CHECK(hipEventRecord(ev[1], stream));
             if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p}, fl.p + F_DONE, stream);
+            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
             HIP_CHECK(hipEventRecord(ev[2], stream));
             const int nb = vb(std::max(n, yacc ? m : 0));
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
-                               yacc, tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p);
+                               yacc, tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
             hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p,
                                fl.p);
           } else {
@@ -1312,22 +1338,23 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   if (slabs_pending) {
     // large matrices: column-sorted pass copy (spmv_cs.hpp), each built from the other orientation's CSR;
     // the L2-blocked slab copy only where the pattern does not fit that format
-    if (!w->At.build_cs_dev(w->Ar, s)) w->At.build_slab_dev(s);
+    // A' products feed the CG update, which takes Gp as the sum of two partial vectors: two workgroups per chunk
+    if (!w->At.build_cs_dev(w->Ar, s, /*want_split=*/true)) w->At.build_slab_dev(s);
     if (!w->Ar.build_cs_dev(w->At, s)) w->Ar.build_slab_dev(s);
     if (w->has_P && !w->Pf.build_cs_dev(w->Pf, s)) w->Pf.build_slab_dev(s);
   }
   if (host_build) {  // SCS_HIP_SETUP=host: the column-sorted copies from the host builder, on the equilibrated values
     std::vector<double> hv;
-    auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci) {
+    auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci, bool want_split) {
       if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
       hv.resize((size_t)M.nnz);
       M.val.download(hv.data(), (size_t)M.nnz, s);
       HIP_CHECK(hipStreamSynchronize(s));
-      M.build_cs_host(rp, ci, hv.data(), s);
+      M.build_cs_host(rp, ci, hv.data(), s, want_split);
     };
-    host_cs(w->At, d->A->p, d->A->i);
-    host_cs(w->Ar, ar.rowptr.data(), ar.col.data());
-    if (w->has_P) host_cs(w->Pf, pf.rowptr.data(), pf.col.data());
+    host_cs(w->At, d->A->p, d->A->i, true);
+    host_cs(w->Ar, ar.rowptr.data(), ar.col.data(), false);
+    if (w->has_P) host_cs(w->Pf, pf.rowptr.data(), pf.col.data(), false);
   }
   mark("column-sorted / L2-blocked copies, value refresh");
   if (w->has_P) {  // diagonal of the (scaled) P for the Jacobi preconditioner
@@ -1794,7 +1821,7 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     for (int i = 0; i < reps; ++i) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->diag_r.p + n}, nullptr, s);
     HIP_CHECK(hipEventRecord(w->ev[1], s));
     for (int i = 0; i < reps; ++i)
-      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->diag_r.p, 0, w->part.p}, nullptr, s);
+      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->diag_r.p, 0, w->part.p, w->gp2()}, nullptr, s);
     HIP_CHECK(hipEventRecord(w->ev[2], s));
     HIP_CHECK(hipEventSynchronize(w->ev[2]));
     float a = 0, b = 0;
@@ -1839,7 +1866,7 @@ static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hip
   DeviceCsr T;  // the other orientation: what the device builder of the column-sorted copy reads
   if (transpose) {
     M.upload(A->n, A->m, A->p, A->i, A->x, s);
-    if (host) { M.build_cs_host(A->p, A->i, A->x, s); return; }
+    if (host) { M.build_cs_host(A->p, A->i, A->x, s, /*want_split=*/true); return; }
     if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/false);
   } else {
@@ -1848,7 +1875,7 @@ static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hip
     if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->n, A->m, A->p, A->i, A->x, s, /*allow_slab=*/false);
   }
-  M.build_cs_dev(T, s);
+  M.build_cs_dev(T, s, /*want_split=*/transpose != 0);
 }
 
 int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose) {
@@ -1871,7 +1898,7 @@ int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans
   }
 }
 
-int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt) {
+int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split) {
   try {
     set_last_error("");
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid matrix");
@@ -1885,36 +1912,42 @@ int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_floa
       rows = A->m; cols = A->n;
     }
     HostCs h;
-    if (!build_cs(rp, ci, v, rows, cols, h, rpt)) return 1;
+    if (split != 1 && split != 2) throw std::runtime_error("split must be 1 or 2");
+    if (!build_cs(rp, ci, v, rows, cols, h, rpt, split)) return 1;
     const int cb = cs_count_bits(h.rpt);
-    std::vector<double> prod(kCsPass), acc((size_t)kCsThreads * h.rpt);
+    std::vector<double> prod(kCsPass), acc((size_t)kCsThreads * h.rpt), tot((size_t)kCsThreads * h.rpt);
     for (int c = 0; c < h.nchunks; ++c) {
-      std::fill(acc.begin(), acc.end(), 0.0);
-      for (int g = h.passptr[c]; g < h.passptr[c + 1]; ++g) {
-        const int2 pi = h.pinfo[g];
-        const size_t o = (size_t)g * kCsPass;
-        for (int sp = 0; sp < kCsPass; ++sp) {
-          if ((((sp >> 2) >> 6) << 8) >= pi.y) continue;  // a block of 256 holding only padding
-          const unsigned id = h.idx[o + sp];
-          prod[id & (kCsPass - 1)] = h.val[o + sp] * x[pi.x + (int)(id >> kCsSlotBits)];
-        }
-        for (int t = 0; t < kCsThreads; ++t) {
-          const unsigned long long mw = h.meta[(size_t)g * kCsThreads + t];
-          int off = (int)(mw & 0xffff);
-          unsigned long long w = mw >> 16;
-          for (int j = 0; j < h.rpt; ++j) {
-            const int n = (int)(w & ((1ull << cb) - 1));
-            w >>= cb;
-            double s = acc[(size_t)j * kCsThreads + t];
-            for (int k = 0; k < n; ++k) s += prod[off + k];
-            acc[(size_t)j * kCsThreads + t] = s;
-            off += n;
+      for (int part = 0; part < h.split; ++part) {  // one workgroup each; split == 2: the two partial sums are added
+        std::fill(acc.begin(), acc.end(), 0.0);
+        const size_t wg = (size_t)c * h.split + part;
+        for (int g = h.passptr[wg]; g < h.passptr[wg + 1]; ++g) {
+          const int2 pi = h.pinfo[g];
+          const size_t o = (size_t)g * kCsPass;
+          for (int sp = 0; sp < kCsPass; ++sp) {
+            if ((((sp >> 2) >> 6) << 8) >= pi.y) continue;  // a block of 256 holding only padding
+            const unsigned id = h.idx[o + sp];
+            prod[id & (kCsPass - 1)] = h.val[o + sp] * x[pi.x + (int)(id >> kCsSlotBits)];
+          }
+          for (int t = 0; t < kCsThreads; ++t) {
+            const unsigned long long mw = h.meta[(size_t)g * kCsThreads + t];
+            int off = (int)(mw & 0xffff);
+            unsigned long long w = mw >> 16;
+            for (int j = 0; j < h.rpt; ++j) {
+              const int n = (int)(w & ((1ull << cb) - 1));
+              w >>= cb;
+              double sacc = acc[(size_t)j * kCsThreads + t];
+              for (int k = 0; k < n; ++k) sacc += prod[off + k];
+              acc[(size_t)j * kCsThreads + t] = sacc;
+              off += n;
+            }
           }
         }
+        if (part == 0) tot = acc;
+        else for (size_t i = 0; i < tot.size(); ++i) tot[i] += acc[i];
       }
       for (int rl = 0; rl < h.R; ++rl) {
         const long r = (long)c * h.R + rl;
-        if (r < rows) y[r] += acc[rl];
+        if (r < rows) y[r] += tot[rl];
       }
     }
     return 0;
@@ -2011,7 +2044,7 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
       w.Pdiag.upload(pdiag.data(), n, s);
     }
     if (!DeviceCsr::host_setup()) {
-      w.At.build_cs_dev(w.Ar, s);
+      w.At.build_cs_dev(w.Ar, s, /*want_split=*/true);
       w.Ar.build_cs_dev(w.At, s);
       if (P) w.Pf.build_cs_dev(w.Pf, s);
     }

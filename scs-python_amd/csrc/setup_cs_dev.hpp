@@ -86,13 +86,21 @@ __global__ __launch_bounds__(1024) void k_cs_scatter(const int *__restrict__ tpt
   }
 }
 
-// one workgroup: passes of every chunk.  pass_info = {first stream position, nonzeros, first column, chunk}
-__global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, int nblocks, int nchunks, long nnz,
+// one workgroup: passes of every (chunk, part).  pass_info = {first stream position, nonzeros, first column, chunk}
+__global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, int nblocks, int nchunks, int split, long nnz,
                                                  const int *__restrict__ s_col, int max_pass, int *passptr, int4 *pass_info, int *fail) {
   __shared__ int sm[kScanThreads / 64];
   __shared__ int carry_sm;
-  auto cut = [&](int c, int4 *out) {  // passes of chunk c (written from out[0] on when out != nullptr)
-    const long e_begin = hoff[(size_t)c * nblocks], e_end = c + 1 < nchunks ? hoff[(size_t)(c + 1) * nblocks] : nnz;
+  auto cut = [&](int v, int4 *out) {  // passes of workgroup v = chunk * split + part (written from out[0] on when out != nullptr)
+    const int c = v / split, part = v - c * split;
+    const long c_begin = hoff[(size_t)c * nblocks], c_end = c + 1 < nchunks ? hoff[(size_t)(c + 1) * nblocks] : nnz;
+    long e_begin = c_begin, e_end = c_end;
+    if (split > 1) {  // the chunk's stream cut at (a multiple of 256 near) its middle
+      const long n = c_end - c_begin;
+      long mid = (n / 2 + 255) & ~255L;
+      if (mid > n) mid = n;
+      if (part == 0) e_end = c_begin + mid; else e_begin = c_begin + mid;
+    }
     int np = 0;
     long e0 = e_begin;
     while (e0 < e_end) {
@@ -114,22 +122,23 @@ __global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, i
   };
   if (threadIdx.x == 0) carry_sm = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < nchunks; c0 += kScanThreads) {
-    const int c = c0 + threadIdx.x;
-    const int np = c < nchunks ? cut(c, nullptr) : 0;
+  const int nwg = nchunks * split;
+  for (int v0 = 0; v0 < nwg; v0 += kScanThreads) {
+    const int v = v0 + threadIdx.x;
+    const int np = v < nwg ? cut(v, nullptr) : 0;
     int total;
     const int off = block_excl_scan(np, sm, total);
     const int start = carry_sm + off;
-    if (c < nchunks) {
-      passptr[c] = start;
-      if (start + np <= max_pass) cut(c, pass_info + start);
+    if (v < nwg) {
+      passptr[v] = start;
+      if (start + np <= max_pass) cut(v, pass_info + start);
       else atomicExch(fail, 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) carry_sm += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) passptr[nchunks] = carry_sm;
+  if (threadIdx.x == 0) passptr[nwg] = carry_sm;
 }
 
 template <int RPT>
@@ -193,15 +202,15 @@ struct DeviceCs {
   DevBuf<unsigned> idx;
   DevBuf<double> val;
   DevBuf<unsigned long long> meta;
-  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0, split = 1;
   bool ok = false;
   void release() {
     passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release();
     ok = false;
   }
-  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt}; }
+  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt, split}; }
   void from_host(const HostCs &h, hipStream_t s) {
-    rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass; rpt = h.rpt;
+    rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass; rpt = h.rpt; split = h.split;
     passptr.upload(h.passptr.data(), h.passptr.size(), s);
     pinfo.upload(h.pinfo.data(), h.pinfo.size(), s);
     idx.upload(h.idx.data(), h.idx.size(), s);
@@ -212,10 +221,11 @@ struct DeviceCs {
   }
   // layout for the matrix M (rows_ x cols_) whose TRANSPOSE is the CSR (tptr, trow, tval) with cols_ rows.
   // false (and nothing kept) when the pattern does not fit the format: the caller keeps its other layouts.
-  bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s) {
+  bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s,
+                            int split_ = 1) {
     release();
-    rows = rows_; cols = cols_;
-    cs_pick_geometry(rows, R, rpt);
+    rows = rows_; cols = cols_; split = split_;
+    cs_pick_geometry(rows, R, rpt, split);
     nchunks = (rows + R - 1) / R;
     const int nblocks = (int)((nnz + kCsBlock - 1) / kCsBlock);
     if (nnz <= 0 || nchunks > kCsMaxChunks || (long)nchunks * nblocks > (long)kScanTile * kScanTile || nnz > 2000000000L) return false;
@@ -232,17 +242,17 @@ struct DeviceCs {
     hipLaunchKernelGGL(k_cs_scatter, dim3(nblocks), dim3(1024), 0, s, tptr, trow, cols, nnz, R, nchunks, nblocks, hoff.p, s_row.p,
                        s_col.p, s_src.p);
     // acceptance bound of build_cs: more passes than this means too much padding
-    const long max_pass_l = (nnz + nnz / 4) / kCsPass + nchunks + 1;
+    const long max_pass_l = (nnz + nnz / 4) / kCsPass + (long)nchunks * split + 1;
     const int max_pass = (int)std::min<long>(max_pass_l, 2000000000L / kCsPass);
     pass_info.alloc((size_t)max_pass);
-    passptr.alloc((size_t)nchunks + 1);
-    hipLaunchKernelGGL(k_cs_cut, dim3(1), dim3(kScanThreads), 0, s, hoff.p, nblocks, nchunks, nnz, s_col.p, max_pass, passptr.p,
+    passptr.alloc((size_t)nchunks * split + 1);
+    hipLaunchKernelGGL(k_cs_cut, dim3(1), dim3(kScanThreads), 0, s, hoff.p, nblocks, nchunks, split, nnz, s_col.p, max_pass, passptr.p,
                        pass_info.p, flag.p);
     int failed = 0;
-    HIP_CHECK(hipMemcpyAsync(&npass, passptr.p + nchunks, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&npass, passptr.p + (size_t)nchunks * split, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&failed, flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    if (failed || (long)npass * kCsPass > nnz + nnz / 4 + (long)nchunks * kCsPass) { release(); return false; }
+    if (failed || (long)npass * kCsPass > nnz + nnz / 4 + (long)nchunks * split * kCsPass) { release(); return false; }
     idx.alloc((size_t)npass * kCsPass);
     val.alloc((size_t)npass * kCsPass);
     meta.alloc((size_t)npass * kCsThreads);

@@ -85,6 +85,7 @@ struct EpiGp {  // Gp[r] = (Pp)[r] + s + rx[r] p[r];  partial sum of p.Gp   (CG 
   const double *p, *rx;
   int has_P;
   double *partial;
+  double *Gp2 = nullptr;  // split layouts (spmv_cs.hpp, two workgroups per row chunk): the second half's partial sums
   static constexpr int kSums = 1, kMaxs = 0;
   __device__ void operator()(int r, double s, double *sums, double *) const {
     const double pr = p[r];
@@ -93,6 +94,27 @@ struct EpiGp {  // Gp[r] = (Pp)[r] + s + rx[r] p[r];  partial sum of p.Gp   (CG 
     Gp[r] = g;
     sums[0] += pr * g;
   }
+  // Gp = Gp[] + Gp2[] is only ever read by the CG update (k_cg_update / k_cg_init), and p'Gp is linear in it: the
+  // first half carries the R_x p (+ P p) terms, the second half its raw partial sum — no combine pass
+  __device__ void split(int r, double s, int part, double *sums, double *) const {
+    const double pr = p[r];
+    if (part == 0) {
+      double g = s + rx[r] * pr;
+      if (has_P) g += Gp[r];
+      Gp[r] = g;
+      sums[0] += pr * g;
+    } else {
+      Gp2[r] = s;
+      sums[0] += pr * s;
+    }
+  }
+};
+
+struct EpiPartial {  // split layouts: raw partial row sums of the two halves (finished by k_epi_finish)
+  double *y0, *y1;
+  static constexpr int kSums = 0, kMaxs = 0;
+  __device__ void operator()(int r, double s, double *, double *) const { y0[r] = s; }
+  __device__ void split(int r, double s, int part, double *, double *) const { (part ? y1 : y0)[r] = s; }
 };
 
 // warm-started CG start, fused:  r0 = R_x (v_x - ws) - (P ws) - s  with s = A'(v_y + R_y^{-1} A ws);
@@ -570,13 +592,51 @@ struct SpmvMat {
   SlabView slab{};
   CsView cs{};
   bool use_slab = false, use_cs = false;  // use_cs wins (spmv_cs.hpp: column-sorted passes)
-  int nblk() const { return use_cs ? cs.nchunks : use_slab ? slab.nchunks : csr.nblk; }
+  double *part0 = nullptr, *part1 = nullptr;  // cs.split == 2: scratch for the partial row sums of epilogues without split()
+  int nblk() const { return use_cs ? cs.nchunks * cs.split : use_slab ? slab.nchunks : csr.nblk; }
 };
+
+// split layouts: the epilogue of a product whose functor is not linear in the row sum — rows finished from the two
+// partial vectors, gridDim.x = the number of workgroups of the product (= the stride of the reduction partials)
+template <class Epi>
+__global__ __launch_bounds__(kSpmvThreads) void k_epi_finish(const double *__restrict__ y0, const double *__restrict__ y1, int rows, Epi epi,
+                                                              const int *done_flag) {
+  if (done_flag && *done_flag) return;
+  __shared__ double red[kSpmvThreads / 64];
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sums[i] = 0.;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) maxs[i] = 0.;
+  for (long r = (long)blockIdx.x * kSpmvThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kSpmvThreads)
+    epi((int)r, y0[r] + y1[r], sums, maxs);
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+#pragma unroll
+    for (int i = 0; i < Epi::kSums; ++i) {
+      const double t = block_sum<kSpmvThreads>(sums[i], red);
+      if (threadIdx.x == 0) epi.partial[(size_t)i * gridDim.x + blockIdx.x] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < Epi::kMaxs; ++i) {
+      const double t = block_max<kSpmvThreads>(maxs[i], red);
+      if (threadIdx.x == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
 
 template <class Epi>
 inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                         int *step_counter = nullptr) {
   if (M.use_cs) {
+    if constexpr (!epi_has_split<Epi>::value) {
+      if (M.cs.split > 1) {
+        if (M.cs.nchunks <= 0) return;
+        launch_spmv_cs(M.cs, x, EpiPartial{M.part0, M.part1}, done_flag, s, step_counter);
+        hipLaunchKernelGGL(k_epi_finish<Epi>, dim3(M.nblk()), dim3(kSpmvThreads), 0, s, M.part0, M.part1, M.cs.rows, epi, done_flag);
+        return;
+      }
+    }
     launch_spmv_cs(M.cs, x, epi, done_flag, s, step_counter);
     return;
   }

@@ -24,6 +24,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -37,12 +38,13 @@ constexpr int kCsColBits = 32 - kCsSlotBits;  // a pass may span 2^19 columns
 constexpr int kCsTargetWgs = 256;             // one resident workgroup per CU
 
 struct CsView {
-  const int *passptr;          // nchunks + 1: first pass of every chunk
+  const int *passptr;          // nchunks * split + 1: first pass of every workgroup (chunk c, part j: entry c * split + j)
   const int2 *pinfo;           // per pass {first column, nonzeros (the rest of the kCsPass entries is padding)}
   const unsigned *idx;         // npass * kCsPass
   const double *val;           // npass * kCsPass
   const unsigned long long *meta;  // npass * kCsThreads
   int rows, cols, nchunks, R, npass, rpt;  // R rows per chunk (<= 1024 * rpt), rpt = accumulators per lane (1, 2, 4, 8, 16)
+  int split;                   // workgroups per chunk (1, or 2: the chunk's column-sorted stream cut in two; partial row sums)
 };
 
 __host__ __device__ inline int cs_count_bits(int rpt) { return 48 / rpt < 13 ? 48 / rpt : 13; }
@@ -50,10 +52,11 @@ __host__ __device__ inline int cs_count_bits(int rpt) { return 48 / rpt < 13 ? 4
 // Chunk geometry: R rows per workgroup so that the launch is ONE wave of workgroups on the 256 CUs (every CU busy,
 // as many rows per CU as possible: the distinct lines per gather instruction fall with R), R a multiple of 64;
 // rpt = the power of two >= R / 1024.  More than 256 * 16384 rows: R = 16384 and several rounds of workgroups.
-inline void cs_pick_geometry(int rows, int &R, int &rpt) {
+inline void cs_pick_geometry(int rows, int &R, int &rpt, int split = 1) {
   const char *e = getenv("SCS_HIP_CS_RPT");  // experiments / tests: full chunks of 1024 * rpt rows
   if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { rpt = v; R = kCsThreads * v; return; } }
-  long r = ((long)rows + kCsTargetWgs - 1) / kCsTargetWgs;
+  const int chunks = kCsTargetWgs / split;
+  long r = ((long)rows + chunks - 1) / chunks;
   r = std::max(64L, (r + 63) / 64 * 64);
   r = std::min<long>(r, 16L * kCsThreads);
   rpt = 1;
@@ -67,7 +70,7 @@ struct HostCs {
   std::vector<unsigned> idx;
   std::vector<double> val;
   std::vector<unsigned long long> meta;
-  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0;
+  int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0, split = 1;
 };
 
 // Slot order inside a pass: (owner lane, the lane's j-th row, column); row-local index rl = j * 1024 + lane.
@@ -84,15 +87,16 @@ __host__ __device__ inline int cs_store_pos(int q) {
 // Host builder (tests, lab, fallback): CSR -> column-sorted passes.  false when the pattern does not fit the
 // format's bit fields (a pass wider than 2^19 columns, or more nonzeros of one row in one pass than the count
 // field holds): the caller keeps the slab / CSR-stream layout.
-inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0) {
+inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0,
+                     int split = 1) {
   int R, rpt;
-  cs_pick_geometry(rows, R, rpt);
+  cs_pick_geometry(rows, R, rpt, split);
   if (force_rpt > 0) { rpt = force_rpt; R = kCsThreads * rpt; }
   const int nchunks = (rows + R - 1) / R;
   const int cb = cs_count_bits(rpt);
   const unsigned maxcnt = (1u << cb) - 1;
-  out.rows = rows; out.cols = cols; out.R = R; out.rpt = rpt; out.nchunks = nchunks;
-  out.passptr.assign(nchunks + 1, 0);
+  out.rows = rows; out.cols = cols; out.R = R; out.rpt = rpt; out.nchunks = nchunks; out.split = split;
+  out.passptr.assign((size_t)nchunks * split + 1, 0);
   out.pinfo.clear(); out.idx.clear(); out.val.clear(); out.meta.clear();
   const int RK = kCsThreads * rpt;  // row keys: lane * rpt + j
   std::vector<int> cnt(RK), start(RK), run(RK);
@@ -105,9 +109,13 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
     for (int r = r0; r < r1; ++r)
       for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ents.push_back(Ent{col[p], r - r0, p});
     std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.col != b.col ? a.col < b.col : a.rl < b.rl; });
-    const long n = (long)ents.size();
+    const long n_all = (long)ents.size();
+    // split = 2: the chunk's stream is cut in two at (a multiple of 256 near) its middle, one workgroup each
+    const long mid = split > 1 ? std::min(n_all, (n_all / 2 + 255) & ~255L) : n_all;
+    for (int part = 0; part < split; ++part) {
+    const long e_lo = part == 0 ? 0 : mid, n = part == 0 ? mid : n_all;
     int np = 0;
-    for (long e0 = 0, e1; e0 < n; e0 = e1, ++np) {
+    for (long e0 = e_lo, e1; e0 < n; e0 = e1, ++np) {
       // a pass = up to kCsPass consecutive sorted nonzeros spanning fewer than 2^kCsColBits columns
       e1 = std::min(n, e0 + kCsPass);
       const int base = ents[e0].col;
@@ -138,14 +146,30 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
         out.meta.push_back(w);
       }
     }
-    out.passptr[c + 1] = out.passptr[c] + np;
+    out.passptr[(size_t)c * split + part + 1] = out.passptr[(size_t)c * split + part] + np;
+    }
   }
-  out.npass = out.passptr[nchunks];
+  out.npass = out.passptr[(size_t)nchunks * split];
   // too many short passes (very wide, very sparse chunks): the padding would be streamed on every product
-  if ((long)out.npass * kCsPass > rowptr[rows] + rowptr[rows] / 4 + (long)nchunks * kCsPass) return false;
+  if ((long)out.npass * kCsPass > rowptr[rows] + rowptr[rows] / 4 + (long)nchunks * split * kCsPass) return false;
   return true;
 }
 
+
+// split == 1: the finished row goes through the epilogue functor.  split == 2: `s` is the partial sum of the
+// workgroup's half of the row — only epilogues that are linear in it (a `split` member: EpiGp, EpiPartial) may be
+// launched on such a layout (launch_spmv routes the others through EpiPartial + k_epi_finish).
+template <class Epi, class = void>
+struct epi_has_split : std::false_type {};
+template <class Epi>
+struct epi_has_split<Epi, std::void_t<decltype(&Epi::split)>> : std::true_type {};
+template <class Epi>
+__device__ __forceinline__ void cs_epilogue(const Epi &epi, int split, int part, int r, double s, double *sums, double *maxs) {
+  if constexpr (epi_has_split<Epi>::value) {
+    if (split > 1) { epi.split(r, s, part, sums, maxs); return; }
+  }
+  epi(r, s, sums, maxs);
+}
 
 // Row sums of one pass from the LDS product buffer: m = {first slot of the lane's run | the lane's RPT counts}.
 // (Measured alternative: level by level — the L-th product of several rows as one batch of independent LDS reads,
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
   constexpr int NQ = kCsQuads;
   __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
   __shared__ double red[kCsThreads / 64];
-  const int tid = threadIdx.x, c = blockIdx.x;
+  const int tid = threadIdx.x, wg = blockIdx.x, c = wg / A.split, part = wg - c * A.split;
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
   double sums[NS], maxs[NM], acc[RPT];
 #pragma unroll
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
 #pragma unroll
   for (int j = 0; j < RPT; ++j) acc[j] = 0.;
 
-  const int g0 = A.passptr[c], g1 = A.passptr[c + 1];
+  const int g0 = A.passptr[wg], g1 = A.passptr[wg + 1];
   uint4 ic[NQ], in[NQ];
   double2 va[NQ], vb[NQ], na[NQ], nb[NQ];
   unsigned long long mc = 0, mn = 0;
@@ -245,18 +269,18 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) epi(r, acc[j], sums, maxs);
+    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + c] = t;
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kCsThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + c] = t;
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
     }
   }
 }
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
   constexpr int NQ = kCsQuads;
   __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
   __shared__ double red[kCsThreads / 64];
-  const int tid = threadIdx.x, c = blockIdx.x;
+  const int tid = threadIdx.x, wg = blockIdx.x, c = wg / A.split, part = wg - c * A.split;
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
   double sums[NS], maxs[NM], acc[RPT];
 #pragma unroll
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
   for (int i = 0; i < NM; ++i) maxs[i] = 0.;
 #pragma unroll
   for (int j = 0; j < RPT; ++j) acc[j] = 0.;
-  const int g0 = A.passptr[c], g1 = A.passptr[c + 1];
+  const int g0 = A.passptr[wg], g1 = A.passptr[wg + 1];
   CsSet<NQ> S0, S1;
   double xg[NQ][4];
   auto load = [&](int g, CsSet<NQ> &S) {
@@ -359,18 +383,18 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) epi(r, acc[j], sums, maxs);
+    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + c] = t;
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kCsThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + c] = t;
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
     }
   }
 }
@@ -384,7 +408,7 @@ template <class Epi>
 inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                            int *step_counter) {
   if (A.nchunks <= 0) return;
-  const dim3 g(A.nchunks), b(kCsThreads);
+  const dim3 g(A.nchunks * A.split), b(kCsThreads);
   if (cs_schedule() == 1) {
     switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

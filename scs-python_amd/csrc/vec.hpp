@@ -153,10 +153,11 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int
 }
 
 // r = b - G ws; x = ws; p = M r; partial [max|r| , sum r M r]
+// Gws2 != nullptr: G ws = Gws + Gws2 (split layout of A', see EpiGp::split)
 __global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restrict__ b, const double *__restrict__ Gws,
                                                          const double *__restrict__ ws, const double *__restrict__ M,
                                                          double *x, double *r, double *p, int n, int have_ws, const int *fl,
-                                                         double *part) {
+                                                         double *part, const double *__restrict__ Gws2 = nullptr) {
   __shared__ double sm[kVecThreads / 64];
   double mx = 0., s = 0.;
   if (fl[F_ZERO_RHS]) {  // zero right-hand side: the solution is zero, no iterations
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restric
     return;
   }
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) {
-    const double ri = have_ws ? b[i] - Gws[i] : b[i];
+    const double ri = have_ws ? b[i] - (Gws2 ? Gws[i] + Gws2[i] : Gws[i]) : b[i];
     const double zi = M[i] * ri;
     x[i] = have_ws ? ws[i] : 0.0;
     r[i] = ri;
@@ -238,14 +239,14 @@ template <class Sync>
 __device__ __forceinline__ void cg_update_block(double *x, double *r, const double *__restrict__ p, const double *__restrict__ Gp,
                                                 const double *__restrict__ M, int n, double *yacc, const double *__restrict__ z,
                                                 int m, double alpha, double *part, int b, int nb, int tid, double *sm, Sync sync,
-                                                bool active = true) {
+                                                bool active = true, const double *__restrict__ Gp2 = nullptr) {
   double mx = 0., s = 0.;
   if (active) {
     if (yacc)
       for (long i = (long)b * kVecThreads + tid; i < m; i += (long)nb * kVecThreads) yacc[i] += alpha * z[i];
     for (long i = (long)b * kVecThreads + tid; i < n; i += (long)nb * kVecThreads) {
       x[i] += alpha * p[i];
-      const double ri = r[i] - alpha * Gp[i];
+      const double ri = r[i] - alpha * (Gp2 ? Gp[i] + Gp2[i] : Gp[i]);
       r[i] = ri;
       mx = fmax(mx, abs_nan_inf(ri));
       s += (M[i] * ri) * ri;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r,
                                                            const double *__restrict__ Gp, const double *__restrict__ M,
                                                            int n, double *yacc, const double *__restrict__ z, int m,
                                                            const double *pgp_part, int pgp_np, double *sc, const int *fl,
-                                                           double *part) {
+                                                           double *part, const double *__restrict__ Gp2 = nullptr) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r,
     }
     __syncthreads();
   }
-  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{});
+  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
 }
 
 // p = M r + beta p.  beta = z'r(new) / z'r(old) and the convergence test are formed in the prologue from the

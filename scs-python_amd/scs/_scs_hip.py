@@ -143,7 +143,7 @@ def _load():
     lib.scs_hip_spmv.restype = c_int
     lib.scs_hip_spmv.argtypes = [C.POINTER(_ScsMatrix), _PD, _PD, c_int]
     lib.scs_hip_cs_layout_host_spmv.restype = c_int
-    lib.scs_hip_cs_layout_host_spmv.argtypes = [C.POINTER(_ScsMatrix), _PD, _PD, c_int, c_int]
+    lib.scs_hip_cs_layout_host_spmv.argtypes = [C.POINTER(_ScsMatrix), _PD, _PD, c_int, c_int, c_int]
     lib.scs_hip_spmv_bench.restype = c_dbl
     lib.scs_hip_spmv_bench.argtypes = [C.POINTER(_ScsMatrix), c_int, c_int]
     lib.scs_hip_proj_cone.restype = c_int
@@ -588,13 +588,13 @@ def spmv(A, x, transpose=False):
     return y
 
 
-def cs_layout_host_spmv(A, x, transpose=False, rpt=0):
+def cs_layout_host_spmv(A, x, transpose=False, rpt=0, split=1):
     """HOST-ONLY: A x (or A' x) evaluated by walking the column-sorted pass layout of the large-matrix SpMV kernels
     as built by the host builder; None when the pattern does not fit the format.  (tests, no GPU needed)"""
     M, keep = _matrix(A)
     xx = np.ascontiguousarray(x, dtype=np.float64)
     y = np.zeros(A.shape[1] if transpose else A.shape[0])
-    rc = _lib.scs_hip_cs_layout_host_spmv(C.byref(M), _pd(xx), _pd(y), 1 if transpose else 0, int(rpt))
+    rc = _lib.scs_hip_cs_layout_host_spmv(C.byref(M), _pd(xx), _pd(y), 1 if transpose else 0, int(rpt), int(split))
     if rc == 1:
         return None
     _check(rc)

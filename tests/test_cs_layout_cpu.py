@@ -37,6 +37,21 @@ def test_layout_walk_matches_oracle_bits(hip, oracle, shape, per_col, rpt):
     np.testing.assert_array_equal(got_t, oracle.spmv(A, y, trans=True))
 
 
+@pytest.mark.parametrize("shape,per_col", [((70000, 20000), 5), ((3000, 1700), 6), ((20000, 50000), 12)])
+def test_layout_split_in_two_workgroups_per_chunk(hip, oracle, shape, per_col):
+    """split = 2 (what scs_init uses for A'): each half of a chunk's column-sorted stream is summed on its own and the
+    two partial sums are added — not the oracle's sequential order any more, but within 1 ulp-ish of it"""
+    rng = np.random.default_rng(43)
+    A = pg.random_sparse(*shape, per_col, rng)
+    x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
+    for trans, vec in ((False, x), (True, y)):
+        got = hip.cs_layout_host_spmv(A, vec, transpose=trans, split=2)
+        ref = oracle.spmv(A, vec, trans=trans)
+        assert got is not None
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+        assert (got != ref).any() or A.nnz < 100000  # it really is a different summation order
+
+
 def test_layout_empty_rows_and_columns(hip, oracle):
     rng = np.random.default_rng(3)
     A = pg.random_sparse(5000, 4000, 2, rng).tolil()

@@ -63,6 +63,7 @@ def test_spmv_bit_exact(hip, oracle, m, n, density, long_rows):
 
 @pytest.mark.parametrize("cs", ["1", "0"], ids=["column-sorted", "slab"])
 def test_spmv_slab_layout_bit_exact(hip, oracle, monkeypatch, cs):
+    monkeypatch.setenv("SCS_HIP_CS_SPLIT", "0")  # one workgroup per row chunk: sequential per-row sums (see below for the split)
     """large gather vector (> 2 MiB) + many rows => the column-sorted pass kernel (or, SCS_HIP_CS=0, the L2-blocked
     slab kernel) is selected; it must reproduce the CSR-stream / oracle summation order bit for bit (incl. a
     dense-ish row and column)."""
@@ -527,13 +528,18 @@ def test_device_setup_matches_host_setup(hip, oracle, monkeypatch, cs):
             np.testing.assert_array_equal(sols["host"][key], sols["device"][key], err_msg=key)
 
 
+@pytest.mark.parametrize("split", ["0", "1"], ids=["one-wg-per-chunk", "split"])
 @pytest.mark.parametrize("shape,per_col,rpt,dense", [((300000, 270000), 7, None, False), ((1100000, 400000), 3, None, False),
                                                      ((270000, 300000), 9, "2", False), ((400000, 300000), 5, "16", False),
                                                      ((400000, 300000), 5, "16", True)])
-def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt, dense):
+def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt, dense, split):
     """spmv_cs.hpp: every chunk size (rows per lane 1 .. 16), both orientations, device and host builders, against the
     oracle's sequential loops — bit for bit.  A pattern that does not fit the format's count fields (16 rows per
-    lane: 3-bit counts; here a dense block) must fall back to the slab kernel with the same bits."""
+    lane: 3-bit counts; here a dense block) must fall back to the slab kernel with the same bits.
+    split: A' products use two workgroups per row chunk (each sums its half of the chunk's column-sorted stream, the
+    two partial sums are added) — still deterministic and identical between the builders, but (a + b) + (c + d) is not
+    the oracle's sequential order: 1e-13 relative instead of bits."""
+    monkeypatch.setenv("SCS_HIP_CS_SPLIT", split)
     rng = np.random.default_rng(23)
     A = pg.random_sparse(*shape, per_col, rng)
     if dense:  # 40 nonzeros of one row inside one pass: more than a 3-bit count holds
@@ -544,10 +550,17 @@ def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt
         monkeypatch.setenv("SCS_HIP_CS_RPT", rpt)
     x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
     ref = (oracle.spmv(A, x), oracle.spmv(A, y, trans=True))
+    got = {}
     for mode in ("device", "host"):
         monkeypatch.setenv("SCS_HIP_SETUP", mode)
-        np.testing.assert_array_equal(hip.spmv(A, x), ref[0], err_msg=mode)
-        np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), ref[1], err_msg=mode)
+        got[mode] = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
+        np.testing.assert_array_equal(got[mode][0], ref[0], err_msg=mode)
+        if split == "0":
+            np.testing.assert_array_equal(got[mode][1], ref[1], err_msg=mode)
+        else:
+            np.testing.assert_allclose(got[mode][1], ref[1], rtol=0, atol=1e-13 * np.abs(ref[1]).max(), err_msg=mode)
+    np.testing.assert_array_equal(got["device"][1], got["host"][1])
+    np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), got["host"][1])  # run-to-run
 
 
 def test_device_setup_long_rows_fall_back(hip, oracle):

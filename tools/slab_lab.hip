@@ -411,7 +411,7 @@ static void run_cs_abl(const char *tag, const Csr &M, const double *dx, double *
   unsigned *idx = to_dev(hc.idx);
   double *val = to_dev(hc.val);
   unsigned long long *meta = to_dev(hc.meta);
-  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt};
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt, hc.split};
   auto launch = [&] { hipLaunchKernelGGL((k_spmv_cs_ga<EpiStore, RPT, ABL>), dim3(hc.nchunks), dim3(kCsThreads), 0, 0, v, dx, EpiStore{dy, 0}, nullptr, nullptr); };
   const double us = time_us(launch, 20);
   std::printf("  %-44s R=%5d : %7.1f us\n", tag, hc.R, us);
@@ -426,13 +426,42 @@ static void run_cs(const char *tag, int rpt, const Csr &M, const double *dx, dou
   unsigned *idx = to_dev(hc.idx);
   double *val = to_dev(hc.val);
   unsigned long long *meta = to_dev(hc.meta);
-  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt};
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt, hc.split};
   HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
   auto launch = [&] { launch_spmv_cs(v, dx, EpiStore{dy, 0}, nullptr, 0, nullptr); };
   const double us = time_us(launch, 20);
   std::printf("  %-34s R=%5d wgs=%4d passes=%5d (%.1f%% padding) : %7.1f us  mismatches %ld\n", tag, hc.R, hc.nchunks, hc.npass,
               100. * ((double)hc.npass * kCsPass / M.rowptr[M.rows] - 1.), us, mismatches(dy, ref));
   hipFree(passptr); hipFree(pinfo); hipFree(idx); hipFree(val); hipFree(meta);
+}
+
+struct EpiRaw2 {  // lab: raw partial row sums of the two halves
+  double *y0, *y1;
+  static constexpr int kSums = 0, kMaxs = 0;
+  __device__ void operator()(int r, double s, double *, double *) const { y0[r] = s; }
+  __device__ void split(int r, double s, int part, double *, double *) const { (part ? y1 : y0)[r] = s; }
+};
+static void run_cs_split(const char *tag, const Csr &M, const double *dx, double *dy, const std::vector<double> &ref) {
+  HostCs hc;
+  if (!build_cs(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hc, 0, 2)) { std::printf("  %-34s build failed\n", tag); return; }
+  int *passptr = to_dev(hc.passptr);
+  int2 *pinfo = to_dev(hc.pinfo);
+  unsigned *idx = to_dev(hc.idx);
+  double *val = to_dev(hc.val);
+  unsigned long long *meta = to_dev(hc.meta);
+  double *dy1;
+  HIP_CHECK(hipMalloc(&dy1, ref.size() * 8));
+  CsView v{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt, hc.split};
+  auto launch = [&] { launch_spmv_cs(v, dx, EpiRaw2{dy, dy1}, nullptr, 0, nullptr); };
+  const double us = time_us(launch, 20);
+  std::vector<double> h0(ref.size()), h1(ref.size());
+  HIP_CHECK(hipMemcpy(h0.data(), dy, ref.size() * 8, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(h1.data(), dy1, ref.size() * 8, hipMemcpyDeviceToHost));
+  double err = 0, scl = 0;
+  for (size_t i = 0; i < ref.size(); ++i) { err = std::max(err, std::fabs(h0[i] + h1[i] - ref[i])); scl = std::max(scl, std::fabs(ref[i])); }
+  std::printf("  %-34s R=%5d rpt=%2d wgs=%4d passes=%5d : %7.1f us  max err %.2e (scale %.1f)\n", tag, hc.R, hc.rpt, hc.nchunks * hc.split,
+              hc.npass, us, err, scl);
+  hipFree(passptr); hipFree(pinfo); hipFree(idx); hipFree(val); hipFree(meta); hipFree(dy1);
 }
 
 static void bench_matrix(const char *name, const Csr &M) {
@@ -468,7 +497,8 @@ static void bench_matrix(const char *name, const Csr &M) {
     return;
   }
   if (getenv("LAB_CS")) {
-    for (int rpt : {4, 8, 0}) run_cs(cs_schedule() ? "column-sorted passes, gather-ahead" : "column-sorted passes", rpt, M, dx, dy, ref);
+    run_cs_split("column-sorted, 2 workgroups/chunk", M, dx, dy, ref);
+    for (int rpt : {0}) run_cs(cs_schedule() ? "column-sorted passes, gather-ahead" : "column-sorted passes", rpt, M, dx, dy, ref);
     hipFree(dx); hipFree(dy);
     return;
   }

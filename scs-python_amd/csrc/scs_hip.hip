@@ -355,6 +355,8 @@ struct ScsHipWork {
   int *stall_fl = nullptr;         // fl (or nullptr): k_tau_dots raises the stall, k_cone_pre parks the CG kernels
   int *h_flags_slot[2] = {nullptr, nullptr};
   hipEvent_t ev_iter[2] = {nullptr, nullptr};
+  hipEvent_t ev_prof[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // in-situ K1/K2 samples of the run-ahead loop
+  int prof_step[2] = {-1, -1};  // CG step (0-based) bracketed by ev_prof[slot], -1 = none
 
   // hipGraphs of the launch-bound inner loop (built lazily at the first solve):
   //   g_pre[i] : iterate normalisation, rhs, CG start + kGraphSteps[i] CG steps + flag read-back
@@ -462,6 +464,7 @@ struct ScsHipWork {
     if (h_params_base) (void)hipHostFree(h_params_base);
     for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
     for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
+    for (auto &es : ev_prof) for (auto &e : es) if (e) (void)hipEventDestroy(e);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
@@ -706,7 +709,25 @@ struct ScsHipWork {
     // an unused step costs four ~1-2 us launches, a stall a drained queue and a host round trip (~100 us)
     int chunk = std::max(2, recent_cg_max() + 1);
     if (pipe_chunk_override > 0) chunk = pipe_chunk_override;
-    for (int k = 0; k < chunk; ++k) enqueue_cg_step(ut.p, ut.p + n);
+    prof_step[slot] = -1;
+    for (int k = 0; k < chunk; ++k) {
+      if (profile && k == chunk / 2) {  // one CG step of the queued iteration bracketed by events: nothing waits for them here
+        for (auto &e : ev_prof[slot]) if (!e) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(ev_prof[slot][0], stream));
+        launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream, fl.p + F_STEP);
+        HIP_CHECK(hipEventRecord(ev_prof[slot][1], stream));
+        if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+        launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
+        HIP_CHECK(hipEventRecord(ev_prof[slot][2], stream));
+        const int nb = vb(std::max(n, m));
+        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, ut.p, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, ut.p + n,
+                           tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
+        hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
+        prof_step[slot] = k;
+      } else {
+        enqueue_cg_step(ut.p, ut.p + n);
+      }
+    }
     enqueue_lin_sys_tail();
     enqueue_cones();
     enqueue_v_update();
@@ -727,6 +748,14 @@ struct ScsHipWork {
     last_cg_iters = hf[F_ITERS];
     note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
+    if (profile && prof_step[slot] >= 0 && last_cg_iters > prof_step[slot]) {  // the sampled step really ran
+      float a = 0, b = 0;
+      if (hipEventElapsedTime(&a, ev_prof[slot][0], ev_prof[slot][1]) == hipSuccess &&
+          hipEventElapsedTime(&b, ev_prof[slot][1], ev_prof[slot][2]) == hipSuccess) {
+        prof_ms[0] += a; prof_n[0]++;
+        prof_ms[1] += b; prof_n[1]++;
+      }
+    }
     return true;
   }
   // after a stall: drain the queue, lower the flags and finish iteration `iter` the synchronous way
@@ -1527,7 +1556,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
   const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= 1000000 && !w->pipelined;
   bool use_graphs = graphs_wanted && w->graphs_ready;
-  const bool run_ahead = w->pipelined && !w->profile && w->persist_wgs == 0;
+  const bool run_ahead = w->pipelined && w->persist_wgs == 0;  // (in-situ profiling samples ride along: enqueue_plain_iteration)
   // an iteration is "plain" when the host has nothing to decide in it: no convergence check / print / log row,
   // no Anderson step, not the last one.  Plain iterations may be enqueued whole, and one ahead (run-ahead mode).
   auto is_plain = [&](int it) {

@@ -598,28 +598,29 @@ struct SpmvMat {
 
 // split layouts: the epilogue of a product whose functor is not linear in the row sum — rows finished from the two
 // partial vectors, gridDim.x = the number of workgroups of the product (= the stride of the reduction partials)
+constexpr int kEpiFinishThreads = 1024;  // few workgroups (their count is the stride of the partials): many lanes each
 template <class Epi>
-__global__ __launch_bounds__(kSpmvThreads) void k_epi_finish(const double *__restrict__ y0, const double *__restrict__ y1, int rows, Epi epi,
+__global__ __launch_bounds__(kEpiFinishThreads) void k_epi_finish(const double *__restrict__ y0, const double *__restrict__ y1, int rows, Epi epi,
                                                               const int *done_flag) {
   if (done_flag && *done_flag) return;
-  __shared__ double red[kSpmvThreads / 64];
+  __shared__ double red[kEpiFinishThreads / 64];
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
   double sums[NS], maxs[NM];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sums[i] = 0.;
 #pragma unroll
   for (int i = 0; i < NM; ++i) maxs[i] = 0.;
-  for (long r = (long)blockIdx.x * kSpmvThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kSpmvThreads)
+  for (long r = (long)blockIdx.x * kEpiFinishThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kEpiFinishThreads)
     epi((int)r, y0[r] + y1[r], sums, maxs);
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
-      const double t = block_sum<kSpmvThreads>(sums[i], red);
+      const double t = block_sum<kEpiFinishThreads>(sums[i], red);
       if (threadIdx.x == 0) epi.partial[(size_t)i * gridDim.x + blockIdx.x] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
-      const double t = block_max<kSpmvThreads>(maxs[i], red);
+      const double t = block_max<kEpiFinishThreads>(maxs[i], red);
       if (threadIdx.x == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + blockIdx.x] = t;
     }
   }
@@ -633,7 +634,7 @@ inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const
       if (M.cs.split > 1) {
         if (M.cs.nchunks <= 0) return;
         launch_spmv_cs(M.cs, x, EpiPartial{M.part0, M.part1}, done_flag, s, step_counter);
-        hipLaunchKernelGGL(k_epi_finish<Epi>, dim3(M.nblk()), dim3(kSpmvThreads), 0, s, M.part0, M.part1, M.cs.rows, epi, done_flag);
+        hipLaunchKernelGGL(k_epi_finish<Epi>, dim3(M.nblk()), dim3(kEpiFinishThreads), 0, s, M.part0, M.part1, M.cs.rows, epi, done_flag);
         return;
       }
     }

@@ -81,3 +81,31 @@ def test_metric_workload_solves_to_certificate(hip, big):
     Y = y[K["l"]:].reshape(-1, q)
     assert (np.linalg.norm(S[:, 1:], axis=1) <= S[:, 0] + 1e-7).all()
     assert (np.linalg.norm(Y[:, 1:], axis=1) <= Y[:, 0] + 1e-7).all()
+
+
+def test_large_qp_solves_to_certificate(hip):
+    """a QP over l + q cones large enough for the column-sorted pass layouts of A, A' (split: two workgroups per row
+    chunk) and P: solved, KKT certificate in original units, and the optimum the instance was constructed with"""
+    import scs
+    from scipy import sparse
+    K = {"l": 200000, "q": [10] * 10000}
+    n = 150000
+    data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, n, 20, 11, lambda z, K: hip.proj_cone(z, K, dual=True))
+    assert data["A"].nnz > (1 << 20) and sparse.triu(data["P"]).nnz > 0
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-6, eps_rel=1e-6, verbose=False).solve()
+    info = sol["info"]
+    assert info["status"] == "solved", info
+    assert "column-sorted" in info["lin_sys_solver"]
+    A, b, c = data["A"], data["b"], data["c"]
+    P = data["P"]
+    Pf = (P + sparse.triu(P, 1).T) if (abs(P - P.T)).nnz else P  # full symmetric P whichever triangle was passed
+    x, y, s = sol["x"], sol["y"], sol["s"]
+    px = Pf @ x
+    pri = np.abs(A @ x + s - b).max()
+    dua = np.abs(px + A.T @ y + c).max()
+    gap = abs(x @ px + c @ x + b @ y)
+    assert pri <= 1e-6 + 1e-6 * max(np.abs(A @ x).max(), np.abs(s).max(), np.abs(b).max()) * 1.01
+    assert dua <= 1e-6 + 1e-6 * max(np.abs(px).max(), np.abs(A.T @ y).max(), np.abs(c).max()) * 1.01
+    assert gap <= 1e-6 + 1e-6 * max(abs(x @ px), abs(c @ x), abs(b @ y)) * 1.01
+    assert abs(info["pobj"] - p_star) <= 1e-4 * max(1.0, abs(p_star))
+    np.testing.assert_allclose(x, x0, rtol=0, atol=2e-4 * max(1.0, np.abs(x0).max()))  # strictly convex: x is unique

@@ -1554,7 +1554,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   const int max_iters = w->stgs.max_iters;
   // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
   // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
-  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= 1000000 && !w->pipelined;
+  static const long graph_max_l = [] { const char *e = getenv("SCS_HIP_GRAPH_MAX_L"); return e ? atol(e) : 1000000L; }();  // experiments
+  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= graph_max_l && !w->pipelined;
   bool use_graphs = graphs_wanted && w->graphs_ready;
   const bool run_ahead = w->pipelined && w->persist_wgs == 0;  // (in-situ profiling samples ride along: enqueue_plain_iteration)
   // an iteration is "plain" when the host has nothing to decide in it: no convergence check / print / log row,

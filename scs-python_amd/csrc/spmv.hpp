@@ -344,7 +344,8 @@ inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20)
 // not the gather vector fits L2 (what it saves is L2 -> L1 line traffic): measured crossover on LP+SOC problems with
 // 10 nonzeros per row at nnz ~ 1e6 (0.240 vs 0.245 ms/iter), -10 % per iteration at nnz = 2e6, -12 % at 4e6.
 inline bool cs_wanted(int rows, int cols, long nnz) {
-  static const long min_nnz = [] { const char *e = getenv("SCS_HIP_CS_MIN_NNZ"); return e ? atol(e) : (1L << 20); }();  // experiments
+  const char *e = getenv("SCS_HIP_CS_MIN_NNZ");  // experiments, tests (read at every scs_init)
+  const long min_nnz = e ? atol(e) : (1L << 20);
   (void)cols;
   return rows >= 16384 && nnz >= min_nnz;
 }

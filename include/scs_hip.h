@@ -53,7 +53,9 @@ size_t scs_sizeof_float(void);
 
 /* number of visible HIP devices (0 => library unusable); does not initialise a context */
 int scs_hip_device_count(void);
-/* choose the device used by subsequent scs_init calls of this process (default 0) */
+/* choose the device used by subsequent scs_init calls (and the kernel-level entry points below) of the CALLING THREAD
+ * (default 0).  A workspace remembers the device it was created on: scs_solve / scs_update / scs_finish select it
+ * themselves, so one process may drive several GPUs, one workspace per device and thread. */
 int scs_hip_set_device(int dev);
 
 /* y (+)= A x or A' x through the hot-path SpMV kernels (row a3; plays the role
@@ -102,6 +104,24 @@ void scs_hip_kernel_times(const ScsWork *w, double *out);
  * data, one HIP event pair per batch (the ~10-20 us per-event overhead is amortised).
  * out[2] = {K1 avg ms, K2 avg ms}.  Returns 0 on success. */
 int scs_hip_time_matvec(ScsWork *w, int reps, double *out);
+
+/* Anderson acceleration as a standalone object on host vectors (row a6): the interface of scs_source/src/aa.c
+ * (aa_init / aa_apply / aa_safeguard / aa_reset / aa_finish; named at R:meson.build:187, knobs R:README.md:98-104,
+ * statistics R:scs/scsobject.h:1096-1107).  mem <= 32.  scs_solve runs the same device object on the resident iterate.
+ *   apply:     f = F(x) on entry; on return f may hold the extrapolated iterate.  Returns aa_norm (0: history
+ *              still filling, < 0: step rejected and history reset, NaN: error).
+ *   safeguard: f_new = F(x_new) of the step after an accepted extrapolation; returns -1 and restores the
+ *              pre-extrapolation pair when the fixed-point residual grew, else 0.
+ *   last_gamma: weights of the most recent solve (returns their count; gamma may be NULL). */
+typedef struct ScsHipAa ScsHipAa;
+ScsHipAa *scs_hip_aa_init(scs_int dim, scs_int mem, scs_int type1, scs_float regularization, scs_float relaxation,
+                          scs_float safeguard_factor, scs_float max_weight_norm);
+scs_float scs_hip_aa_apply(ScsHipAa *a, scs_float *f, const scs_float *x);
+scs_int scs_hip_aa_safeguard(ScsHipAa *a, scs_float *f_new, scs_float *x_new);
+void scs_hip_aa_reset(ScsHipAa *a);
+void scs_hip_aa_get_stats(const ScsHipAa *a, ScsAaStats *st);
+scs_int scs_hip_aa_last_gamma(const ScsHipAa *a, scs_float *gamma);
+void scs_hip_aa_finish(ScsHipAa *a);
 
 /* last error message of the calling thread ("" if none) */
 const char *scs_hip_last_error(void);

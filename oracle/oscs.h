@@ -122,6 +122,7 @@ scs_int o_aa_safeguard(scs_float *f_new, scs_float *x_new, OAa *a);
 void o_aa_reset(OAa *a);
 void o_aa_free(OAa *a);
 void o_aa_get_stats(const OAa *a, ScsAaStats *st);
+scs_int o_aa_last_gamma(const OAa *a, scs_float *gamma);
 
 /* small dense solve with partial pivoting; returns numerical rank (n if ok, <n if singular) */
 scs_int o_dense_solve(scs_float *M, scs_float *rhs, scs_int n);

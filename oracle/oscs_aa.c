@@ -17,6 +17,8 @@ struct OAa {
   scs_float relaxation, regularization, safeguard_factor, max_weight_norm;
   scs_float *x, *f, *g, *g_prev, *y, *s, *d, *Y, *S, *D, *M, *work, *x_work;
   scs_float norm_g;
+  scs_float last_gamma[64]; /* weights of the most recent solve (tests) */
+  scs_int last_len;
   ScsAaStats st;
 };
 
@@ -54,6 +56,11 @@ void o_aa_free(OAa *a) {
 }
 
 void o_aa_get_stats(const OAa *a, ScsAaStats *st) { *st = a->st; }
+
+scs_int o_aa_last_gamma(const OAa *a, scs_float *gamma) {
+  if (gamma) memcpy(gamma, a->last_gamma, (size_t)a->last_len * sizeof(scs_float));
+  return a->last_len;
+}
 
 static void set_m(OAa *a, scs_int len) {
   scs_int i, j, dim = a->dim;
@@ -97,6 +104,8 @@ static scs_float solve(scs_float *f, OAa *a, scs_int len) {
   for (j = 0; j < len; ++j) a->work[j] = o_dot(&L[(size_t)j * dim], a->g, dim);
   rank = o_dense_solve(a->M, a->work, len);
   a->st.last_rank = rank;
+  a->last_len = OMIN(len, 64);
+  memcpy(a->last_gamma, a->work, (size_t)a->last_len * sizeof(scs_float));
   if (rank == 0) { a->st.n_reject_rank0++; a->success = 0; o_aa_reset(a); return -1.; }
   if (rank < len) { a->st.n_reject_lapack++; a->success = 0; o_aa_reset(a); return -1.; }
   aa_norm = o_norm_2(a->work, len);

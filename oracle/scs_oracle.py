@@ -104,6 +104,20 @@ def lib():
                                      c_dbl, PI]
         L.oscs_spmv.restype = None
         L.oscs_spmv.argtypes = [C.POINTER(ScsMatrix), PD, PD, c_int]
+        L.o_aa_init.restype = C.c_void_p
+        L.o_aa_init.argtypes = [c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl]
+        L.o_aa_apply.restype = c_dbl
+        L.o_aa_apply.argtypes = [PD, PD, C.c_void_p]
+        L.o_aa_safeguard.restype = c_int
+        L.o_aa_safeguard.argtypes = [PD, PD, C.c_void_p]
+        L.o_aa_reset.restype = None
+        L.o_aa_reset.argtypes = [C.c_void_p]
+        L.o_aa_free.restype = None
+        L.o_aa_free.argtypes = [C.c_void_p]
+        L.o_aa_get_stats.restype = None
+        L.o_aa_get_stats.argtypes = [C.c_void_p, C.POINTER(ScsAaStats)]
+        L.o_aa_last_gamma.restype = c_int
+        L.o_aa_last_gamma.argtypes = [C.c_void_p, PD]
         _lib = L
     return _lib
 
@@ -305,3 +319,45 @@ def spmv(A, x, trans=False):
     y = np.zeros(n if trans else m)
     lib().oscs_spmv(C.byref(Am.mat), _pd(xx), _pd(y), 1 if trans else 0)
     return y
+
+
+class OracleAA(object):
+    """oracle/oscs_aa.c driven step by step (the checker of tests/test_aa_gpu.py)."""
+    _FIELDS = ("iter", "n_accept", "n_reject_lapack", "n_reject_rank0", "n_reject_nonfinite",
+               "n_reject_weight_cap", "n_safeguard_reject", "last_rank", "last_aa_norm", "last_regularization")
+
+    def __init__(self, dim, mem, type1=True, regularization=1e-8, relaxation=1.0, safeguard_factor=1.0,
+                 max_weight_norm=1e10):
+        self._h = lib().o_aa_init(int(dim), int(mem), 1 if type1 else 0, float(regularization), float(relaxation),
+                                  float(safeguard_factor), float(max_weight_norm))
+        self.dim = int(dim)
+
+    def apply(self, f, x):
+        ff = np.array(f, dtype=np.float64, copy=True)
+        xx = _f64(x)
+        nrm = lib().o_aa_apply(_pd(ff), _pd(xx), self._h)
+        return nrm, ff
+
+    def safeguard(self, f_new, x_new):
+        ff = np.array(f_new, dtype=np.float64, copy=True)
+        xx = np.array(x_new, dtype=np.float64, copy=True)
+        rc = lib().o_aa_safeguard(_pd(ff), _pd(xx), self._h)
+        return rc, ff, xx
+
+    def reset(self):
+        lib().o_aa_reset(self._h)
+
+    def stats(self):
+        st = ScsAaStats()
+        lib().o_aa_get_stats(self._h, C.byref(st))
+        return {k: getattr(st, k) for k in self._FIELDS}
+
+    def last_gamma(self):
+        g = np.zeros(64)
+        n = lib().o_aa_last_gamma(self._h, _pd(g))
+        return g[:n]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().o_aa_free(h)

@@ -1,16 +1,27 @@
-// aa.hpp — K10: Anderson acceleration on the device-resident iterate v (length l = n+m+1).
+// aa.hpp — K10: Anderson acceleration on a device-resident iterate (length dim = n+m+1 inside the ADMM loop).
 //
-// Plays the role of scs_source/src/aa.c (named at R:meson.build:187; absent); knobs
-// R:README.md:98-104, statistics R:scs/scsobject.h:1096-1107.
+// Plays the role of scs_source/src/aa.c (named at R:meson.build:187; absent): same interface
+// (init / apply / safeguard / reset / finish), knobs R:README.md:98-104, statistics R:scs/scsobject.h:1096-1107.
 //
-// Data layout: S, Y, D are tall-skinny l x mem column-major matrices in HBM
-// (3 * l * mem * 8 B; 720 MB at l = 3e6, mem = 10 — trivial against 288 GB).
-// Per call exactly ONE column changes, so the mem x mem system matrix
-// M = S'Y (type-I) / Y'Y (type-II) is updated incrementally: one fused pass
-// streams S and Y once (coalesced, HBM-bound) and produces the new row, the new
-// column and S'g with fixed-order two-stage reductions.  The tiny dense solve
-// (mem <= 32) is done by the host from 3*mem reduced scalars — the only values
-// that cross PCIe — and the extrapolation f -= D gamma is one more streaming pass.
+// Data layout: S, Y, D are tall-skinny dim x mem column-major matrices in HBM (3 * dim * mem * 8 B; 720 MB at
+// dim = 3e6, mem = 10 — trivial against 288 GB).  One call = one streaming pass that writes the new column of S, Y, D
+// (k_aa_update), then the least-squares weights
+//     type-I : gamma = (S'Y + r I)^{-1} S'g        type-II: gamma = (Y'Y + r I)^{-1} Y'g ,   r = regularization * ||M||_F
+// and the extrapolation f -= D gamma (k_aa_apply).  Two ways to the weights:
+//
+//  * TSQR (default): ONE pass over the history W = [L | Y | g] (L = S or Y) factors it with Householder reflectors,
+//    tile by tile, one wavefront per tile chain: the tile (64 * rho rows x c columns) and the running triangle live in
+//    LDS, the reflector of pivot column k is applied to the remaining columns in batches of four whose dot products are
+//    reduced with interleaved DPP trees.  Only the L columns are pivots (the rows of [R_LL | Q'Y | Q'g] are all the
+//    system needs: L'Y = R_LL'(Q'Y), L'g = R_LL'(Q'g)), the per-wave triangles are stacked and reduced by the same
+//    kernel in a fixed tree (1024 -> 16 -> 1 waves), and a one-wave kernel forms the regularised mem x mem system from
+//    the final triangle, solves it by LU with partial pivoting, applies the rank / finite / weight-cap tests and leaves
+//    gamma + verdict in device memory: nothing but 8 + mem doubles crosses PCIe.  Fixed order everywhere => bitwise
+//    run-to-run determinism.
+//  * Gram (SCS_HIP_AA=gram; also the A/B reference of tests/test_aa_gpu.py): per call one column changes, so the
+//    system matrix is updated incrementally from one fused pass (new row, new column, L'g: k_aa_dots) and solved on
+//    the host.
+// Both are compared step by step with the CPU checker in tests/test_aa_gpu.py.
 #pragma once
 #include "common.hpp"
 #include "vec.hpp"
@@ -18,6 +29,11 @@
 namespace scship {
 
 constexpr int kAaMaxMem = 32;
+constexpr int kAaMaxCols = 2 * kAaMaxMem + 1;
+
+// device result record of one solve (doubles): verdict, statistics, then gamma
+enum : int { AA_R_OK = 0, AA_R_RANK, AA_R_CODE, AA_R_NORM, AA_R_REG, AA_R_NORMG, AA_R_NORMD, AA_R_GAMMA = 8, AA_R_COUNT = 8 + kAaMaxMem };
+enum : int { AA_CODE_OK = 0, AA_CODE_RANK0, AA_CODE_LAPACK, AA_CODE_NONFINITE, AA_CODE_WEIGHT };
 
 // first call after a reset: x_prev = x, f_prev = f, g_prev = x - f
 __global__ __launch_bounds__(kVecThreads) void k_aa_seed(const double *__restrict__ x, const double *__restrict__ f, double *ax,
@@ -53,6 +69,7 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_update(const double *__restr
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------ Gram path
 // one streaming pass over L (= S or Y) and Y:  row[j] = L_idx . Y_j,  col[j] = L_j . Y_idx,  w[j] = L_j . g
 // partial layout: part[(k*kAaMaxMem + j) * nb + b], k = 0 (row), 1 (col), 2 (w)
 __global__ __launch_bounds__(kVecThreads) void k_aa_dots(const double *__restrict__ L, const double *__restrict__ Y,
@@ -89,14 +106,14 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_dots(const double *__restric
   }
 }
 
-// out[0] = sum of norm partials (||g||^2); out[1 + k*kAaMaxMem + j] = reduced dots
+// out[0] = sum of norm partials (||g||^2); out[1 + k*kAaMaxMem + j] = reduced dots; res[AA_R_NORMG] = ||g||
 __global__ __launch_bounds__(kVecThreads) void k_fin_aa(const double *npart, int nnp, const double *part, int np, int len,
-                                                        double *out, double *sc) {
+                                                        double *out, double *res) {
   __shared__ double sm[kVecThreads / 64];
   const double ng = part_sum(npart, nnp, sm);
   if (threadIdx.x == 0) {
     out[0] = ng;
-    sc[S_AA_NORMG] = sqrt(ng);
+    res[AA_R_NORMG] = sqrt(ng);
   }
   __syncthreads();
   for (int k = 0; k < 3; ++k)
@@ -107,10 +124,220 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_aa(const double *npart, int
     }
 }
 
-// f -= D gamma;  optional relaxation: f = beta f + (1-beta) (x - S gamma)
+// ------------------------------------------------------------------------------------------------ TSQR path
+// The tall matrix handed to one level of the reduction.  Level 1: the history itself — columns [L_0 .. L_{nL-1} |
+// Y_0 .. Y_{nY-1} | g], each a contiguous vector of `rows` doubles (L, Y with leading dimension ld).  Levels >= 2:
+// the stacked triangles of the level below, one column-major buffer (L = buffer, nL = c, ld = its row count).
+struct AaTall {
+  const double *L, *Y, *g;
+  long ld, rows;
+  int nL, nY, c, npiv;  // c columns in total, the first npiv are pivots
+};
+__device__ __forceinline__ const double *aa_col(const AaTall &W, int j) {
+  if (j < W.nL) return W.L + (size_t)W.ld * j;
+  if (j < W.nL + W.nY) return W.Y + (size_t)W.ld * (j - W.nL);
+  return W.g;
+}
+
+// value of the DPP source lane, +0.0 where the source is outside the row or the lane is masked off
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double aa_dpp0(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+// NR independent 64-lane sums, their DPP trees interleaved (row_shr 1,2,3,4,8, row_bcast 15, 31: total in lane 63,
+// handed to every lane through two v_readlane).  Fixed order: bitwise reproducible.
+template <int NR>
+__device__ __forceinline__ void aa_wave_allsum(double (&v)[NR]) {
+  double s[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] = v[i] + aa_dpp0<0x111, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x112, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x113, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x114, 0xf, 0xe>(s[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x118, 0xf, 0xc>(s[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x142, 0xa, 0xf>(s[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] += aa_dpp0<0x143, 0xc, 0xf>(s[i]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(s[i]), 63), hi = __builtin_amdgcn_readlane(__double2hiint(s[i]), 63);
+    v[i] = __hiloint2double(hi, lo);
+  }
+}
+
+constexpr int kAaRhoMax = 4;  // a tile has 64 * rho rows (rho rows per lane)
+inline int aa_pick_rho(int c) {  // ~40 KB of LDS per wavefront: 4 resident tile chains per CU
+  const int r = (40 * 1024) / (64 * c * 8);
+  return r < 1 ? 1 : (r > kAaRhoMax ? kAaRhoMax : r);
+}
+inline size_t aa_tsqr_lds(int c, int npiv, int rho) { return ((size_t)c * 64 * rho + (size_t)npiv * c) * sizeof(double); }
+
+// One wavefront per workgroup.  Wave w factors tiles [w * tiles_per_wave, (w+1) * tiles_per_wave) into one running
+// npiv x c triangle E (rows of [R_LL | Q'(other columns)]), which it stores as rows [w * npiv, (w+1) * npiv) of the
+// column-major output (leading dimension out_ld).  Householder step k on the stacked [E row k; tile]: only E row k and
+// the tile carry column k below the diagonal (E is upper trapezoidal), v = [alpha - beta; tile column k].
+__global__ __launch_bounds__(64) void k_aa_tsqr(AaTall W, int rho, long tiles_per_wave, double *out, long out_ld) {
+  extern __shared__ double aa_lds[];
+  const int lane = threadIdx.x, c = W.c, npiv = W.npiv, TR = 64 * rho;
+  double *T = aa_lds;                      // T[j * TR + r]: tile, column-major (lane-consecutive rows: conflict-free)
+  double *E = aa_lds + (size_t)c * TR;     // E[i * c + j]
+  for (int t = lane; t < npiv * c; t += 64) E[t] = 0.;
+  const long ntiles = (W.rows + TR - 1) / TR;
+  const long t0 = (long)blockIdx.x * tiles_per_wave, t1 = t0 + tiles_per_wave < ntiles ? t0 + tiles_per_wave : ntiles;
+  for (long t = t0; t < t1; ++t) {
+    const long r0 = t * TR;
+    for (int j = 0; j < c; ++j) {
+      const double *col = aa_col(W, j);
+#pragma unroll
+      for (int q = 0; q < kAaRhoMax; ++q)
+        if (q < rho) {
+          const long r = r0 + q * 64 + lane;
+          T[(size_t)j * TR + q * 64 + lane] = r < W.rows ? col[r] : 0.;
+        }
+    }
+    __syncthreads();  // (one wave: orders lane 0's writes of E against the other lanes' reads)
+    for (int k = 0; k < npiv; ++k) {
+      double xk[kAaRhoMax], ss[1] = {0.};
+#pragma unroll
+      for (int q = 0; q < kAaRhoMax; ++q) {
+        xk[q] = q < rho ? T[(size_t)k * TR + q * 64 + lane] : 0.;
+        ss[0] += xk[q] * xk[q];
+      }
+      aa_wave_allsum<1>(ss);
+      const double sigma = ss[0], alpha = E[k * c + k];
+      if (sigma == 0.) continue;  // nothing below the diagonal (wave-uniform; a NaN flows on into E)
+      const double nrm = sqrt(alpha * alpha + sigma);
+      const double beta = alpha >= 0. ? -nrm : nrm;
+      const double vp = alpha - beta;
+      const double tau = 1.0 / (nrm * (nrm + fabs(alpha)));  // 2 / v'v
+      for (int j = k + 1; j < c; j += 4) {
+        double tj[4][kAaRhoMax], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[i] = 0.;
+#pragma unroll
+          for (int q = 0; q < kAaRhoMax; ++q) {
+            tj[i][q] = (j + i < c && q < rho) ? T[(size_t)(j + i) * TR + q * 64 + lane] : 0.;
+            d[i] += xk[q] * tj[i][q];
+          }
+        }
+        aa_wave_allsum<4>(d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (j + i < c) {
+            const double ekj = E[k * c + j + i];
+            const double wj = tau * (vp * ekj + d[i]);
+#pragma unroll
+            for (int q = 0; q < kAaRhoMax; ++q)
+              if (q < rho) T[(size_t)(j + i) * TR + q * 64 + lane] = tj[i][q] - wj * xk[q];
+            if (lane == 0) E[k * c + j + i] = ekj - wj * vp;
+          }
+        }
+      }
+      if (lane == 0) E[k * c + k] = beta;
+    }
+    __syncthreads();
+  }
+  for (int t = lane; t < npiv * c; t += 64) {
+    const int i = t / c, j = t - i * c;
+    out[(size_t)j * out_ld + (size_t)blockIdx.x * npiv + i] = E[t];
+  }
+}
+
+// One wavefront: the regularised len x len system from the final triangle R (column-major npiv x c, npiv = len),
+//   type-I : M = R_LL' R_LY (columns len .. 2 len - 1), w = R_LL' R_Lg;   type-II: M = R_YY' R_YY, w = R_YY' R_Yg,
+// LU with partial pivoting (row swaps, then eliminations, the order DeviceAa::dense_solve uses), then the rank / finite /
+// weight-cap tests of aa.c's solve.  Leaves the verdict and gamma in res.
+__global__ __launch_bounds__(64) void k_aa_solve(const double *__restrict__ R, int len, int c, int type1, double regularization,
+                                                 double max_weight_norm, const double *npart, int nnp, double *res) {
+  __shared__ double M[kAaMaxMem * kAaMaxMem], w[kAaMaxMem];
+  const int lane = threadIdx.x;
+  {
+    double s = 0.;
+    for (int i = lane; i < nnp; i += 64) s += npart[i];
+    s = wave_sum(s);
+    if (lane == 0) res[AA_R_NORMG] = sqrt(s);
+  }
+  const int yoff = type1 ? len : 0;
+  for (int e = lane; e < len * len; e += 64) {
+    const int i = e % len, j = e / len;
+    double s = 0.;
+    for (int k = 0; k < len; ++k) s += R[(size_t)i * len + k] * R[(size_t)(yoff + j) * len + k];
+    M[i + len * j] = s;
+  }
+  for (int j = lane; j < len; j += 64) {
+    double s = 0.;
+    for (int k = 0; k < len; ++k) s += R[(size_t)j * len + k] * R[(size_t)(c - 1) * len + k];
+    w[j] = s;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double nrm = 0.;
+    for (int j = 0; j < len; ++j)
+      for (int i = 0; i < len; ++i) nrm += M[i + len * j] * M[i + len * j];
+    const double reg = regularization * sqrt(nrm);
+    if (regularization > 0)
+      for (int i = 0; i < len; ++i) M[i + len * i] += reg;
+    int rank = 0;
+    bool singular = false;
+    for (int k = 0; k < len && !singular; ++k) {
+      int piv = k;
+      double mx = fabs(M[k + len * k]);
+      for (int i = k + 1; i < len; ++i) {
+        const double a = fabs(M[i + len * k]);
+        if (a > mx) { mx = a; piv = i; }
+      }
+      if (!(mx > 0.) || !isfinite(mx)) { singular = true; break; }
+      rank++;
+      if (piv != k) {
+        for (int j = 0; j < len; ++j) { const double t = M[k + len * j]; M[k + len * j] = M[piv + len * j]; M[piv + len * j] = t; }
+        const double t = w[k]; w[k] = w[piv]; w[piv] = t;
+      }
+      for (int i = k + 1; i < len; ++i) {
+        const double f = M[i + len * k] / M[k + len * k];
+        if (f == 0.) continue;
+        for (int j = k + 1; j < len; ++j) M[i + len * j] -= f * M[k + len * j];
+        w[i] -= f * w[k];
+      }
+    }
+    int code = AA_CODE_OK;
+    double nw = 0.;
+    if (rank == 0) code = AA_CODE_RANK0;
+    else if (rank < len) code = AA_CODE_LAPACK;
+    else {
+      for (int k = len - 1; k >= 0; --k) {
+        double s = w[k];
+        for (int j = k + 1; j < len; ++j) s -= M[k + len * j] * w[j];
+        w[k] = s / M[k + len * k];
+      }
+      for (int j = 0; j < len; ++j) nw += w[j] * w[j];
+      nw = sqrt(nw);
+      if (!isfinite(nw)) code = AA_CODE_NONFINITE;
+      else if (nw >= max_weight_norm) code = AA_CODE_WEIGHT;
+    }
+    res[AA_R_OK] = code == AA_CODE_OK ? 1.0 : 0.0;
+    res[AA_R_RANK] = (double)rank;
+    res[AA_R_CODE] = (double)code;
+    res[AA_R_NORM] = nw;
+    res[AA_R_REG] = reg;
+    for (int j = 0; j < len; ++j) res[AA_R_GAMMA + j] = code == AA_CODE_OK ? w[j] : 0.0;
+  }
+}
+
+// f -= D gamma;  optional relaxation: f = beta f + (1-beta) (x - S gamma).  ok != nullptr: the device-side verdict
+// of k_aa_solve (gamma sits right behind it); a rejected step leaves f untouched.
 __global__ __launch_bounds__(kVecThreads) void k_aa_apply(double *f, const double *__restrict__ D, const double *__restrict__ S,
                                                           const double *__restrict__ xcur, const double *__restrict__ gamma,
-                                                          long dim, int len, double relaxation) {
+                                                          long dim, int len, double relaxation, const double *ok) {
+  if (ok && !(*ok != 0.)) return;
   double gm[kAaMaxMem];
 #pragma unroll
   for (int j = 0; j < kAaMaxMem; ++j) gm[j] = j < len ? gamma[j] : 0.;
@@ -141,24 +368,252 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_diffsq(const double *__restr
   acc = block_sum<kVecThreads>(acc, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(kVecThreads) void k_fin_safeguard(const double *part, int np, double factor, double *sc, int *fl) {
+__global__ __launch_bounds__(kVecThreads) void k_fin_safeguard(const double *part, int np, double factor, double *res, int *bad) {
   __shared__ double sm[kVecThreads / 64];
   const double s = part_sum(part, np, sm);
   if (threadIdx.x == 0) {
     const double nd = sqrt(s);
-    sc[S_AA_NORMD] = nd;
+    res[AA_R_NORMD] = nd;
     // NaN-safe: reject unless the new residual is provably no larger
-    fl[F_SAFE_BAD] = (nd <= factor * sc[S_AA_NORMG]) ? 0 : 1;
+    *bad = (nd <= factor * res[AA_R_NORMG]) ? 0 : 1;
   }
 }
 // roll back to the pre-AA iterate when the safeguard fired
 __global__ __launch_bounds__(kVecThreads) void k_aa_restore(double *f_new, double *x_new, const double *__restrict__ af,
-                                                            const double *__restrict__ ax, long dim, const int *fl) {
-  if (!fl[F_SAFE_BAD]) return;
+                                                            const double *__restrict__ ax, long dim, const int *bad) {
+  if (!*bad) return;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < dim; i += (long)gridDim.x * kVecThreads) {
     f_new[i] = af[i];
     x_new[i] = ax[i];
   }
 }
+
+// ================================================================================================ host object
+// Mirrors the control flow of aa.c: apply() / safeguard() / reset(); all vectors are device pointers on `stream`.
+struct DeviceAa {
+  long dim = 0;
+  int mem = 0, type1 = 1, iter = 0, success = 0;
+  double relaxation = 1.0, regularization = 1e-8, safeguard_factor = 1.0, max_weight_norm = 1e10;
+  bool tsqr = true;
+  hipStream_t stream = nullptr;
+  DevBuf<double> x, f, gprev, S, Y, D, npart, spart, part, out, res, gamma, rbuf[2];
+  DevBuf<int> bad;
+  double *h_pin = nullptr;  // pinned: 1 + 3 * kAaMaxMem (Gram partial results) / AA_R_COUNT (TSQR verdict)
+  std::vector<double> M;    // Gram path: raw mem x mem system matrix (col-major), maintained incrementally
+  ScsAaStats st{};
+  bool pending_safeguard = false;
+  double last_norm_g = 0;
+  std::vector<double> last_gamma;  // weights of the last solve (tests: scs_hip_aa_last_gamma)
+
+  DeviceAa() = default;
+  DeviceAa(const DeviceAa &) = delete;
+  DeviceAa &operator=(const DeviceAa &) = delete;
+  ~DeviceAa() { if (h_pin) (void)hipHostFree(h_pin); }
+
+  static bool tsqr_default() {  // SCS_HIP_AA=gram: incremental Gram update + host solve (A/B, tests)
+    const char *e = getenv("SCS_HIP_AA");
+    return !(e && e[0] == 'g');
+  }
+  int nbl() const { return vec_blocks(dim); }
+
+  void init(long dim_, int mem_, int type1_, double regularization_, double relaxation_, double safeguard_factor_,
+            double max_weight_norm_, hipStream_t s) {
+    dim = dim_; mem = mem_; type1 = type1_ ? 1 : 0; regularization = regularization_; relaxation = relaxation_;
+    safeguard_factor = safeguard_factor_; max_weight_norm = max_weight_norm_; stream = s;
+    iter = 0; success = 0; st = ScsAaStats{}; pending_safeguard = false;
+    tsqr = tsqr_default();
+    if (mem <= 0) return;
+    for (DevBuf<double> *b : {&x, &f, &gprev}) b->alloc_zero((size_t)dim, s);
+    for (DevBuf<double> *b : {&S, &Y, &D}) b->alloc_zero((size_t)dim * mem, s);
+    npart.alloc_zero(kMaxVecBlocks, s);
+    spart.alloc_zero(kMaxVecBlocks, s);
+    res.alloc_zero(AA_R_COUNT, s);
+    bad.alloc_zero(1, s);
+    if (!h_pin) HIP_CHECK(hipHostMalloc((void **)&h_pin, sizeof(double) * 256));
+    if (tsqr) {
+      const int c = ncols();
+      const size_t cap = (size_t)c * kTsqrWaves1 * mem;
+      rbuf[0].alloc_zero(cap, s);
+      rbuf[1].alloc_zero((size_t)c * kTsqrWaves2 * mem, s);
+    } else {
+      part.alloc_zero((size_t)3 * kAaMaxMem * kMaxVecBlocks, s);
+      out.alloc_zero(1 + 3 * kAaMaxMem, s);
+      gamma.alloc_zero(kAaMaxMem, s);
+      M.assign((size_t)mem * mem, 0.0);
+    }
+  }
+  void reset() { iter = 0; }
+  int ncols() const { return type1 ? 2 * mem + 1 : mem + 1; }
+
+  static constexpr int kTsqrWaves1 = 1024, kTsqrWaves2 = 16;
+
+  // [L | Y | g] -> final npiv x c triangle (column-major, ld = npiv); returns the device pointer holding it
+  const double *tsqr_factor(int len) {
+    AaTall W{};
+    W.L = type1 ? S.p : Y.p; W.Y = type1 ? Y.p : nullptr; W.g = gprev.p;
+    W.ld = dim; W.rows = dim; W.nL = len; W.nY = type1 ? len : 0; W.c = W.nL + W.nY + 1; W.npiv = len;
+    const int c = W.c, rho = aa_pick_rho(c), TR = 64 * rho;
+    const size_t lds = aa_tsqr_lds(c, len, rho);
+    int level = 0, dst = 0;
+    while (true) {
+      const long ntiles = std::max(1L, (W.rows + TR - 1) / TR);
+      const long cap = level == 0 ? kTsqrWaves1 : kTsqrWaves2;
+      long nw = ntiles <= 8 ? 1 : std::min(ntiles, cap);
+      const long tpw = (ntiles + nw - 1) / nw;
+      nw = (ntiles + tpw - 1) / tpw;
+      double *o = rbuf[dst].p;
+      const long out_ld = nw * len;
+      hipLaunchKernelGGL(k_aa_tsqr, dim3((unsigned)nw), dim3(64), lds, stream, W, rho, tpw, o, out_ld);
+      if (nw == 1) return o;
+      W.L = o; W.Y = nullptr; W.g = nullptr; W.ld = out_ld; W.rows = out_ld; W.nL = c; W.nY = 0;
+      dst ^= 1;
+      ++level;
+    }
+  }
+
+  // f = current map output F(x) (device, may be overwritten with the extrapolated iterate), x = map input.
+  // Returns aa_norm with aa.c's sign convention (0: nothing done, < 0: rejected).
+  double apply(double *fdev, const double *xdev) {
+    double aa_norm = 0;
+    success = 0;
+    if (mem <= 0) return aa_norm;
+    st.iter++;
+    const int nb = nbl();
+    if (iter == 0) {
+      hipLaunchKernelGGL(k_aa_seed, dim3(nb), dim3(kVecThreads), 0, stream, xdev, fdev, x.p, f.p, gprev.p, dim);
+      iter++;
+      return aa_norm;
+    }
+    const int len = std::min(iter, mem), idx = (iter - 1) % mem;
+    hipLaunchKernelGGL(k_aa_update, dim3(nb), dim3(kVecThreads), 0, stream, xdev, fdev, x.p, f.p, gprev.p, S.p, Y.p, D.p, dim,
+                       idx, npart.p);
+    if (tsqr) {
+      if (iter >= mem) {
+        const double *R = tsqr_factor(len);
+        hipLaunchKernelGGL(k_aa_solve, dim3(1), dim3(64), 0, stream, R, len, ncols(), type1, regularization, max_weight_norm,
+                           (const double *)npart.p, nb, res.p);
+        hipLaunchKernelGGL(k_aa_apply, dim3(nb), dim3(kVecThreads), 0, stream, fdev, D.p, S.p, x.p, res.p + AA_R_GAMMA, dim, len,
+                           relaxation, (const double *)res.p + AA_R_OK);
+        HIP_CHECK(hipMemcpyAsync(h_pin, res.p, sizeof(double) * AA_R_COUNT, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        aa_norm = verdict((int)h_pin[AA_R_RANK], (int)h_pin[AA_R_CODE], h_pin[AA_R_NORM], h_pin[AA_R_REG]);
+        last_gamma.assign(h_pin + AA_R_GAMMA, h_pin + AA_R_GAMMA + len);
+        last_norm_g = h_pin[AA_R_NORMG];
+      }
+    } else {
+      const double *L = type1 ? S.p : Y.p;
+      hipLaunchKernelGGL(k_aa_dots, dim3(nb), dim3(kVecThreads), 0, stream, L, Y.p, gprev.p, dim, len, idx, part.p);
+      hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, npart.p, nb, part.p, nb, len, out.p, res.p);
+      HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * (1 + 3 * kAaMaxMem), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      const double *o = h_pin;
+      last_norm_g = std::sqrt(o[0]);
+      for (int j = 0; j < len; ++j) {
+        M[idx + mem * j] = o[1 + 0 * kAaMaxMem + j];  // row idx
+        M[j + mem * idx] = o[1 + 1 * kAaMaxMem + j];  // col idx
+      }
+      if (iter >= mem) {
+        std::vector<double> A((size_t)len * len), w(len);
+        double nrm = 0.;
+        for (int j = 0; j < len; ++j)
+          for (int i = 0; i < len; ++i) {
+            A[i + (size_t)len * j] = M[i + mem * j];
+            nrm += A[i + (size_t)len * j] * A[i + (size_t)len * j];
+          }
+        const double reg = regularization * std::sqrt(nrm);
+        if (regularization > 0)
+          for (int i = 0; i < len; ++i) A[i + (size_t)len * i] += reg;
+        for (int j = 0; j < len; ++j) w[j] = o[1 + 2 * kAaMaxMem + j];
+        const int rank = dense_solve(A.data(), w.data(), len);
+        double nw = 0.;
+        int code = AA_CODE_OK;
+        if (rank == 0) code = AA_CODE_RANK0;
+        else if (rank < len) code = AA_CODE_LAPACK;
+        else {
+          for (int j = 0; j < len; ++j) nw += w[j] * w[j];
+          nw = std::sqrt(nw);
+          if (!std::isfinite(nw)) code = AA_CODE_NONFINITE;
+          else if (nw >= max_weight_norm) code = AA_CODE_WEIGHT;
+        }
+        aa_norm = verdict(rank, code, nw, reg);
+        last_gamma = w;
+        if (code == AA_CODE_OK) {
+          HIP_CHECK(hipMemcpyAsync(gamma.p, w.data(), sizeof(double) * len, hipMemcpyHostToDevice, stream));
+          hipLaunchKernelGGL(k_aa_apply, dim3(nb), dim3(kVecThreads), 0, stream, fdev, D.p, S.p, x.p, gamma.p, dim, len, relaxation,
+                             (const double *)nullptr);
+          HIP_CHECK(hipStreamSynchronize(stream));  // w is a local
+        }
+      }
+    }
+    iter++;
+    return aa_norm;
+  }
+
+  // statistics and control state after a solve (same branches as aa.c's solve)
+  double verdict(int rank, int code, double nw, double reg) {
+    st.last_regularization = reg;
+    st.last_rank = rank;
+    switch (code) {
+      case AA_CODE_RANK0: st.n_reject_rank0++; success = 0; iter = 0; return -1.;
+      case AA_CODE_LAPACK: st.n_reject_lapack++; success = 0; iter = 0; return -1.;
+      default: break;
+    }
+    st.last_aa_norm = nw;
+    if (code == AA_CODE_NONFINITE) { st.n_reject_nonfinite++; success = 0; iter = 0; return -1.; }
+    if (code == AA_CODE_WEIGHT) { st.n_reject_weight_cap++; success = 0; iter = 0; return -nw; }
+    success = 1;
+    st.n_accept++;
+    return nw;
+  }  // (as in aa.c the reset happens inside solve and apply's iter++ follows: the rejected call's (x, f) is the new seed)
+
+  // f_new = F(x_new) after an accepted extrapolation x_new.  Enqueues the residual test and the conditional roll-back;
+  // the verdict lands in *bad_dev (device int) — hand it to safeguard_verdict() once read.  false: nothing to test.
+  bool safeguard(double *f_new, double *x_new, int *bad_dev) {
+    if (!success) return false;
+    success = 0;
+    const int nb = nbl();
+    double *p = spart.p;
+    hipLaunchKernelGGL(k_aa_diffsq, dim3(nb), dim3(kVecThreads), 0, stream, (const double *)x_new, (const double *)f_new, dim, p);
+    hipLaunchKernelGGL(k_fin_safeguard, dim3(1), dim3(kVecThreads), 0, stream, (const double *)p, nb, safeguard_factor, res.p, bad_dev);
+    hipLaunchKernelGGL(k_aa_restore, dim3(nb), dim3(kVecThreads), 0, stream, f_new, x_new, (const double *)f.p, (const double *)x.p,
+                       dim, (const int *)bad_dev);
+    pending_safeguard = true;
+    return true;
+  }
+  void safeguard_verdict(bool rejected) {
+    pending_safeguard = false;
+    if (rejected) { st.n_safeguard_reject++; reset(); }
+  }
+
+  static int dense_solve(double *A, double *rhs, int nn) {
+    int rank = 0;
+    for (int k = 0; k < nn; ++k) {
+      int piv = k;
+      double mx = std::fabs(A[k + nn * k]);
+      for (int i = k + 1; i < nn; ++i) {
+        const double a = std::fabs(A[i + nn * k]);
+        if (a > mx) { mx = a; piv = i; }
+      }
+      if (!(mx > 0.) || !std::isfinite(mx)) return rank;
+      rank++;
+      if (piv != k) {
+        for (int j = 0; j < nn; ++j) std::swap(A[k + nn * j], A[piv + nn * j]);
+        std::swap(rhs[k], rhs[piv]);
+      }
+      for (int i = k + 1; i < nn; ++i) {
+        const double f = A[i + nn * k] / A[k + nn * k];
+        if (f == 0.) continue;
+        for (int j = k + 1; j < nn; ++j) A[i + nn * j] -= f * A[k + nn * j];
+        rhs[i] -= f * rhs[k];
+      }
+    }
+    for (int k = nn - 1; k >= 0; --k) {
+      double s = rhs[k];
+      for (int j = k + 1; j < nn; ++j) s -= A[k + nn * j] * rhs[j];
+      rhs[k] = s / A[k + nn * k];
+    }
+    return rank;
+  }
+};
 
 }  // namespace scship

@@ -35,7 +35,9 @@ namespace scship {
 
 static thread_local std::string g_last_error;
 inline void set_last_error(const std::string &s) { g_last_error = s; }
-static int g_device = 0;
+// default device of scs_init / the standalone entry points of THIS thread (scs_hip_set_device); a workspace remembers
+// the device it was created on and every later call on it selects that device
+static thread_local int g_device = 0;
 
 static double now_ms() {
   using namespace std::chrono;
@@ -329,6 +331,7 @@ static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, c
 
 // ============================================================== workspace
 struct ScsHipWork {
+  int device = 0;  // the HIP device this workspace (stream, buffers, events) lives on
   int n = 0, m = 0;
   long l = 0;
   ScsSettings stgs{};
@@ -430,13 +433,9 @@ struct ScsHipWork {
   }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
-  // AA (host mirrors the control state; heavy lifting on device)
-  int aa_mem = 0, aa_iter = 0, aa_success = 0;
-  bool aa_pending_safeguard = false;
+  // AA (aa.hpp): f = v (map output), x = v_prev (map input); the safeguard verdict rides along with the CG flags
+  DeviceAa aa;
   double aa_norm = 0;
-  std::vector<double> aa_M;  // raw mem x mem system matrix (col-major), maintained incrementally
-  DevBuf<double> aa_x, aa_f, aa_gprev, aa_S, aa_Y, aa_D, aa_gamma, aa_npart;
-  ScsAaStats aa_stats{};
   int rejected_accel = 0, accepted_accel = 0;
 
   // per-solve state
@@ -495,15 +494,11 @@ struct ScsHipWork {
   }
 
   void process_pending_flags() {
-    if (aa_pending_safeguard) {
-      aa_pending_safeguard = false;
-      if (h_flags[F_SAFE_BAD]) {
-        rejected_accel++;
-        aa_stats.n_safeguard_reject++;
-        aa_iter = 0;
-      } else {
-        accepted_accel++;
-      }
+    if (aa.pending_safeguard) {
+      const bool bad = h_flags[F_SAFE_BAD] != 0;
+      aa.safeguard_verdict(bad);
+      if (bad) rejected_accel++;
+      else accepted_accel++;
     }
   }
 
@@ -968,7 +963,7 @@ struct ScsHipWork {
       scale = new_scale;
       set_diag_r();
       update_work_cache();
-      aa_iter = 0;  // reset acceleration
+      aa.reset();  // reset acceleration
       hipLaunchKernelGGL(k_v_rescale, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, rsk.p, u.p, ut.p, diag_r.p, l);
       v_norm_fresh = false;
     }
@@ -976,82 +971,19 @@ struct ScsHipWork {
 
   // --------------------------------------------------------------------- AA
   void aa_apply() {  // f = v (map output), x = v_prev (map input)
-    aa_success = 0;
     aa_norm = 0;
-    if (aa_mem <= 0) return;
-    aa_stats.iter++;
-    const int nbl = vb(l);
-    if (aa_iter == 0) {
-      hipLaunchKernelGGL(k_aa_seed, dim3(nbl), dim3(kVecThreads), 0, stream, v_prev.p, v.p, aa_x.p, aa_f.p, aa_gprev.p, l);
-      aa_iter++;
-      return;
-    }
-    const int len = std::min(aa_iter, aa_mem), idx = (aa_iter - 1) % aa_mem;
-    const double *L = stgs.acceleration_type_1 ? aa_S.p : aa_Y.p;
-    hipLaunchKernelGGL(k_aa_update, dim3(nbl), dim3(kVecThreads), 0, stream, v_prev.p, v.p, aa_x.p, aa_f.p, aa_gprev.p, aa_S.p,
-                       aa_Y.p, aa_D.p, l, idx, aa_npart.p);
-    hipLaunchKernelGGL(k_aa_dots, dim3(nbl), dim3(kVecThreads), 0, stream, L, aa_Y.p, aa_gprev.p, l, len, idx, part.p);
-    hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, aa_npart.p, nbl, part.p, nbl, len, out.p + 64, sc.p);
-    HIP_CHECK(hipMemcpyAsync(h_pin + 64, out.p + 64, sizeof(double) * (1 + 3 * kAaMaxMem), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    const double *o = h_pin + 64;
-    for (int j = 0; j < len; ++j) {
-      aa_M[idx + aa_mem * j] = o[1 + 0 * kAaMaxMem + j];  // row idx
-      aa_M[j + aa_mem * idx] = o[1 + 1 * kAaMaxMem + j];  // col idx
-    }
-    if (aa_iter >= aa_mem) {
-      // regularised dense solve on the host (len <= 32)
-      std::vector<double> M((size_t)len * len), w(len);
-      double nrm = 0.;
-      for (int j = 0; j < len; ++j)
-        for (int i = 0; i < len; ++i) {
-          M[i + (size_t)len * j] = aa_M[i + aa_mem * j];
-          nrm += M[i + (size_t)len * j] * M[i + (size_t)len * j];
-        }
-      const double reg = stgs.acceleration_regularization * std::sqrt(nrm);
-      aa_stats.last_regularization = reg;
-      if (stgs.acceleration_regularization > 0)
-        for (int i = 0; i < len; ++i) M[i + (size_t)len * i] += reg;
-      for (int j = 0; j < len; ++j) w[j] = o[1 + 2 * kAaMaxMem + j];
-      const int rank = dense_solve(M.data(), w.data(), len);
-      aa_stats.last_rank = rank;
-      double nw = 0.;
-      for (int j = 0; j < len; ++j) nw += w[j] * w[j];
-      nw = std::sqrt(nw);
-      bool ok = true;
-      if (rank == 0) { aa_stats.n_reject_rank0++; ok = false; }
-      else if (rank < len) { aa_stats.n_reject_lapack++; ok = false; }
-      else {
-        aa_stats.last_aa_norm = nw;
-        if (!std::isfinite(nw)) { aa_stats.n_reject_nonfinite++; ok = false; }
-        else if (nw >= 1e10) { aa_stats.n_reject_weight_cap++; ok = false; aa_norm = -nw; }
-      }
-      if (!ok) {
-        aa_iter = 0;
-        if (aa_norm == 0) aa_norm = -1.;
-      } else {
-        HIP_CHECK(hipMemcpyAsync(aa_gamma.p, w.data(), sizeof(double) * len, hipMemcpyHostToDevice, stream));
-        v_norm_fresh = false;
-        hipLaunchKernelGGL(k_aa_apply, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, aa_D.p, aa_S.p, aa_x.p, aa_gamma.p, l, len,
-                           stgs.acceleration_relaxation);
-        HIP_CHECK(hipStreamSynchronize(stream));  // w is a local
-        aa_success = 1;
-        aa_stats.n_accept++;
-        aa_norm = nw;
-      }
-    }
-    aa_iter++;
+    if (aa.mem <= 0) return;
+    // acceleration_interval == 1: the verdict of the previous step's safeguard has not been read yet (it rides with the
+    // CG flags of the NEXT linear solve) — a rejected step must reset the history before it is extended
+    if (aa.pending_safeguard) read_flags();
+    aa_norm = aa.apply(v.p, v_prev.p);
+    if (aa.success) v_norm_fresh = false;
   }
 
   void aa_safeguard() {  // f_new = v, x_new = v_prev
-    if (!aa_success) { accepted_accel++; return; }
-    aa_success = 0;
-    const int nbl = vb(l);
-    hipLaunchKernelGGL(k_aa_diffsq, dim3(nbl), dim3(kVecThreads), 0, stream, v_prev.p, v.p, l, part.p);
-    hipLaunchKernelGGL(k_fin_safeguard, dim3(1), dim3(kVecThreads), 0, stream, part.p, nbl, 1.0, sc.p, fl.p);
-    hipLaunchKernelGGL(k_aa_restore, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, aa_f.p, aa_x.p, l, fl.p);
+    if (aa.mem <= 0) return;
+    if (!aa.safeguard(v.p, v_prev.p, fl.p + F_SAFE_BAD)) { accepted_accel++; return; }
     v_norm_fresh = false;
-    aa_pending_safeguard = true;
   }
 
   // one CSV row: residuals of this iteration are already in `r`; diff norms are reduced here
@@ -1062,36 +994,6 @@ struct ScsHipWork {
     HIP_CHECK(hipMemcpyAsync(h_pin + 40, out.p + 40, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     write_csv_row(f, iter, r, scale, h_pin + 40, aa_norm, elapsed_ms / 1e3);
-  }
-
-  static int dense_solve(double *M, double *rhs, int nn) {
-    int rank = 0;
-    for (int k = 0; k < nn; ++k) {
-      int piv = k;
-      double mx = std::fabs(M[k + nn * k]);
-      for (int i = k + 1; i < nn; ++i) {
-        const double a = std::fabs(M[i + nn * k]);
-        if (a > mx) { mx = a; piv = i; }
-      }
-      if (!(mx > 0.) || !std::isfinite(mx)) return rank;
-      rank++;
-      if (piv != k) {
-        for (int j = 0; j < nn; ++j) std::swap(M[k + nn * j], M[piv + nn * j]);
-        std::swap(rhs[k], rhs[piv]);
-      }
-      for (int i = k + 1; i < nn; ++i) {
-        const double f = M[i + nn * k] / M[k + nn * k];
-        if (f == 0.) continue;
-        for (int j = k + 1; j < nn; ++j) M[i + nn * j] -= f * M[k + nn * j];
-        rhs[i] -= f * rhs[k];
-      }
-    }
-    for (int k = nn - 1; k >= 0; --k) {
-      double s = rhs[k];
-      for (int j = k + 1; j < nn; ++j) s -= M[k + nn * j] * rhs[j];
-      rhs[k] = s / M[k + nn * k];
-    }
-    return rank;
   }
 };
 
@@ -1272,6 +1174,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   HIP_CHECK(hipSetDevice(g_device));
 
   std::unique_ptr<ScsHipWork> w(new ScsHipWork());
+  w->device = g_device;
   if (!build_cone(k, w->cone)) throw std::runtime_error("invalid cone");
   if (w->cone.m != d->m) throw std::runtime_error("cone dimensions do not match m");
   const int n = d->n, m = d->m;
@@ -1402,7 +1305,6 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->soly.alloc_zero(m, s);
   w->sols.alloc_zero(m, s);
   w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->At.nwg(), w->Ar.nwg(), w->has_P ? std::max(w->Pf.nblk, w->Pf.nwg()) : 0, kMaxVecBlocks}) * 8;
-  w->part_len = std::max(w->part_len, 3 * kAaMaxMem * kMaxVecBlocks);
   w->part.alloc_zero(w->part_len, s);
   w->part2.alloc_zero(2 * kMaxVecBlocks, s);
   w->part_v.alloc_zero(kMaxVecBlocks, s);
@@ -1451,14 +1353,8 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     HIP_CHECK(hipStreamSynchronize(s));
   }
   // ---- AA workspace ----
-  w->aa_mem = stgs->acceleration_lookback;
-  if (w->aa_mem > 0) {
-    for (DevBuf<double> *b : {&w->aa_x, &w->aa_f, &w->aa_gprev}) b->alloc_zero(l, s);
-    for (DevBuf<double> *b : {&w->aa_S, &w->aa_Y, &w->aa_D}) b->alloc_zero((size_t)l * w->aa_mem, s);
-    w->aa_gamma.alloc_zero(kAaMaxMem, s);
-    w->aa_npart.alloc_zero(kMaxVecBlocks, s);
-    w->aa_M.assign((size_t)w->aa_mem * w->aa_mem, 0.0);
-  }
+  w->aa.init(l, stgs->acceleration_lookback, stgs->acceleration_type_1, stgs->acceleration_regularization,
+             stgs->acceleration_relaxation, /*safeguard_factor=*/1.0, /*max_weight_norm=*/1e10, s);
   mark("vectors, b/c scaling, cones, AA workspace");
   // ---- R, preconditioner, pre-solved g ----
   w->set_diag_r();
@@ -1476,7 +1372,7 @@ static void fill_nan(double *p, long nelem) {
 
 static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) {
   std::lock_guard<std::mutex> lock(w->mtx);
-  HIP_CHECK(hipSetDevice(g_device));
+  HIP_CHECK(hipSetDevice(w->device));
   const double t_start = now_ms();
   const int n = w->n, m = w->m;
   const long l = w->l;
@@ -1491,8 +1387,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
                   w->At.cs.ok ? "column-sorted pass" : w->At.has_slab ? "L2-blocked slab" : "CSR-stream");
   // per-solve state
   w->sum_log_scale_factor = 0; w->n_log_scale_factor = 0; w->last_scale_update_iter = 0; w->scale_updates = 0;
-  w->rejected_accel = 0; w->accepted_accel = 0; w->aa_iter = 0; w->aa_success = 0; w->aa_pending_safeguard = false;
-  w->aa_stats = ScsAaStats{};
+  w->rejected_accel = 0; w->accepted_accel = 0; w->aa_norm = 0;
+  w->aa.reset(); w->aa.success = 0; w->aa.pending_safeguard = false; w->aa.st = ScsAaStats{};
   w->r = Residuals{};
   w->cg_res_min = 0;
   w->tot_cg_iters = 0;
@@ -1563,7 +1459,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   auto is_plain = [&](int it) {
     if (it <= 0 || it >= max_iters - 1 || csv) return false;
     if (it % 25 == 0 || (verbose && it % 250 == 0)) return false;
-    if (w->aa_mem > 0 && it % w->stgs.acceleration_interval == 0) return false;
+    if (w->aa.mem > 0 && it % w->stgs.acceleration_interval == 0) return false;
     if (w->last_cg_iters > 120) return false;  // very long linear solves: enqueue them in adaptive chunks as before
     return true;
   };
@@ -1584,7 +1480,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       w->build_graphs();
       use_graphs = w->graphs_ready;
     }
-    const bool aa_now = w->aa_mem > 0 && i > 0 && (i % w->stgs.acceleration_interval == 0);
+    const bool aa_now = w->aa.mem > 0 && i > 0 && (i % w->stgs.acceleration_interval == 0);
     double t = now_ms();
     if (aa_now) {
       w->aa_apply();
@@ -1707,7 +1603,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   info->cone_time = t_cone;
   info->accel_time = t_acc;
   info->cg_iters = (scs_int)w->tot_cg_iters;
-  info->aa_stats = w->aa_stats;
+  info->aa_stats = w->aa.st;
   info->solve_time = now_ms() - t_start;
   if (verbose) {
     std::printf("------------------------------------------------------------------\n");
@@ -1756,7 +1652,7 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {
   if (!w) return -1;
   try {
     std::lock_guard<std::mutex> lock(w->mtx);
-    HIP_CHECK(hipSetDevice(g_device));
+    HIP_CHECK(hipSetDevice(w->device));
     const int n = w->n, m = w->m;
     if (b) w->b_orig.assign(b, b + m);
     if (c) w->c_orig.assign(c, c + n);
@@ -1789,7 +1685,7 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {
 void scs_finish(ScsWork *w) {
   if (!w) return;
   try {
-    (void)hipSetDevice(g_device);
+    (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
   } catch (...) {
   }
@@ -1843,7 +1739,7 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
   if (!w || !out || reps <= 0) return -1;
   try {
     std::lock_guard<std::mutex> lock(w->mtx);
-    HIP_CHECK(hipSetDevice(g_device));
+    HIP_CHECK(hipSetDevice(w->device));
     hipStream_t s = w->stream;
     const int n = w->n;
     for (int i = 0; i < 2; ++i) w->matvec(w->cg_p.p, nullptr);
@@ -2146,6 +2042,97 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
     set_last_error(e.what());
     return -1;
   }
+}
+
+// ---- Anderson acceleration as a standalone object (row a6): the interface of scs_source/src/aa.c
+// (aa_init / aa_apply / aa_safeguard / aa_reset / aa_finish, named at R:meson.build:187) on host vectors — tests
+// drive it step by step next to the CPU checker.  Inside scs_solve the same DeviceAa works on the resident iterate.
+struct ScsHipAa {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DeviceAa aa;
+  DevBuf<double> f, x;
+  DevBuf<int> bad;
+  ~ScsHipAa() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+ScsHipAa *scs_hip_aa_init(scs_int dim, scs_int mem, scs_int type1, scs_float regularization, scs_float relaxation,
+                          scs_float safeguard_factor, scs_float max_weight_norm) {
+  try {
+    set_last_error("");
+    if (dim <= 0 || mem < 0 || mem > kAaMaxMem) throw std::runtime_error("invalid AA dimensions (lookback must be <= 32)");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) throw std::runtime_error("libscs_hip: no HIP device available");
+    std::unique_ptr<ScsHipAa> a(new ScsHipAa());
+    a->device = g_device;
+    HIP_CHECK(hipSetDevice(a->device));
+    HIP_CHECK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    a->aa.init(dim, mem, type1, regularization, relaxation, safeguard_factor, max_weight_norm, a->stream);
+    a->f.alloc_zero((size_t)dim, a->stream);
+    a->x.alloc_zero((size_t)dim, a->stream);
+    a->bad.alloc_zero(1, a->stream);
+    HIP_CHECK(hipStreamSynchronize(a->stream));
+    return a.release();
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+scs_float scs_hip_aa_apply(ScsHipAa *a, scs_float *f, const scs_float *x) {
+  if (!a || !f || !x) return NAN;
+  try {
+    set_last_error("");
+    HIP_CHECK(hipSetDevice(a->device));
+    a->f.upload(f, (size_t)a->aa.dim, a->stream);
+    a->x.upload(x, (size_t)a->aa.dim, a->stream);
+    const double nrm = a->aa.apply(a->f.p, a->x.p);
+    a->f.download(f, (size_t)a->aa.dim, a->stream);
+    HIP_CHECK(hipStreamSynchronize(a->stream));
+    return nrm;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return NAN;
+  }
+}
+
+scs_int scs_hip_aa_safeguard(ScsHipAa *a, scs_float *f_new, scs_float *x_new) {
+  if (!a || !f_new || !x_new) return -2;
+  try {
+    set_last_error("");
+    HIP_CHECK(hipSetDevice(a->device));
+    a->f.upload(f_new, (size_t)a->aa.dim, a->stream);
+    a->x.upload(x_new, (size_t)a->aa.dim, a->stream);
+    if (!a->aa.safeguard(a->f.p, a->x.p, a->bad.p)) return 0;
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, a->bad.p, sizeof(int), hipMemcpyDeviceToHost, a->stream));
+    a->f.download(f_new, (size_t)a->aa.dim, a->stream);
+    a->x.download(x_new, (size_t)a->aa.dim, a->stream);
+    HIP_CHECK(hipStreamSynchronize(a->stream));
+    a->aa.safeguard_verdict(bad != 0);
+    return bad ? -1 : 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -2;
+  }
+}
+
+void scs_hip_aa_reset(ScsHipAa *a) {
+  if (a) a->aa.reset();
+}
+void scs_hip_aa_get_stats(const ScsHipAa *a, ScsAaStats *st) {
+  if (a && st) *st = a->aa.st;
+}
+scs_int scs_hip_aa_last_gamma(const ScsHipAa *a, scs_float *gamma) {
+  if (!a) return 0;
+  if (gamma) std::copy(a->aa.last_gamma.begin(), a->aa.last_gamma.end(), gamma);
+  return (scs_int)a->aa.last_gamma.size();
+}
+void scs_hip_aa_finish(ScsHipAa *a) {
+  if (!a) return;
+  (void)hipSetDevice(a->device);
+  if (a->stream) (void)hipStreamSynchronize(a->stream);
+  delete a;
 }
 
 __global__ void k_copy4(const double4 *__restrict__ src, double4 *dst, size_t n4) {

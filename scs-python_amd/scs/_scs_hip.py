@@ -161,6 +161,20 @@ def _load():
     lib.scs_hip_time_matvec.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
     lib.scs_hip_copy_bandwidth.argtypes = [C.c_size_t, c_int]
+    lib.scs_hip_aa_init.restype = C.c_void_p
+    lib.scs_hip_aa_init.argtypes = [c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl]
+    lib.scs_hip_aa_apply.restype = c_dbl
+    lib.scs_hip_aa_apply.argtypes = [C.c_void_p, _PD, _PD]
+    lib.scs_hip_aa_safeguard.restype = c_int
+    lib.scs_hip_aa_safeguard.argtypes = [C.c_void_p, _PD, _PD]
+    lib.scs_hip_aa_reset.restype = None
+    lib.scs_hip_aa_reset.argtypes = [C.c_void_p]
+    lib.scs_hip_aa_get_stats.restype = None
+    lib.scs_hip_aa_get_stats.argtypes = [C.c_void_p, C.POINTER(_ScsAaStats)]
+    lib.scs_hip_aa_last_gamma.restype = c_int
+    lib.scs_hip_aa_last_gamma.argtypes = [C.c_void_p, _PD]
+    lib.scs_hip_aa_finish.restype = None
+    lib.scs_hip_aa_finish.argtypes = [C.c_void_p]
     return lib
 
 
@@ -435,8 +449,10 @@ class SCS(object):
         self._s = np.zeros(m)
         work = _lib.scs_init(C.byref(d), C.byref(k), C.byref(st))  # GIL released by ctypes
         if not work:
+            # the reference's message (R:scs/scsobject.h:903-912) + the backend's own reason: invalid data, no GPU,
+            # out of HBM, or a limit this backend has and the reference has not (INTEGRATION.md "Limits")
             self._init_error = last_error()
-            raise ValueError("ScsWork allocation error!")
+            raise ValueError("ScsWork allocation error!" + (" (%s)" % self._init_error if self._init_error else ""))
         self._work = work
 
     # ------------------------------------------------------------------ solve
@@ -646,3 +662,58 @@ def normalize(A, P, b, c, cone):
 
 def copy_bandwidth(nbytes=1 << 30, reps=10):
     return float(_lib.scs_hip_copy_bandwidth(int(nbytes), int(reps)))
+
+
+_AA_STAT_FIELDS = ("iter", "n_accept", "n_reject_lapack", "n_reject_rank0", "n_reject_nonfinite",
+                   "n_reject_weight_cap", "n_safeguard_reject", "last_rank", "last_aa_norm", "last_regularization")
+
+
+class AndersonAccelerator(object):
+    """The device Anderson accelerator of the ADMM loop as a standalone object on host vectors — the
+    aa_init / aa_apply / aa_safeguard / aa_reset interface of the SCS core's aa.c (tests drive it next to the oracle)."""
+
+    def __init__(self, dim, mem, type1=True, regularization=1e-8, relaxation=1.0, safeguard_factor=1.0,
+                 max_weight_norm=1e10):
+        self._h = _lib.scs_hip_aa_init(int(dim), int(mem), 1 if type1 else 0, float(regularization),
+                                       float(relaxation), float(safeguard_factor), float(max_weight_norm))
+        if not self._h:
+            raise RuntimeError("libscs_hip: " + last_error())
+        self.dim = int(dim)
+
+    def apply(self, f, x):
+        """f = F(x).  Returns (aa_norm, f_out): f_out is the extrapolated iterate when the step was accepted."""
+        ff = np.array(f, dtype=np.float64, copy=True)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        assert ff.size == self.dim and xx.size == self.dim
+        nrm = _lib.scs_hip_aa_apply(self._h, _pd(ff), _pd(xx))
+        if nrm != nrm and last_error():
+            raise RuntimeError("libscs_hip: " + last_error())
+        return nrm, ff
+
+    def safeguard(self, f_new, x_new):
+        """Returns (rc, f_new, x_new); rc = -1: rejected, the pair was rolled back to the pre-extrapolation one."""
+        ff = np.array(f_new, dtype=np.float64, copy=True)
+        xx = np.array(x_new, dtype=np.float64, copy=True)
+        rc = _lib.scs_hip_aa_safeguard(self._h, _pd(ff), _pd(xx))
+        if rc == -2:
+            raise RuntimeError("libscs_hip: " + last_error())
+        return rc, ff, xx
+
+    def reset(self):
+        _lib.scs_hip_aa_reset(self._h)
+
+    def stats(self):
+        st = _ScsAaStats()
+        _lib.scs_hip_aa_get_stats(self._h, C.byref(st))
+        return {k: getattr(st, k) for k in _AA_STAT_FIELDS}
+
+    def last_gamma(self):
+        n = _lib.scs_hip_aa_last_gamma(self._h, None)
+        g = np.zeros(max(n, 1))
+        _lib.scs_hip_aa_last_gamma(self._h, _pd(g))
+        return g[:n]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.scs_hip_aa_finish(h)

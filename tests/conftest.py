@@ -22,8 +22,21 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # -m gpu on a box without a GPU must fail loudly, not skip silently
-    pass
+    """`-m gpu` on a box without a usable GPU must FAIL, not pass on skips: every gpu-marked test gets a
+    setup-time check (tests selected without the marker expression are left alone)."""
+    if "gpu" not in (config.getoption("-m") or "") or "not gpu" in (config.getoption("-m") or ""):
+        return
+    if _have_gpu():
+        return
+    for item in items:
+        if item.get_closest_marker("gpu"):
+            item.add_marker(pytest.mark.usefixtures("_require_gpu"))
+
+
+@pytest.fixture
+def _require_gpu():
+    if not _have_gpu():
+        pytest.fail("-m gpu was requested but no HIP device / libscs_hip.so is usable (no CPU fallback exists)")
 
 
 @pytest.fixture(scope="session")

@@ -89,3 +89,40 @@ def proj_hermitian_psd(v, k):
         return np.zeros(0)
     w, U = np.linalg.eigh(cvec_to_herm(v, k))
     return herm_to_cvec((U * np.maximum(w, 0.0)) @ U.conj().T)
+
+
+# ---- independent numpy projections for instance construction at sizes the oracle's Jacobi is too slow for ----
+def svec_to_sym(v, k):
+    """packed PSD-cone slice (lower triangle by column, off-diagonals scaled by sqrt 2) -> symmetric matrix"""
+    X = np.zeros((k, k))
+    p = 0
+    for j in range(k):
+        X[j:, j] = v[p:p + k - j] / np.sqrt(2.0)
+        X[j, j] = v[p]
+        p += k - j
+    return X + np.tril(X, -1).T
+
+
+def sym_to_svec(X):
+    k = X.shape[0]
+    out = []
+    for j in range(k):
+        col = X[j:, j] * np.sqrt(2.0)
+        col[0] = X[j, j]
+        out.append(col)
+    return np.concatenate(out) if out else np.zeros(0)
+
+
+def proj_dual_l_s_numpy(z, K):
+    """Pi_{K*}(z) for cones made of `l` and `s` blocks only (both self-dual), with LAPACK's symmetric eigensolver —
+    independent of the oracle and of the HIP kernels"""
+    assert set(K) <= {"l", "s"}
+    out = np.array(z, dtype=np.float64, copy=True)
+    o = int(K.get("l", 0))
+    out[:o] = np.maximum(out[:o], 0.0)
+    for k in K.get("s", []):
+        d = k * (k + 1) // 2
+        w, U = np.linalg.eigh(svec_to_sym(out[o:o + d], k))
+        out[o:o + d] = sym_to_svec((U * np.maximum(w, 0.0)) @ U.T)
+        o += d
+    return out

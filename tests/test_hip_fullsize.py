@@ -109,3 +109,101 @@ def test_large_qp_solves_to_certificate(hip):
     assert gap <= 1e-6 + 1e-6 * max(abs(x @ px), abs(c @ x), abs(b @ y)) * 1.01
     assert abs(info["pobj"] - p_star) <= 1e-4 * max(1.0, abs(p_star))
     np.testing.assert_allclose(x, x0, rtol=0, atol=2e-4 * max(1.0, np.abs(x0).max()))  # strictly convex: x is unique
+
+
+def _certificate(data, sol, eps, P=None):
+    """SCS's own stopping rule evaluated independently (scipy products, original units); returns the three margins"""
+    A, b, c = data["A"], data["b"], data["c"]
+    x, y, s = sol["x"], sol["y"], sol["s"]
+    ax, aty = A @ x, A.T @ y
+    px = P @ x if P is not None else np.zeros_like(x)
+    pri = np.abs(ax + s - b).max()
+    dua = np.abs(px + aty + c).max()
+    gap = abs(x @ px + c @ x + b @ y)
+    assert pri <= eps + eps * max(np.abs(ax).max(), np.abs(s).max(), np.abs(b).max()) * 1.01, ("pri", pri)
+    assert dua <= eps + eps * max(np.abs(px).max(), np.abs(aty).max(), np.abs(c).max()) * 1.01, ("dual", dua)
+    assert gap <= eps + eps * max(abs(x @ px), abs(c @ x), abs(b @ y)) * 1.01, ("gap", gap)
+
+
+def test_config2_exact_workload_solves_to_certificate(hip):
+    """BASELINE.json configs[1]: random LP+SOC m=2e5 n=1e5 nnz~2e6, indirect CG, AA lookback 10 — the exact workload"""
+    import scs
+    K, n, k, seed = pg.workload("config2_lp_soc")
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: hip.proj_cone(z, K, dual=True))
+    assert data["A"].shape == (200000, 100000)
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-6, eps_rel=1e-6, verbose=False,
+                  acceleration_lookback=10).solve()
+    info = sol["info"]
+    assert info["status"] == "solved", info
+    assert info["aa_stats"]["n_accept"] > 0
+    _certificate(data, sol, 1e-6)
+    assert abs(info["pobj"] - p_star) <= 1e-5 * abs(p_star)
+    s, y = sol["s"], sol["y"]
+    assert s[: K["l"]].min() >= -1e-9 and y[: K["l"]].min() >= -1e-9
+    S, Y = s[K["l"]:].reshape(-1, 10), y[K["l"]:].reshape(-1, 10)
+    assert (np.linalg.norm(S[:, 1:], axis=1) <= S[:, 0] + 1e-7).all() and (np.linalg.norm(Y[:, 1:], axis=1) <= Y[:, 0] + 1e-7).all()
+
+
+def _config3_cone():
+    rng = np.random.default_rng(3)
+    return {"z": 100000, "l": 300000, "bu": rng.uniform(0.5, 2.0, 99999).tolist(), "bl": (-rng.uniform(0.5, 2.0, 99999)).tolist(),
+            "q": [20] * 5000, "ep": 50000, "ed": 50000,
+            "p": (rng.uniform(0.1, 0.9, 33333) * rng.choice([-1.0, 1.0], 33333)).tolist()}
+
+
+def test_config3_projections_full_size_with_box(hip):
+    """every cone type of config 3 at its size, INCLUDING the 99,999-bound box cone: idempotence and Moreau"""
+    K = _config3_cone()
+    m = pg.cone_dims(K)
+    assert m == 999999
+    rng = np.random.default_rng(7)
+    z = rng.standard_normal(m)
+    p = hip.proj_cone(z, K)
+    d = hip.proj_cone(-z, K, dual=True)
+    np.testing.assert_allclose(hip.proj_cone(p, K), p, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(p - d, z, rtol=0, atol=1e-7)
+    assert abs(p @ d) <= 1e-6 * max(1.0, np.linalg.norm(p) * np.linalg.norm(d))
+    # box block: t >= 0 and bl t <= s <= bu t
+    o = K["z"] + K["l"]
+    t, sb = p[o], p[o + 1:o + 100000]
+    assert t >= 0 and (sb <= np.array(K["bu"]) * t + 1e-9).all() and (sb >= np.array(K["bl"]) * t - 1e-9).all()
+
+
+def test_config3_mixed_cones_with_box_solves_to_certificate(hip):
+    """BASELINE.json configs[2]: mixed z/l/box/q/exp/pow, m~1e6 n=5e5 nnz~1e7 — a FULL solve, checked by its KKT
+    certificate in original units, the constructed optimum p*, and cone membership of s through the projections"""
+    import scs
+    K = _config3_cone()
+    data, p_star, _ = pg.gen_feasible(K, 500000, 20, 3, lambda z, K: hip.proj_cone(z, K, dual=True))
+    assert data["A"].nnz > 9e6
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-4, eps_rel=1e-4, verbose=False).solve()
+    info = sol["info"]
+    assert info["status"] == "solved", info
+    _certificate(data, sol, 1e-4)
+    assert abs(info["pobj"] - p_star) <= 1e-3 * max(1.0, abs(p_star))
+    s, y = sol["s"], sol["y"]
+    tol = 1e-5 * max(1.0, np.abs(s).max())
+    np.testing.assert_allclose(hip.proj_cone(s, K), s, rtol=0, atol=tol)
+    np.testing.assert_allclose(hip.proj_cone(y, K, dual=True), y, rtol=0, atol=1e-5 * max(1.0, np.abs(y).max()))
+
+
+def test_config4_psd_heavy_solves_to_certificate(hip):
+    """BASELINE.json configs[3]: s=[200]*50 + l — the batched MFMA eigen-solve path (split mode, warm starts) in a
+    full solve: certificate, p*, and PSD membership of every 200 x 200 block of s and y by LAPACK"""
+    import scs
+    import helpers
+    K = {"l": 1000, "s": [200] * 50}
+    m = pg.cone_dims(K)
+    assert m == 1006000
+    data, p_star, _ = pg.gen_feasible(K, 335000, 30, 4, lambda z, K: hip.proj_cone(z, K, dual=True))
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-4, eps_rel=1e-4, verbose=False).solve()
+    info = sol["info"]
+    assert info["status"] == "solved", info
+    _certificate(data, sol, 1e-4)
+    assert abs(info["pobj"] - p_star) <= 1e-3 * max(1.0, abs(p_star))
+    o, d = K["l"], 200 * 201 // 2
+    for vec in (sol["s"], sol["y"]):
+        assert vec[: K["l"]].min() >= -1e-8
+        scale = max(1.0, np.abs(vec).max())
+        for i in range(50):
+            assert np.linalg.eigvalsh(helpers.svec_to_sym(vec[o + i * d:o + (i + 1) * d], 200)).min() > -1e-6 * scale

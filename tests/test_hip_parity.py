@@ -354,6 +354,29 @@ def test_psd_heavy_parity(hip, oracle):
     _assert_xys(got, {"x": x0, "y": y0, "s": s0})
 
 
+@pytest.mark.parametrize("orders,split", [([40, 64, 100], "1"), ([40, 64, 100], "0"), ([200] * 3, "1"), ([33, 128], "0")])
+def test_psd_large_orders_warm_path_in_solve(hip, monkeypatch, orders, split):
+    """The order > 32 kernel INSIDE a solve: MFMA block Jacobi warm-started from the previous call's eigenvectors,
+    Newton-Schulz re-orthogonalisation every 32 calls, second-order reconstruction, split mode (config 4 lives here).
+    Strictly convex QP with n >= m: x, y, s are unique, so the answer is compared entry-wise with the optimum the
+    instance was constructed from (numpy/LAPACK projections — no oracle, no HIP kernel in the construction)."""
+    monkeypatch.setenv("SCS_HIP_PSD_SPLIT", split)
+    K = {"l": 50, "s": orders}
+    m = pg.cone_dims(K)
+    data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, m + 2, 6, 40 + len(orders), helpers.proj_dual_l_s_numpy)
+    got = hip.SCS(*helpers.raw_args(data, K), **STG).solve(False, None, None, None)
+    assert got["info"]["status"] == "solved", got["info"]
+    assert got["info"]["iter"] > 64  # past the first re-orthogonalisation
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+    _assert_xys(got, {"x": x0, "y": y0, "s": s0})
+    o = K["l"]
+    for k in orders:  # membership: eigenvalues of the s and y blocks
+        d = k * (k + 1) // 2
+        for vec in (got["s"], got["y"]):
+            assert np.linalg.eigvalsh(helpers.svec_to_sym(vec[o:o + d], k)).min() > -1e-7 * max(1.0, np.abs(vec[o:o + d]).max())
+        o += d
+
+
 # ---- complex PSD cone `cs` (SURVEY §8 f3) ---------------------------------------------------------------------
 @pytest.mark.parametrize("orders", [[1], [2], [3], [5, 4], [8, 1, 0, 13], [40], [100]])
 def test_cs_projection_vs_oracle_and_complex_eigh(hip, oracle, orders):
@@ -456,8 +479,9 @@ def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
     sols = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("SCS_HIP_PSD_SPLIT", mode)
-        sols[mode] = hip.SCS(*args, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iters=300).solve(False, None, None, None)
+        sols[mode] = hip.SCS(*args, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iters=5000).solve(False, None, None, None)
     assert sols["0"]["info"]["iter"] == sols["1"]["info"]["iter"]
+    assert sols["0"]["info"]["status"] == sols["1"]["info"]["status"] == "solved", sols["0"]["info"]
     for key in ("x", "y", "s"):
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
 

@@ -2,26 +2,37 @@
 """bench.py — ADMM iterations/sec of the MI355X-native SCS hot path + SpMV roofline.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-  * workload (N=1): the configuration BASELINE.json's metric is quoted on — random LP+SOC cone
-    program m=2e6, n=1e6, nnz~2e7 (problem_gen.workload("target_lp_soc")), synthetic, seeded.
-  * a "step" = one ADMM iteration of the reference's hot path (KKT solve by PCG over A/A' on the
-    device, cone projection, dual update, AA every 10th, convergence check every 25th).  The timed
-    region is ONE scs.SCS(...).solve() call that executes EXACTLY K iterations from a cold start
-    (max_iters=K, eps=0 so the termination test can never fire early); inputs are resident in HBM
-    (scs_init uploaded them) when the timed region starts.  Warm-up = a separate solver instance
-    running W iterations on the same data.
-  * N>1 (torchrun, one rank per GPU): every rank solves its own independent instance of the same
-    size (seed + rank) — the path shards across problems with no data-path collective
-    (SURVEY §8e); value = sum of iterations over ranks / max time; the solutions are then
-    collected with one RCCL gather, outside the timed region.
-  * roofline: dominant kernel = the CG-step SpMV pair.  Its average launch duration is measured
-    live inside the timed solve with HIP events on the solver's own stream (scs_hip_kernel_times).
-  * cpu_baseline (rank 0, N=1): the oracle's CPU-CG variant ("port", 1 thread) on the same
-    instance for the first few iterations.
+  * N > 1 without a launcher (WORLD_SIZE unset): this process starts N ranks itself
+    (`python -m torch.distributed.run --nproc-per-node N ... bench.py`, rendezvous on 127.0.0.1) BEFORE it
+    touches the GPU, forwards rank 0's JSON line and exits with the children's code.  Under torchrun
+    (WORLD_SIZE set) it is one of the ranks; WORLD_SIZE != --gpus is an error.
+  * workload (per GPU): the configuration BASELINE.json's metric is quoted on — random LP+SOC cone program
+    m=2e6, n=1e6, nnz~2e7 (problem_gen.workload("target_lp_soc")), synthetic, seeded (seed + rank).
+  * a "step" = one ADMM iteration of the reference's hot path (KKT solve by PCG over A/A' on the device, cone
+    projection, dual update, AA every 10th, convergence check every 25th).  The timed region is ONE
+    scs.SCS(...).solve() that executes EXACTLY K iterations from a cold start (max_iters=K, eps=0 so the
+    termination test can never fire); inputs are resident in HBM (scs_init uploaded them) when it starts.
+    Warm-up = a separate solver instance running W iterations on the same data.  Barrier + device sync on both
+    sides, MAX over ranks, value = sum of iterations over ranks / that time ("weak" scaling: the path shards across
+    independent problems, no data-path collective — SURVEY §8e); the solutions are then collected with one RCCL
+    gather outside the timed region.
+  * The iteration rate depends on how many CG steps an iteration needs (12 in the first 20 iterations of a cold
+    start, 8 later), so the line also carries the step-count-independent figures `cg_steps_per_s` / `ms_per_cg_step`
+    and a second window, `steady_window`: iterations [120, 220) of one longer solve (timestamp taken inside the
+    solve), in which the Anderson extrapolations and their safeguards run (the first one fires at iteration 110).
+  * roofline: dominant kernel = the CG-step SpMV pair, average launch duration measured live with HIP events on
+    the solver's own stream (scs_hip_kernel_times / scs_hip_time_matvec).
+  * cpu_baseline (rank 0, N=1): the oracle's CPU-CG variant ("port", 1 thread) on the same instance for the first
+    few iterations, plus the oracle's sparse-LDL' direct variant on config 1 (direct factorisation of config 2 and
+    of the target is infeasible: stated in the JSON).
+  * config5_batch: BASELINE.json configs[4] — 512 independent small cone programs sharded round-robin over the
+    ranks, `threads` in flight per GPU (one stream each), one gather of the solutions; aggregate ADMM iters/s.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,11 +45,15 @@ for p in (ROOT, os.path.join(ROOT, "scs-python_amd")):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)     # the driver's values
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="target_lp_soc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--no-steady", action="store_true", help="skip the AA-inclusive window (iterations 120..220)")
+    ap.add_argument("--no-batch", action="store_true", help="skip the config-5 batch leg")
+    ap.add_argument("--batch-problems", type=int, default=512)
+    ap.add_argument("--batch-threads", type=int, default=16)
     # testing aids (the driver never passes these): run the N>1 flow on a 1-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--force-device", type=int, default=None)
@@ -50,17 +65,37 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
 
 
+def launch_ranks(args):
+    """--gpus N without a launcher: become the launcher.  Nothing here has touched the GPU (no torch import, no HIP
+    call), the ranks are fresh child processes, and this process only forwards their output and exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
+                         % (args.gpus, world, args.gpus))
 
     import torch  # first: its bundled HIP runtime must be the one in the process
     import torch.distributed as dist
     import numpy as np
     import scs
     from scs import _scs_hip
+    from scs import batch as scs_batch
     import problem_gen as pg
 
     if _scs_hip.device_count() < 1:
@@ -80,10 +115,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max_sum(t_local, n_local):
+        tm = torch.tensor([t_local], dtype=torch.float64, device=coll_dev)
+        ns = torch.tensor([float(n_local)], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        return float(tm.item()), float(ns.item())
+
+    proj = lambda z, K: _scs_hip.proj_cone(z, K, dual=True)  # noqa: E731
+
     # ---------------- synthetic instance (per rank) ----------------
     K, n, k, seed = pg.workload(args.workload)
     t0 = time.perf_counter()
-    data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, lambda z, K: _scs_hip.proj_cone(z, K, dual=True))
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, proj)
     m = data["A"].shape[0]
     nnz = int(data["A"].nnz)
     t_gen = time.perf_counter() - t0
@@ -109,14 +154,8 @@ def main():
     assert info["iter"] == args.steps, (info["iter"], args.steps, info["status"])
     kt = solver._solver._kernel_times()          # in-situ samples (one CG step per host sync)
     kb = solver._solver._time_matvec(reps=30)    # back-to-back batch, event overhead amortised
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-    its = torch.tensor([float(info["iter"])], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(its, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tmax.item())
-    total_iters = float(its.item())
+    elapsed_max, total_iters = reduce_max_sum(elapsed, info["iter"])
+    _, total_cg = reduce_max_sum(elapsed, info["cg_iters"])
 
     # ---------------- single RCCL gather of the solutions (outside the timed region) ----------------
     gather_ms = None
@@ -128,6 +167,70 @@ def main():
         dist.gather(payload, bufs, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        del bufs, payload
+    del solver
+
+    # ---------------- steady window: iterations [120, 220) of one solve, Anderson steps inside ----------------
+    steady = None
+    if not args.no_steady:
+        mark, span = 120, 100
+        ssolver = scs.SCS(data, K, max_iters=mark + span, **common)
+        ssolver._solver._set_mark(mark)
+        barrier()
+        ssol = ssolver.solve(warm_start=False)
+        sinfo, mk = ssol["info"], ssolver._solver._get_mark()
+        win_ms = sinfo["solve_time"] - mk["ms"]
+        win_cg = sinfo["cg_iters"] - mk["cg_iters"]
+        w_max, w_iters = reduce_max_sum(win_ms * 1e-3, span)
+        _, w_cg = reduce_max_sum(0.0, win_cg)
+        steady = {
+            "window": "ADMM iterations [%d, %d) of one cold-started solve (timestamp inside scs_solve, stream drained)" % (mark, mark + span),
+            "value": round(w_iters / w_max, 3), "unit": "ADMM iters/s", "ms_per_step": round(w_max * 1e3 / span, 4),
+            "cg_steps_per_admm_iter": round(w_cg / w_iters, 2), "cg_steps_per_s": round(w_cg / w_max, 1),
+            "aa_calls_in_window": sinfo["aa_stats"]["iter"] - mk["aa_calls"],
+            "aa_accepted_in_window": sinfo["aa_stats"]["n_accept"] - mk["aa_accept"],
+            "aa_safeguard_rejects_total": sinfo["aa_stats"]["n_safeguard_reject"],
+            "accel_ms_total": round(sinfo["accel_time"], 2),
+        }
+        del ssolver
+
+    # ---------------- config 5: batch of independent small problems, sharded over the ranks ----------------
+    batch_leg = None
+    if not args.no_batch:
+        Kb, nb_, kb_, seedb = pg.workload("config5_small")
+        NB = args.batch_problems
+        mine = set(scs_batch.shard_indices(NB, rank, world))
+        mb = pg.cone_dims(Kb)
+        tgen = time.perf_counter()
+        problems = []
+        for i in range(NB):  # a rank only generates (and touches) its own shard
+            if i in mine:
+                d_i, _, _ = pg.gen_feasible(Kb, nb_, kb_, seedb + i, proj)
+                problems.append((d_i, Kb, dict(verbose=False)))
+            else:
+                problems.append(None)
+        tgen = time.perf_counter() - tgen
+        dims = [(nb_, mb)] * NB
+        # warm the kernels of this shape once (code objects, allocator)
+        scs.SCS(problems[min(mine)][0], Kb, verbose=False, max_iters=50, linear_solver=scs.LinearSolver.HIP_INDIRECT).solve()
+        barrier()
+        tb = time.perf_counter()
+        res = scs_batch.solve_sharded(problems, dims=dims, threads=args.batch_threads, device=coll_dev)
+        torch.cuda.synchronize()
+        barrier()
+        tb = time.perf_counter() - tb
+        tb_max, _ = reduce_max_sum(tb, 0)
+        if rank == 0:
+            its = sum(r["info"]["iter"] for r in res)
+            ok = sum(r["info"]["status_val"] == 1 for r in res)
+            batch_leg = {
+                "workload": "config5: %d independent problems, each cone={'l': 2000, 'q': '20x50', 's': '5x20'} m=%d n=%d, seeds %d..%d, "
+                            "default settings (eps 1e-4), problem i -> rank i %% %d, %d in flight per GPU, one gather of [x|y|s]"
+                            % (NB, mb, nb_, seedb, seedb + NB - 1, world, args.batch_threads),
+                "value": round(its / tb_max, 1), "unit": "ADMM iters/s (aggregate, wall time incl. scs_init and the gather)",
+                "problems_per_s": round(NB / tb_max, 2), "solved": int(ok), "problems": NB, "total_iters": int(its),
+                "wall_s": round(tb_max, 3), "gen_s_rank0": round(tgen, 2), "n_gpus": world,
+            }
 
     if rank != 0:
         if world > 1:
@@ -155,14 +258,16 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the
     # committed rocprofv3 --pmc passes on the same matrix shape are used when the workload matches.
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        if pmc.get("workload") == args.workload:
-            kk = pmc["K1" if k1_avg >= k2_avg else "K2"]
-            traffic = int((2 * kk["FETCH_SIZE_KiB"] + kk["WRITE_SIZE_KiB"]) * 1024)
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                pmc = json.load(f)
+            if pmc.get("workload") == args.workload:
+                kk = pmc["K1" if k1_avg >= k2_avg else "K2"]
+                traffic = int((2 * kk["FETCH_SIZE_KiB"] + kk["WRITE_SIZE_KiB"]) * 1024)
+                break
+        except (OSError, KeyError, ValueError):
+            traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(dom[3], 1), "peak": HBM_PEAK, "unit": "GB/s",
         "frac": round(dom[3] / HBM_PEAK, 4), "traffic": traffic,
@@ -174,7 +279,7 @@ def main():
                "in_situ_event_ms": round(k2_situ, 5)},
     }
 
-    # ---------------- CPU baseline (oracle CPU-CG, 1 thread, bounded sample) ----------------
+    # ---------------- CPU baseline (oracle, 1 thread, bounded samples) ----------------
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import scs_oracle  # the checker, timed beside the product; never in the product path
@@ -185,15 +290,31 @@ def main():
         gsolver = scs.SCS(data, K, max_iters=ci, **common)
         gsol = gsolver.solve(warm_start=False)
         gpu_ms = gsol["info"]["solve_time"]
+        # the "QDLDL path": the oracle's sparse LDL' direct variant.  Its factorisation of config 2 (KKT order 3e5,
+        # random pattern => catastrophic fill) did not finish in 900 s on an 8-core Xeon, so it is timed on the
+        # reference's own CPU-runnable case, config 1 (BASELINE.json configs[0]), with the HIP path beside it.
+        K1c, n1, k1c, s1 = pg.workload("config1_lp")
+        d1, _, _ = pg.gen_feasible(K1c, n1, k1c, s1, proj)
+        st1 = dict(eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False, acceleration_lookback=10, max_iters=200)
+        dref = scs_oracle.solve(d1, K1c, indirect=False, **st1)
+        dgpu = scs.SCS(d1, K1c, linear_solver=scs.LinearSolver.HIP_INDIRECT, **st1).solve(warm_start=False)
         cpu_baseline = {
             "value": round(ci / (cpu_ms * 1e-3), 5), "unit": "ADMM iters/s", "cores": 1, "kind": "port",
-            "sample": "first %d ADMM iterations (cold start, %d CG steps) of the same instance on the "
-                      "oracle's CPU-CG variant: %.1f s; the HIP path runs the same %d iterations "
-                      "(%d CG steps) in %.3f s; host has %d cores" % (
-                          ci, ref["info"]["cg_iters"], cpu_ms * 1e-3, ci, gsol["info"]["cg_iters"],
-                          gpu_ms * 1e-3, os.cpu_count()),
+            "sample": "first %d ADMM iterations (cold start, %d CG steps) of the same instance on the oracle's "
+                      "CPU-CG variant: %.1f s; the HIP path runs the same %d iterations (%d CG steps) in %.3f s; "
+                      "host has %d cores" % (ci, ref["info"]["cg_iters"], cpu_ms * 1e-3, ci, gsol["info"]["cg_iters"],
+                                             gpu_ms * 1e-3, os.cpu_count()),
+            "direct_ldl": {
+                "workload": "config1_lp: m=%d n=%d nnz=%d (BASELINE.json configs[0])" % (d1["A"].shape[0], n1, d1["A"].nnz),
+                "value": round(200 / (dref["info"]["solve_time"] * 1e-3), 2), "unit": "ADMM iters/s", "cores": 1,
+                "factorization_s": round(dref["info"]["setup_time"] * 1e-3, 2),
+                "hip_same_workload_iters_per_s": round(200 / (dgpu["info"]["solve_time"] * 1e-3), 1),
+                "target_and_config2": "direct infeasible: the LDL' factorisation of config 2 (m=2e5, n=1e5) did not finish "
+                                      "in 900 s / 8-core Xeon (random sparsity pattern, fill-in); the target is 10x larger",
+            },
         }
 
+    cg_per_s = total_cg / elapsed_max
     out = {
         "metric": "ADMM iters/sec (random LP+SOC cone program, indirect CG linsys, AA lookback 10)",
         "value": round(total_iters / elapsed_max, 4),
@@ -206,14 +327,19 @@ def main():
             "workload": "%s: m=%d n=%d nnz=%d cone=%s seed=%d(+rank); one independent instance per GPU" % (
                 args.workload, m, n, nnz, {kk: (vv if not isinstance(vv, list) else "%dx%s" % (len(vv), vv[0]))
                                            for kk, vv in K.items()}, seed),
+            "world_size_seen": world, "backend": args.dist_backend if world > 1 else None,
             "cg_steps_per_admm_iter": round(info["cg_iters"] / max(info["iter"], 1), 2),
+            "cg_steps_per_s": round(cg_per_s, 1), "ms_per_cg_step": round(1e3 / cg_per_s * world, 4),
             "admm_iters_timed": int(info["iter"]),
+            "aa_extrapolations_in_timed_region": int(info["aa_stats"]["n_accept"]),
             "lin_sys_ms": round(info["lin_sys_time"], 1), "cone_ms": round(info["cone_time"], 1),
             "accel_ms": round(info["accel_time"], 1), "setup_ms": round(info["setup_time"], 1),
             "gen_s": round(t_gen, 1), "gather_ms": gather_ms,
         },
+        "steady_window": steady,
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "config5_batch": batch_leg,
     }
     print(json.dumps(out))
     sys.stdout.flush()

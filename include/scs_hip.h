@@ -53,10 +53,12 @@ size_t scs_sizeof_float(void);
 
 /* number of visible HIP devices (0 => library unusable); does not initialise a context */
 int scs_hip_device_count(void);
-/* choose the device used by subsequent scs_init calls (and the kernel-level entry points below) of the CALLING THREAD
- * (default 0).  A workspace remembers the device it was created on: scs_solve / scs_update / scs_finish select it
- * themselves, so one process may drive several GPUs, one workspace per device and thread. */
+/* choose the device used by subsequent scs_init calls (and the kernel-level entry points below): the process-wide
+ * default (0 at start), or — set_thread_device, dev < 0 clears it — a default of the calling thread only.  A workspace
+ * remembers the device it was created on: scs_solve / scs_update / scs_finish select it themselves, so one process
+ * may drive several GPUs. */
 int scs_hip_set_device(int dev);
+int scs_hip_set_thread_device(int dev);
 
 /* y (+)= A x or A' x through the hot-path SpMV kernels (row a3; plays the role
  * of scs_source/linsys/scs_matrix.c accum_by_a / accum_by_atrans, R:meson.build:199-202).
@@ -100,6 +102,11 @@ double scs_hip_copy_bandwidth(size_t bytes, int reps);
  * where K1 = z <- R_y^{-1} A p  and  K2 = Gp <- A' z + R_x p (+ P p). */
 void scs_hip_set_profiling(ScsWork *w, int on);
 void scs_hip_kernel_times(const ScsWork *w, double *out);
+/* bench.py: a timestamp inside the next scs_solve calls.  When ADMM iteration `iter` is about to start, the stream is
+ * drained and out[4] = {ms since the start of the solve, CG steps so far, Anderson calls so far, accepted so far} is
+ * recorded (out[0] < 0: the solve ended before that iteration); iter < 0 switches it off. */
+void scs_hip_set_mark(ScsWork *w, int iter);
+void scs_hip_get_mark(const ScsWork *w, double *out);
 /* `reps` back-to-back launches of K1 and then of K2 on the solver's own stream and HBM-resident
  * data, one HIP event pair per batch (the ~10-20 us per-event overhead is amortised).
  * out[2] = {K1 avg ms, K2 avg ms}.  Returns 0 on success. */

@@ -14,6 +14,7 @@
 //   u   = Pi_{R^n x K* x R+}(2 u_t - v)
 //   rsk = R (v + u - 2 u_t)   (only when residuals are needed)
 //   v  += alpha (u - u_t)
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <memory>
@@ -35,9 +36,12 @@ namespace scship {
 
 static thread_local std::string g_last_error;
 inline void set_last_error(const std::string &s) { g_last_error = s; }
-// default device of scs_init / the standalone entry points of THIS thread (scs_hip_set_device); a workspace remembers
-// the device it was created on and every later call on it selects that device
-static thread_local int g_device = 0;
+// Device of the NEXT scs_init / standalone entry point: the process default (scs_hip_set_device) unless the calling
+// thread has its own (scs_hip_set_thread_device).  A workspace remembers the device it was created on and every later
+// call on it selects that device, so one process may drive several GPUs.
+static std::atomic<int> g_default_device{0};
+static thread_local int t_device = -1;
+static int current_device() { return t_device >= 0 ? t_device : g_default_device.load(); }
 
 static double now_ms() {
   using namespace std::chrono;
@@ -452,6 +456,12 @@ struct ScsHipWork {
   bool profile = false;
   double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
   long prof_n[2] = {0, 0};
+  // bench.py: a timestamp INSIDE a solve (scs_hip_set_mark): when iteration mark_iter is about to start the stream is
+  // drained and the elapsed time / counters are recorded, so a window that starts past the cold start can be timed
+  int mark_iter = -1;
+  double mark_ms = -1;
+  long mark_cg = 0;
+  int mark_aa_calls = 0, mark_aa_accept = 0;
   std::mutex mtx;
 
   ~ScsHipWork() {
@@ -1171,10 +1181,10 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     throw std::runtime_error("libscs_hip: no HIP device available (this backend has no CPU fallback)");
-  HIP_CHECK(hipSetDevice(g_device));
+  HIP_CHECK(hipSetDevice(current_device()));
 
   std::unique_ptr<ScsHipWork> w(new ScsHipWork());
-  w->device = g_device;
+  w->device = current_device();
   if (!build_cone(k, w->cone)) throw std::runtime_error("invalid cone");
   if (w->cone.m != d->m) throw std::runtime_error("cone dimensions do not match m");
   const int n = d->n, m = d->m;
@@ -1457,14 +1467,22 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   // an iteration is "plain" when the host has nothing to decide in it: no convergence check / print / log row,
   // no Anderson step, not the last one.  Plain iterations may be enqueued whole, and one ahead (run-ahead mode).
   auto is_plain = [&](int it) {
-    if (it <= 0 || it >= max_iters - 1 || csv) return false;
+    if (it <= 0 || it >= max_iters - 1 || csv || it == w->mark_iter) return false;
     if (it % 25 == 0 || (verbose && it % 250 == 0)) return false;
     if (w->aa.mem > 0 && it % w->stgs.acceleration_interval == 0) return false;
     if (w->last_cg_iters > 120) return false;  // very long linear solves: enqueue them in adaptive chunks as before
     return true;
   };
   int enq_upto = -1;  // run-ahead: last iteration already in the queue
+  w->mark_ms = -1;
   for (i = 0; i < max_iters; ++i) {
+    if (i == w->mark_iter) {
+      HIP_CHECK(hipStreamSynchronize(s));
+      w->mark_ms = now_ms() - t_start;
+      w->mark_cg = w->tot_cg_iters;
+      w->mark_aa_calls = w->aa.st.iter;
+      w->mark_aa_accept = w->aa.st.n_accept;
+    }
     if (run_ahead && (enq_upto >= i || is_plain(i))) {  // (already queued: is_plain may have changed its mind since)
       double t = now_ms();
       if (enq_upto < i) { w->enqueue_plain_iteration(i); enq_upto = i; }
@@ -1728,7 +1746,13 @@ int scs_hip_device_count(void) {
 int scs_hip_set_device(int dev) {
   int n = scs_hip_device_count();
   if (dev < 0 || dev >= n) return -1;
-  g_device = dev;
+  g_default_device.store(dev);
+  return 0;
+}
+int scs_hip_set_thread_device(int dev) {
+  if (dev < 0) { t_device = -1; return 0; }
+  if (dev >= scs_hip_device_count()) return -1;
+  t_device = dev;
   return 0;
 }
 const char *scs_hip_last_error(void) { return g_last_error.c_str(); }
@@ -1762,6 +1786,14 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
   }
 }
 
+void scs_hip_set_mark(ScsWork *w, int iter) {
+  if (w) w->mark_iter = iter;
+}
+void scs_hip_get_mark(const ScsWork *w, double *out) {
+  if (!w || !out) return;
+  out[0] = w->mark_ms; out[1] = (double)w->mark_cg; out[2] = (double)w->mark_aa_calls; out[3] = (double)w->mark_aa_accept;
+}
+
 void scs_hip_set_profiling(ScsWork *w, int on) {
   if (w) w->profile = on != 0;
 }
@@ -1779,7 +1811,7 @@ struct TmpStream {
   TmpStream() {
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) throw std::runtime_error("libscs_hip: no HIP device available");
-    HIP_CHECK(hipSetDevice(g_device));
+    HIP_CHECK(hipSetDevice(current_device()));
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   }
   ~TmpStream() { if (s) (void)hipStreamDestroy(s); }
@@ -2064,7 +2096,7 @@ ScsHipAa *scs_hip_aa_init(scs_int dim, scs_int mem, scs_int type1, scs_float reg
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) throw std::runtime_error("libscs_hip: no HIP device available");
     std::unique_ptr<ScsHipAa> a(new ScsHipAa());
-    a->device = g_device;
+    a->device = current_device();
     HIP_CHECK(hipSetDevice(a->device));
     HIP_CHECK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     a->aa.init(dim, mem, type1, regularization, relaxation, safeguard_factor, max_weight_norm, a->stream);

@@ -139,6 +139,8 @@ def _load():
     lib.scs_hip_device_count.restype = c_int
     lib.scs_hip_set_device.restype = c_int
     lib.scs_hip_set_device.argtypes = [c_int]
+    lib.scs_hip_set_thread_device.restype = c_int
+    lib.scs_hip_set_thread_device.argtypes = [c_int]
     lib.scs_hip_last_error.restype = C.c_char_p
     lib.scs_hip_spmv.restype = c_int
     lib.scs_hip_spmv.argtypes = [C.POINTER(_ScsMatrix), _PD, _PD, c_int]
@@ -157,6 +159,10 @@ def _load():
     lib.scs_hip_set_profiling.argtypes = [C.c_void_p, c_int]
     lib.scs_hip_kernel_times.restype = None
     lib.scs_hip_kernel_times.argtypes = [C.c_void_p, _PD]
+    lib.scs_hip_set_mark.restype = None
+    lib.scs_hip_set_mark.argtypes = [C.c_void_p, c_int]
+    lib.scs_hip_get_mark.restype = None
+    lib.scs_hip_get_mark.argtypes = [C.c_void_p, _PD]
     lib.scs_hip_time_matvec.restype = c_int
     lib.scs_hip_time_matvec.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
@@ -200,6 +206,12 @@ def device_count():
 def set_device(dev):
     if _lib.scs_hip_set_device(int(dev)) != 0:
         raise ValueError("invalid HIP device %r" % (dev,))
+
+
+def set_thread_device(dev):
+    """device of the calling THREAD's subsequent SCS(...) constructions (None / negative: back to the process default)"""
+    if _lib.scs_hip_set_thread_device(-1 if dev is None else int(dev)) != 0:
+        raise ValueError("invalid HIP device index %r" % (dev,))
 
 
 def last_error():
@@ -552,6 +564,14 @@ class SCS(object):
             _lib.scs_hip_kernel_times(self._work, _pd(out))
         return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
                 "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7])}
+
+    def _set_mark(self, it):
+        _lib.scs_hip_set_mark(self._work, int(it))
+
+    def _get_mark(self):
+        out = np.zeros(4)
+        _lib.scs_hip_get_mark(self._work, _pd(out))
+        return {"ms": float(out[0]), "cg_iters": int(out[1]), "aa_calls": int(out[2]), "aa_accept": int(out[3])}
 
     def _time_matvec(self, reps=20):
         out = np.zeros(2)

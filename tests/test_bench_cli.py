@@ -1,0 +1,72 @@
+"""bench.py's command-line contract: `--gpus N` really runs N ranks (the process becomes the launcher when no
+launcher started it), and a world size that contradicts --gpus is an error rather than a silently wrong line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_world_size_mismatch_is_refused():
+    """no GPU needed: the check runs before anything is imported"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=3" in r.stderr and "--gpus 2" in r.stderr
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def _last_json(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_gpus_2_spawns_two_ranks_on_one_gpu_box():
+    """`python bench.py --gpus 2` with no launcher: two ranks are started (torch.distributed.run), here both on device
+    0 with the gloo backend (a 1-GPU box); rank 0 prints the one JSON line with n_gpus = 2 = the world size it saw,
+    the batch leg covers every problem exactly once across the ranks."""
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "2", "--workload", "config2_lp_soc",
+           "--dist-backend", "gloo", "--force-device", "0", "--batch-problems", "12", "--batch-threads", "4"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["world_size_seen"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["steps"] == 20 and out["config"]["admm_iters_timed"] == 20
+    assert out["value"] > 0 and abs(out["value"] - 2 * 20 / (out["ms_per_step"] * 20 * 1e-3)) < 1e-2 * out["value"]
+    assert out["cpu_baseline"] is None  # N = 1 only
+    assert out["steady_window"]["aa_calls_in_window"] == 10 and out["steady_window"]["value"] > 0
+    b = out["config5_batch"]
+    assert b["n_gpus"] == 2 and b["problems"] == 12 and b["solved"] == 12 and b["value"] > 0
+    assert out["config"]["gather_ms"] is not None
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_every_leg():
+    cmd = [sys.executable, BENCH, "--steps", "20", "--warmup", "2", "--workload", "config2_lp_soc", "--cpu-iters", "3",
+           "--batch-problems", "8", "--batch-threads", "4"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["dtype"] == "f64" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["direct_ldl"]["value"] > 0 and "infeasible" in cb["direct_ldl"]["target_and_config2"]
+    assert out["config"]["cg_steps_per_s"] > 0 and out["config"]["ms_per_cg_step"] > 0
+    assert out["steady_window"]["aa_accepted_in_window"] >= 0
+    assert out["config5_batch"]["solved"] == 8

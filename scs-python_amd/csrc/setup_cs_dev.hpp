@@ -103,8 +103,9 @@ __global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, i
     }
     int np = 0;
     long e0 = e_begin;
+    const int plen = cs_pass_len(e_end - e_begin);
     while (e0 < e_end) {
-      long e1 = e0 + kCsPass < e_end ? e0 + kCsPass : e_end;
+      long e1 = e0 + plen < e_end ? e0 + plen : e_end;
       const int base = s_col[e0];
       if ((long)s_col[e1 - 1] - base >= (1L << kCsColBits)) {
         long lo = e0, hi = e1 - 1;  // s_col[lo] - base fits, s_col[hi] - base does not

@@ -73,6 +73,16 @@ struct HostCs {
   int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0, split = 1;
 };
 
+// Passes of one workgroup are balanced: its n nonzeros go into ceil(n / kCsPass) passes of (nearly) equal length, a
+// multiple of 256, instead of full passes and one short one — the kernel processes whole passes (padding included),
+// so the padding is what this bounds: < 256 slots per pass.
+__host__ __device__ inline int cs_pass_len(long n) {
+  const long np = (n + kCsPass - 1) / kCsPass;
+  if (np <= 0) return kCsPass;
+  const long len = (((n + np - 1) / np) + 255) & ~255L;
+  return (int)(len < kCsPass ? len : kCsPass);
+}
+
 // Slot order inside a pass: (owner lane, the lane's j-th row, column); row-local index rl = j * 1024 + lane.
 // (Measured alternative: rows of a wave interleaved — (wave, j, lane) — with a DPP prefix sum per row so that the
 // row-sum reads of neighbouring lanes are bank-conflict free: not faster, 104 vs 99 us on the K1 shape.)
@@ -115,9 +125,10 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
     for (int part = 0; part < split; ++part) {
     const long e_lo = part == 0 ? 0 : mid, n = part == 0 ? mid : n_all;
     int np = 0;
+    const int plen = cs_pass_len(n - e_lo);
     for (long e0 = e_lo, e1; e0 < n; e0 = e1, ++np) {
-      // a pass = up to kCsPass consecutive sorted nonzeros spanning fewer than 2^kCsColBits columns
-      e1 = std::min(n, e0 + kCsPass);
+      // a pass = up to plen (<= kCsPass) consecutive sorted nonzeros spanning fewer than 2^kCsColBits columns
+      e1 = std::min(n, e0 + plen);
       const int base = ents[e0].col;
       while ((long)ents[e1 - 1].col - base >= (1L << kCsColBits)) --e1;
       std::fill(cnt.begin(), cnt.end(), 0);
@@ -399,7 +410,187 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
   }
 }
 
-inline int cs_schedule() {  // 1 (default) = gather-ahead (k_spmv_cs_ga); 0 = gathers, then next pass's stream (k_spmv_cs)
+// Braided schedule (default): same passes, same per-row order => same bits as k_spmv_cs_ga.  What the timeline of
+// the gather-ahead kernel shows (tools/cs_lab.hip, s_memtime stamps): a wave spends 43 % of the launch ISSUING the
+// gathers of the next pass — the texture addresser takes ~2.3 clk per distinct 128-byte line and back-pressures the
+// issue — then 20 % in the LDS row sums of the current pass while the addresser runs dry, then waits at the barrier for
+// the slowest issuer.  Here the two are braided: after the barrier every lane alternates "issue a slice of the memory
+// instructions of the coming passes" / "sum one of its rows from LDS", so the LDS latency hides behind the addresser
+// instead of following it.  Two details keep hipcc's wait-count insertion exact (a conditional load in one arm of a
+// branch makes it fall back to vmcnt(0), i.e. to draining the stream loads it just issued): full passes — all but the
+// last of a workgroup — run a branch-free body with unconditional loads (MASKED = false), and the per-pass header
+// {first column, count} comes through the scalar cache (constant address space) two passes ahead.
+typedef const int __attribute__((address_space(4))) *CsPinfoScalarPtr;
+
+// tools/cs_lab.hip defines CS_LAB_TIMELINE (and the buffer) to get per-wave phase sums out of the kernel; no-ops otherwise
+#ifdef CS_LAB_TIMELINE
+#define CS_TL_DECL unsigned long long tl_[6] = {0, 0, 0, 0, 0, 0}, tl_t0 = __builtin_amdgcn_s_memtime(), tl_t1; const unsigned long long tl_begin = tl_t0
+#define CS_TL_STAMP(slot) do { tl_t1 = __builtin_amdgcn_s_memtime(); tl_[slot] += tl_t1 - tl_t0; tl_t0 = tl_t1; } while (0)
+#define CS_TL_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long *o_ = cs_lab_tl + ((size_t)blockIdx.x * (kCsThreads / 64) + (threadIdx.x >> 6)) * 8; \
+    for (int i_ = 0; i_ < 6; ++i_) o_[i_] = tl_[i_]; o_[6] = tl_t1 - tl_begin; } } while (0)
+#else
+#define CS_TL_DECL
+#define CS_TL_STAMP(slot)
+#define CS_TL_FLUSH()
+#endif
+
+template <class Epi, int RPT, int ABL = 0>
+__global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const double *__restrict__ x, Epi epi, const int *done_flag,
+                                                            int *step_counter) {
+  if (done_flag && *done_flag) return;
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
+  constexpr int NQ = kCsQuads;
+  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr unsigned CM = (1u << CB) - 1;
+  __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
+  __shared__ double red[kCsThreads / 64];
+  const int tid = threadIdx.x, wg = blockIdx.x, c = wg / A.split, part = wg - c * A.split;
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM], acc[RPT];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sums[i] = 0.;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) maxs[i] = 0.;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) acc[j] = 0.;
+  const int g0 = A.passptr[wg], g1 = A.passptr[wg + 1];
+  CS_TL_DECL;
+  if (g0 < g1) {
+    CsPinfoScalarPtr pinf = (CsPinfoScalarPtr)A.pinfo;
+    auto get_pi = [&](int g) {  // uniform index: s_load_dwordx2
+      const int gg = g < g1 ? g : g1 - 1;
+      return int2{pinf[2 * gg], pinf[2 * gg + 1]};
+    };
+    // Every load is unconditional: the padding of a pass holds zero values with their own slots beyond every run and
+    // column offset 0, so it is harmless to process (build_cs balances the passes of a workgroup: < 2 % padding).
+    // Issue order inside a braid: the gathers of pass g + 1 FIRST, the stream loads of pass g + 2 behind them — a
+    // wave's loads return in order, and gathered lines that had to wait in the 32 KB L1 behind an HBM-latency load
+    // of the same wave would be evicted before they are consumed.
+    struct Set { uint4 ic[NQ]; double2 va[NQ], vb[NQ]; unsigned long long meta; };
+    Set S0, S1;
+    double xg[NQ][4];
+    auto ld_idx = [&](int s, Set &S, int gl) {
+      S.ic[s] = reinterpret_cast<const uint4 *>(A.idx + (size_t)gl * kCsPass)[tid + s * kCsThreads];
+    };
+    auto ld_val = [&](int s, Set &S, int gl) {  // s in [0, 2 NQ)
+      const int i = s >> 1, h = s & 1;
+      const double2 v = reinterpret_cast<const double2 *>(A.val + (size_t)gl * kCsPass)[2 * (tid + i * kCsThreads) + h];
+      if (h == 0) S.va[i] = v; else S.vb[i] = v;
+    };
+    auto ld_meta = [&](Set &S, int gl) { S.meta = A.meta[(size_t)gl * kCsThreads + tid]; };
+    auto gat = [&](int k, const Set &S, int col0) {  // k in [0, 4 NQ)
+      const int i = k >> 2, e = k & 3;
+      const unsigned id = e == 0 ? S.ic[i].x : e == 1 ? S.ic[i].y : e == 2 ? S.ic[i].z : S.ic[i].w;
+      constexpr unsigned GM = ABL == 1 ? 255u : 0xffffffffu;  // (lab ablation 1: gathers folded into a 2 KB table)
+      // (uniform base + unsigned 32-bit byte offset: the saddr form of global_load, no 64-bit address arithmetic)
+      const unsigned off = ((id >> kCsSlotBits) & GM) << 3;
+      xg[i][e] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x + col0) + off);
+    };
+    // memory instruction k of the braid of step g, in issue order: the gathers of pass g + 1 (in Y, first column c1),
+    // then index quads, values and run descriptor of pass g + 2 into X.  TAIL: the last two steps of the workgroup,
+    // where some of these passes do not exist (uniform branches).
+    constexpr int NGAT = 4 * NQ, NVAL = 2 * NQ, NMEM = NGAT + NQ + NVAL + 1;
+    auto mem_op = [&](auto tail, int k, int g, const Set &Y, int c1, Set &X) {
+      constexpr bool T = decltype(tail)::value;
+      if (k < NGAT) { if (!T || g + 1 < g1) gat(k, Y, c1); }
+      else if (k < NGAT + NQ) { if (!T || g + 2 < g1) ld_idx(k - NGAT, X, g + 2); }
+      else if (k < NGAT + NQ + NVAL) { if (!T || g + 2 < g1) ld_val(k - NGAT - NQ, X, g + 2); }
+      else { if (!T || g + 2 < g1) ld_meta(X, g + 2); }
+    };
+    // products of pass g (in X) -> LDS, barrier, then the braid with the row sums of pass g
+    auto step = [&](auto tail, int g, Set &X, const Set &Y, int c1, int buf) {
+      double *pb = prod[buf];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        pb[X.ic[i].x & (kCsPass - 1)] = X.va[i].x * xg[i][0];
+        pb[X.ic[i].y & (kCsPass - 1)] = X.va[i].y * xg[i][1];
+        pb[X.ic[i].z & (kCsPass - 1)] = X.vb[i].x * xg[i][2];
+        pb[X.ic[i].w & (kCsPass - 1)] = X.vb[i].y * xg[i][3];
+      }
+      const unsigned long long mc = X.meta;
+      CS_TL_STAMP(1);
+      __syncthreads();
+      CS_TL_STAMP(2);
+      int o = (int)(mc & 0xffff);
+      unsigned long long w = mc >> 16;
+      constexpr int PER = (NMEM + RPT - 1) / RPT;  // memory instructions per row
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+        for (int k = j * PER; k < (j + 1) * PER && k < NMEM; ++k) mem_op(tail, k, g, Y, c1, X);
+        __builtin_amdgcn_sched_barrier(0);
+        const int n = (int)((unsigned)w & CM);
+        w >>= CB;
+        double t = acc[j];
+        if (ABL == 2) t += (double)n;  // (lab ablation 2: no LDS row sums)
+        else {
+#pragma nounroll
+          for (int k = 0; k < n; ++k) t += pb[o + k];  // (n is ~1: unrolling only costs registers)
+        }
+        acc[j] = t;
+        o += n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      CS_TL_STAMP(3);
+    };
+    // first column of pass g + 1: scalar loads ahead of use
+    int cn = get_pi(g0 + 1).x;
+    {  // prologue: stream passes g0 and g0 + 1, gather g0
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) ld_idx(s, S0, g0);
+#pragma unroll
+      for (int s = 0; s < NVAL; ++s) ld_val(s, S0, g0);
+      ld_meta(S0, g0);
+      const int c0 = get_pi(g0).x;
+#pragma unroll
+      for (int k = 0; k < NGAT; ++k) gat(k, S0, c0);
+      if (g0 + 1 < g1) {
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) ld_idx(s, S1, g0 + 1);
+#pragma unroll
+        for (int s = 0; s < NVAL; ++s) ld_val(s, S1, g0 + 1);
+        ld_meta(S1, g0 + 1);
+      }
+    }
+    CS_TL_STAMP(0);
+    // The steady-state loop holds ONLY the branch-free body (a variant with conditional loads inside the same loop
+    // would merge its wait-count state into it); a second loop drains the last two or three passes.
+    int g = g0;
+    for (; g + 3 < g1; g += 2) {
+      step(std::false_type{}, g, S0, S1, cn, 0);      // pass g in S0, g + 1 in S1, g + 2 streams into S0
+      cn = get_pi(g + 2).x;
+      step(std::false_type{}, g + 1, S1, S0, cn, 1);  // pass g + 1 in S1, g + 2 in S0, g + 3 streams into S1
+      cn = get_pi(g + 3).x;
+    }
+    for (; g < g1; g += 2) {
+      step(std::true_type{}, g, S0, S1, cn, 0);
+      cn = get_pi(g + 2).x;
+      if (g + 1 < g1) step(std::true_type{}, g + 1, S1, S0, cn, 1);
+      cn = get_pi(g + 3).x;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
+    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+  }
+  CS_TL_STAMP(4);
+  CS_TL_FLUSH();
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+#pragma unroll
+    for (int i = 0; i < Epi::kSums; ++i) {
+      const double t = block_sum<kCsThreads>(sums[i], red);
+      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < Epi::kMaxs; ++i) {
+      const double t = block_max<kCsThreads>(maxs[i], red);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
+    }
+  }
+}
+
+inline int cs_schedule() {  // 2 = braided gathers / row sums (k_spmv_cs_il); 1 = gather-ahead (k_spmv_cs_ga); 0 = k_spmv_cs
   static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 1; }();
   return v;
 }
@@ -409,6 +600,16 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
                            int *step_counter) {
   if (A.nchunks <= 0) return;
   const dim3 g(A.nchunks * A.split), b(kCsThreads);
+  if (cs_schedule() == 2) {
+    switch (A.rpt) {
+      case 1: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 2: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 4: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 4>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 8: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 8>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      default: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 16>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    }
+    return;
+  }
   if (cs_schedule() == 1) {
     switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_ga<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

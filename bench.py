@@ -18,7 +18,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
     gather outside the timed region.
   * The iteration rate depends on how many CG steps an iteration needs (12 in the first 20 iterations of a cold
     start, 8 later), so the line also carries the step-count-independent figures `cg_steps_per_s` / `ms_per_cg_step`
-    and a second window, `steady_window`: iterations [120, 220) of one longer solve (timestamp taken inside the
+    and a second window, `steady_window`: iterations [105, 225) of one longer solve (timestamp taken inside the
     solve), in which the Anderson extrapolations and their safeguards run (the first one fires at iteration 110).
   * roofline: dominant kernel = the CG-step SpMV pair, average launch duration measured live with HIP events on
     the solver's own stream (scs_hip_kernel_times / scs_hip_time_matvec).
@@ -173,7 +173,7 @@ def main():
     # ---------------- steady window: iterations [120, 220) of one solve, Anderson steps inside ----------------
     steady = None
     if not args.no_steady:
-        mark, span = 120, 100
+        mark, span = 105, 120  # the Anderson solves of iterations 110 and 220 (and their safeguards) are inside
         ssolver = scs.SCS(data, K, max_iters=mark + span, **common)
         ssolver._solver._set_mark(mark)
         barrier()
@@ -252,7 +252,8 @@ def main():
     gb1 = b1 / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
     gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
     lss = info.get("lin_sys_solver", "")
-    kname = "k_spmv_cs_ga" if "column-sorted" in lss else "k_spmv_slab" if "slab" in lss else "k_spmv_stream"
+    kname = ("k_spmv_cs_il" if os.environ.get("SCS_HIP_CS_SCHED", "2") == "2" else "k_spmv_cs_ga") if "column-sorted" in lss \
+        else "k_spmv_slab" if "slab" in lss else "k_spmv_stream"
     dom = ("K1 %s<EpiDivR> (z = R_y^-1 A p)" % kname, b1, k1_avg, gb1) if k1_avg >= k2_avg else \
           ("K2 %s<EpiGp> (Gp = A'z + R_x p)" % kname, b2, k2_avg, gb2)
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; the

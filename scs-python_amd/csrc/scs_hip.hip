@@ -67,44 +67,71 @@ struct DeviceCsr {
     const char *e = getenv("SCS_HIP_CS");
     return !(e && e[0] == '0');
   }
-  DevBuf<double> cs_part0, cs_part1;  // cs.split == 2: partial row sums (spmv.hpp EpiPartial / EpiGp::split)
-  static bool cs_split_enabled() {  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (A/B measurements)
+  DevBuf<double> cs_part0, cs_part1;  // cs.split == 2 without the in-kernel combine: partial row sums (spmv.hpp EpiPartial / EpiGp::split)
+  static bool cs_split_enabled() {  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (bit-exact sequential row sums; A/B)
     const char *e = getenv("SCS_HIP_CS_SPLIT");
     return !(e && e[0] == '0');
   }
-  // two workgroups per row chunk pay when the chunk can be twice as tall within 8 rows per lane (6-bit counts)
-  bool cs_split_possible() const {
-    int R, rpt;
-    cs_pick_geometry(rows, R, rpt, 2);
-    return cs_split_enabled() && rpt <= 8 && !getenv("SCS_HIP_CS_RPT");
+  // Workgroups per row chunk.  kind: 0 = A (y-space products), 1 = A' (x-space products), 2 = P.  Taller chunks mean more
+  // nonzeros per 128-byte line of the gather vector, i.e. fewer lines per gather instruction — the quantity that bounds
+  // these kernels — at the price of partial row sums.  Default: only A' is split, in two, and hands its two partial
+  // vectors to the CG update (EpiGp::split: Gp is linear in them) or to k_epi_finish — no combine pass.
+  // SCS_HIP_CS_COMBINE=1 (braided kernel only): the partial sums of up to 4 parts are added INSIDE the kernel by the
+  // last workgroup of a chunk to arrive, so every product — A too — may be split (SCS_HIP_CS_SPLIT_A / _AT / _P).
+  // Measured at the bench size (tools/cs_lab.hip): the 48 MB of partial-sum traffic and the 16-rows-per-lane row sums
+  // eat the gather gain (A: 91.5 us unsplit, 95 us split in two + combine; A': 93 us two partial vectors, 100 us four
+  // parts + combine) => off by default.
+  static bool cs_combine_enabled() {
+    const char *e = getenv("SCS_HIP_CS_COMBINE");
+    return e && e[0] == '1' && cs_schedule() == 2;
   }
-  void cs_alloc_parts(hipStream_t s) {
-    if (cs.ok && cs.split > 1) { cs_part0.alloc_zero((size_t)rows, s); cs_part1.alloc_zero((size_t)rows, s); }
-    else { cs_part0.release(); cs_part1.release(); }
+  int cs_pick_split(int kind) const {
+    if (!cs_split_enabled() || getenv("SCS_HIP_CS_RPT")) return 1;
+    if (!cs_combine_enabled()) {
+      if (kind != 1) return 1;
+      int R, rpt;
+      cs_pick_geometry(rows, R, rpt, 2);
+      return rpt <= 8 ? 2 : 1;
+    }
+    const char *e = getenv(kind == 0 ? "SCS_HIP_CS_SPLIT_A" : kind == 1 ? "SCS_HIP_CS_SPLIT_AT" : "SCS_HIP_CS_SPLIT_P");
+    if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    for (int sp : {4, 2}) {
+      int R, rpt;
+      cs_pick_geometry(rows, R, rpt, sp);
+      if ((long)R * (kCsTargetWgs / sp) >= rows && rpt <= 16 && R >= 64 * sp) return sp;  // the chunks still cover all rows in one wave of workgroups
+    }
+    return 1;
+  }
+  void cs_after_build(hipStream_t s) {
+    cs_part0.release(); cs_part1.release();
+    if (!cs.ok || cs.split <= 1) return;
+    if (cs_combine_enabled()) cs.enable_combine(s);
+    else { cs_part0.alloc_zero((size_t)rows, s); cs_part1.alloc_zero((size_t)rows, s); }
   }
   // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays.
-  // want_split: try two workgroups per chunk first (only for matrices whose products tolerate partial sums: A')
-  bool build_cs_dev(const DeviceCsr &T, hipStream_t s, bool want_split = false) {
+  bool build_cs_dev(const DeviceCsr &T, hipStream_t s, int kind) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     bool ok = false;
-    if (want_split && cs_split_possible()) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 2);
+    const int sp = cs_pick_split(kind);
+    if (sp > 1) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, sp);
     if (!ok) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1);
-    cs_alloc_parts(s);
+    cs_after_build(s);
     return ok;
   }
-  bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, bool want_split = false) {
+  bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, int kind) {
     cs.release();
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
     bool ok = false;
-    if (want_split && cs_split_possible()) ok = build_cs(rp, ci, v, rows, cols, h, 0, 2);
+    const int sp = cs_pick_split(kind);
+    if (sp > 1) ok = build_cs(rp, ci, v, rows, cols, h, 0, sp);
     if (!ok) ok = build_cs(rp, ci, v, rows, cols, h, 0, 1);
     if (!ok) return false;
     cs.from_host(h, s);
-    cs_alloc_parts(s);
+    cs_after_build(s);
     return true;
   }
   static bool host_setup() {  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
@@ -223,7 +250,7 @@ struct DeviceCsr {
     if (cs.ok) { M.cs = cs.view(); M.part0 = cs_part0.p; M.part1 = cs_part1.p; }
     return M;
   }
-  int nwg() const { return cs.ok ? cs.nchunks * cs.split : has_slab ? s_nchunks : nblk; }
+  int nwg() const { return cs.ok ? (cs.combine() ? cs.nchunks : cs.nchunks * cs.split) : has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
     if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)
@@ -490,7 +517,7 @@ struct ScsHipWork {
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
   // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
   // second half of Gp when A' has the split layout (EpiGp::split): Gp = cg_Gp + gp2()
-  double *gp2() const { return At.cs.ok && At.cs.split > 1 ? At.cs_part1.p : nullptr; }
+  double *gp2() const { return At.cs.ok && At.cs.split > 1 && !At.cs.combine() ? At.cs_part1.p : nullptr; }
   void matvec(const double *x, const int *done, int *step_counter = nullptr) {
     launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, diag_r.p + n}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
@@ -1281,22 +1308,22 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     // large matrices: column-sorted pass copy (spmv_cs.hpp), each built from the other orientation's CSR;
     // the L2-blocked slab copy only where the pattern does not fit that format
     // A' products feed the CG update, which takes Gp as the sum of two partial vectors: two workgroups per chunk
-    if (!w->At.build_cs_dev(w->Ar, s, /*want_split=*/true)) w->At.build_slab_dev(s);
-    if (!w->Ar.build_cs_dev(w->At, s)) w->Ar.build_slab_dev(s);
-    if (w->has_P && !w->Pf.build_cs_dev(w->Pf, s)) w->Pf.build_slab_dev(s);
+    if (!w->At.build_cs_dev(w->Ar, s, /*kind=*/1)) w->At.build_slab_dev(s);
+    if (!w->Ar.build_cs_dev(w->At, s, /*kind=*/0)) w->Ar.build_slab_dev(s);
+    if (w->has_P && !w->Pf.build_cs_dev(w->Pf, s, /*kind=*/2)) w->Pf.build_slab_dev(s);
   }
   if (host_build) {  // SCS_HIP_SETUP=host: the column-sorted copies from the host builder, on the equilibrated values
     std::vector<double> hv;
-    auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci, bool want_split) {
+    auto host_cs = [&](DeviceCsr &M, const int *rp, const int *ci, int kind) {
       if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
       hv.resize((size_t)M.nnz);
       M.val.download(hv.data(), (size_t)M.nnz, s);
       HIP_CHECK(hipStreamSynchronize(s));
-      M.build_cs_host(rp, ci, hv.data(), s, want_split);
+      M.build_cs_host(rp, ci, hv.data(), s, kind);
     };
-    host_cs(w->At, d->A->p, d->A->i, true);
-    host_cs(w->Ar, ar.rowptr.data(), ar.col.data(), false);
-    if (w->has_P) host_cs(w->Pf, pf.rowptr.data(), pf.col.data(), false);
+    host_cs(w->At, d->A->p, d->A->i, 1);
+    host_cs(w->Ar, ar.rowptr.data(), ar.col.data(), 0);
+    if (w->has_P) host_cs(w->Pf, pf.rowptr.data(), pf.col.data(), 2);
   }
   mark("column-sorted / L2-blocked copies, value refresh");
   if (w->has_P) {  // diagonal of the (scaled) P for the Jacobi preconditioner
@@ -1824,16 +1851,16 @@ static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hip
   DeviceCsr T;  // the other orientation: what the device builder of the column-sorted copy reads
   if (transpose) {
     M.upload(A->n, A->m, A->p, A->i, A->x, s);
-    if (host) { M.build_cs_host(A->p, A->i, A->x, s, /*want_split=*/true); return; }
+    if (host) { M.build_cs_host(A->p, A->i, A->x, s, /*kind=*/1); return; }
     if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*allow_slab=*/false);
   } else {
     M.upload(A->m, A->n, ar.rowptr.data(), ar.col.data(), ar.val.data(), s);
-    if (host) { M.build_cs_host(ar.rowptr.data(), ar.col.data(), ar.val.data(), s); return; }
+    if (host) { M.build_cs_host(ar.rowptr.data(), ar.col.data(), ar.val.data(), s, /*kind=*/0); return; }
     if (!cs_wanted(M.rows, M.cols, M.nnz)) return;
     T.upload(A->n, A->m, A->p, A->i, A->x, s, /*allow_slab=*/false);
   }
-  M.build_cs_dev(T, s, /*want_split=*/transpose != 0);
+  M.build_cs_dev(T, s, /*kind=*/transpose != 0 ? 1 : 0);
 }
 
 int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose) {
@@ -1870,27 +1897,27 @@ int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_floa
       rows = A->m; cols = A->n;
     }
     HostCs h;
-    if (split != 1 && split != 2) throw std::runtime_error("split must be 1 or 2");
+    if (split != 1 && split != 2 && split != 4) throw std::runtime_error("split must be 1, 2 or 4");
     if (!build_cs(rp, ci, v, rows, cols, h, rpt, split)) return 1;
-    const int cb = cs_count_bits(h.rpt);
+    const int cb = cs_count_bits(h.rpt), mw = cs_meta_words(h.rpt);
     std::vector<double> prod(kCsPass), acc((size_t)kCsThreads * h.rpt), tot((size_t)kCsThreads * h.rpt);
     for (int c = 0; c < h.nchunks; ++c) {
-      for (int part = 0; part < h.split; ++part) {  // one workgroup each; split == 2: the two partial sums are added
+      for (int part = 0; part < h.split; ++part) {  // one workgroup each; split > 1: the partial sums are added in part order
         std::fill(acc.begin(), acc.end(), 0.0);
         const size_t wg = (size_t)c * h.split + part;
         for (int g = h.passptr[wg]; g < h.passptr[wg + 1]; ++g) {
           const int2 pi = h.pinfo[g];
           const size_t o = (size_t)g * kCsPass;
-          for (int sp = 0; sp < kCsPass; ++sp) {
-            if ((((sp >> 2) >> 6) << 8) >= pi.y) continue;  // a block of 256 holding only padding
+          for (int sp = 0; sp < kCsPass; ++sp) {  // the whole pass, padding included, as the kernel does
             const unsigned id = h.idx[o + sp];
             prod[id & (kCsPass - 1)] = h.val[o + sp] * x[pi.x + (int)(id >> kCsSlotBits)];
           }
           for (int t = 0; t < kCsThreads; ++t) {
-            const unsigned long long mw = h.meta[(size_t)g * kCsThreads + t];
-            int off = (int)(mw & 0xffff);
-            unsigned long long w = mw >> 16;
+            const unsigned long long mw0 = h.meta[((size_t)g * kCsThreads + t) * mw];
+            int off = (int)(mw0 & 0xffff);
+            unsigned long long w = mw0 >> 16;
             for (int j = 0; j < h.rpt; ++j) {
+              if (h.rpt == 16 && j == 8) w = h.meta[((size_t)g * kCsThreads + t) * mw + 1];
               const int n = (int)(w & ((1ull << cb) - 1));
               w >>= cb;
               double sacc = acc[(size_t)j * kCsThreads + t];
@@ -2002,9 +2029,9 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
       w.Pdiag.upload(pdiag.data(), n, s);
     }
     if (!DeviceCsr::host_setup()) {
-      w.At.build_cs_dev(w.Ar, s, /*want_split=*/true);
-      w.Ar.build_cs_dev(w.At, s);
-      if (P) w.Pf.build_cs_dev(w.Pf, s);
+      w.At.build_cs_dev(w.Ar, s, /*kind=*/1);
+      w.Ar.build_cs_dev(w.At, s, /*kind=*/0);
+      if (P) w.Pf.build_cs_dev(w.Pf, s, /*kind=*/2);
     }
     std::vector<double> dr(w.l, 10.0);
     std::copy(diag_r, diag_r + n + m, dr.begin());

@@ -94,13 +94,8 @@ __global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, i
   auto cut = [&](int v, int4 *out) {  // passes of workgroup v = chunk * split + part (written from out[0] on when out != nullptr)
     const int c = v / split, part = v - c * split;
     const long c_begin = hoff[(size_t)c * nblocks], c_end = c + 1 < nchunks ? hoff[(size_t)(c + 1) * nblocks] : nnz;
-    long e_begin = c_begin, e_end = c_end;
-    if (split > 1) {  // the chunk's stream cut at (a multiple of 256 near) its middle
-      const long n = c_end - c_begin;
-      long mid = (n / 2 + 255) & ~255L;
-      if (mid > n) mid = n;
-      if (part == 0) e_end = c_begin + mid; else e_begin = c_begin + mid;
-    }
+    // the chunk's stream cut into `split` parts at (multiples of 256 near) k * n / split
+    const long e_begin = c_begin + cs_part_cut(c_end - c_begin, part, split), e_end = c_begin + cs_part_cut(c_end - c_begin, part + 1, split);
     int np = 0;
     long e0 = e_begin;
     const int plen = cs_pass_len(e_end - e_begin);
@@ -147,7 +142,7 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
                                                   const int *__restrict__ s_col, const int *__restrict__ s_src,
                                                   const double *__restrict__ tval, int R, unsigned *idx, double *val,
                                                   unsigned long long *meta, int2 *pinfo, int *fail) {
-  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr int CB = RPT == 16 ? 6 : (48 / RPT < 13 ? 48 / RPT : 13);
   constexpr int RR = kCsThreads * RPT;
   __shared__ unsigned key[kCsPass];
   __shared__ int cnt[RR];
@@ -185,14 +180,21 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
     const int mid = (lo + hi) >> 1;
     if (key[mid] < want) lo = mid; else hi = mid;
   }
-  unsigned long long w = (unsigned long long)hi;
+  unsigned long long w = (unsigned long long)hi, w1 = 0;
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int n = cnt[cs_row_key(j * kCsThreads + tid, RPT)];
     if (n > (1 << CB) - 1) atomicExch(fail, 1);
-    w |= (unsigned long long)(n & ((1 << CB) - 1)) << (16 + CB * j);
+    const unsigned long long nb = (unsigned long long)(n & ((1 << CB) - 1));
+    if (RPT < 16 || j < 8) w |= nb << (16 + CB * j);
+    else w1 |= nb << (CB * (j - 8));
   }
-  meta[(size_t)g * kCsThreads + tid] = w;
+  if (RPT == 16) {
+    meta[((size_t)g * kCsThreads + tid) * 2] = w;
+    meta[((size_t)g * kCsThreads + tid) * 2 + 1] = w1;
+  } else {
+    meta[(size_t)g * kCsThreads + tid] = w;
+  }
   if (tid == 0) pinfo[g] = int2{base, len};
 }
 
@@ -203,13 +205,27 @@ struct DeviceCs {
   DevBuf<unsigned> idx;
   DevBuf<double> val;
   DevBuf<unsigned long long> meta;
+  DevBuf<double> scratch;    // in-kernel combine of split layouts (CsView::scratch / ticket); empty: partial outputs
+  DevBuf<unsigned> ticket;
   int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0, split = 1;
   bool ok = false;
   void release() {
-    passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release();
+    passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release(); scratch.release(); ticket.release();
     ok = false;
   }
-  CsView view() const { return CsView{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt, split}; }
+  bool combine() const { return ok && split > 1 && ticket.p != nullptr; }
+  // the workgroups of a chunk add their partial row sums inside the kernel (k_spmv_cs_il): every epilogue sees finished rows
+  void enable_combine(hipStream_t s) {
+    if (!ok || split <= 1) return;
+    scratch.alloc_zero((size_t)nchunks * split * kCsThreads * rpt, s);
+    ticket.alloc_zero((size_t)nchunks, s);
+  }
+  CsView view() const {
+    CsView v{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt, split};
+    v.scratch = scratch.p;
+    v.ticket = ticket.p;
+    return v;
+  }
   void from_host(const HostCs &h, hipStream_t s) {
     rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass; rpt = h.rpt; split = h.split;
     passptr.upload(h.passptr.data(), h.passptr.size(), s);
@@ -256,7 +272,7 @@ struct DeviceCs {
     if (failed || (long)npass * kCsPass > nnz + nnz / 4 + (long)nchunks * split * kCsPass) { release(); return false; }
     idx.alloc((size_t)npass * kCsPass);
     val.alloc((size_t)npass * kCsPass);
-    meta.alloc((size_t)npass * kCsThreads);
+    meta.alloc((size_t)npass * kCsThreads * cs_meta_words(rpt));
     pinfo.alloc((size_t)npass);
     const dim3 gr(npass), bl(kCsThreads);
 #define SCS_CS_FILL(RPT_) hipLaunchKernelGGL((k_cs_fill<RPT_>), gr, bl, 0, s, pass_info.p, s_row.p, s_col.p, s_src.p, tval, R, idx.p, val.p, meta.p, pinfo.p, flag.p)

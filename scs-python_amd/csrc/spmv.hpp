@@ -594,7 +594,8 @@ struct SpmvMat {
   CsView cs{};
   bool use_slab = false, use_cs = false;  // use_cs wins (spmv_cs.hpp: column-sorted passes)
   double *part0 = nullptr, *part1 = nullptr;  // cs.split == 2: scratch for the partial row sums of epilogues without split()
-  int nblk() const { return use_cs ? cs.nchunks * cs.split : use_slab ? slab.nchunks : csr.nblk; }
+  bool cs_combine() const { return use_cs && cs.split > 1 && cs.ticket != nullptr; }
+  int nblk() const { return use_cs ? (cs_combine() ? cs.nchunks : cs.nchunks * cs.split) : use_slab ? slab.nchunks : csr.nblk; }
 };
 
 // split layouts: the epilogue of a product whose functor is not linear in the row sum — rows finished from the two
@@ -631,6 +632,10 @@ template <class Epi>
 inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                         int *step_counter = nullptr) {
   if (M.use_cs) {
+    if (M.cs_combine()) {  // partial sums are added inside the kernel: finished rows for any epilogue
+      launch_spmv_cs(M.cs, x, epi, done_flag, s, step_counter);
+      return;
+    }
     if constexpr (!epi_has_split<Epi>::value) {
       if (M.cs.split > 1) {
         if (M.cs.nchunks <= 0) return;

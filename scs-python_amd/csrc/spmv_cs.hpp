@@ -42,12 +42,19 @@ struct CsView {
   const int2 *pinfo;           // per pass {first column, nonzeros (the rest of the kCsPass entries is padding)}
   const unsigned *idx;         // npass * kCsPass
   const double *val;           // npass * kCsPass
-  const unsigned long long *meta;  // npass * kCsThreads
+  const unsigned long long *meta;  // npass * kCsThreads * cs_meta_words(rpt)
   int rows, cols, nchunks, R, npass, rpt;  // R rows per chunk (<= 1024 * rpt), rpt = accumulators per lane (1, 2, 4, 8, 16)
-  int split;                   // workgroups per chunk (1, or 2: the chunk's column-sorted stream cut in two; partial row sums)
+  int split;                   // workgroups per chunk (1, 2, 4: the chunk's column-sorted stream cut into equal parts; partial row sums)
+  // In-kernel combine (k_spmv_cs_il only; nullptr = the workgroups hand their partial row sums to the epilogue's split()):
+  // every workgroup of a chunk publishes its partial sums in `scratch` and takes a ticket; the LAST arriver adds the
+  // parts in fixed order and runs the epilogue on the finished rows.  No spinning: nothing ever waits for a workgroup.
+  double *scratch = nullptr;   // nchunks * split * 1024 * rpt doubles
+  unsigned *ticket = nullptr;  // nchunks counters, monotone: split arrivals per launch
 };
 
-__host__ __device__ inline int cs_count_bits(int rpt) { return 48 / rpt < 13 ? 48 / rpt : 13; }
+// bits per row count in a run descriptor; 16 rows per lane use two words (8 counts each)
+__host__ __device__ inline int cs_count_bits(int rpt) { return rpt == 16 ? 6 : (48 / rpt < 13 ? 48 / rpt : 13); }
+__host__ __device__ inline int cs_meta_words(int rpt) { return rpt == 16 ? 2 : 1; }
 
 // Chunk geometry: R rows per workgroup so that the launch is ONE wave of workgroups on the 256 CUs (every CU busy,
 // as many rows per CU as possible: the distinct lines per gather instruction fall with R), R a multiple of 64;
@@ -81,6 +88,14 @@ __host__ __device__ inline int cs_pass_len(long n) {
   if (np <= 0) return kCsPass;
   const long len = (((n + np - 1) / np) + 255) & ~255L;
   return (int)(len < kCsPass ? len : kCsPass);
+}
+
+// first stream position of part k of a chunk with n nonzeros cut into `split` parts (k = split: n)
+__host__ __device__ inline long cs_part_cut(long n, int k, int split) {
+  if (k <= 0) return 0;
+  if (k >= split) return n;
+  const long c = ((n * k) / split + 255) & ~255L;
+  return c < n ? c : n;
 }
 
 // Slot order inside a pass: (owner lane, the lane's j-th row, column); row-local index rl = j * 1024 + lane.
@@ -120,10 +135,9 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
       for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ents.push_back(Ent{col[p], r - r0, p});
     std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.col != b.col ? a.col < b.col : a.rl < b.rl; });
     const long n_all = (long)ents.size();
-    // split = 2: the chunk's stream is cut in two at (a multiple of 256 near) its middle, one workgroup each
-    const long mid = split > 1 ? std::min(n_all, (n_all / 2 + 255) & ~255L) : n_all;
+    // split > 1: the chunk's stream is cut into `split` parts at (multiples of 256 near) k * n / split, one workgroup each
     for (int part = 0; part < split; ++part) {
-    const long e_lo = part == 0 ? 0 : mid, n = part == 0 ? mid : n_all;
+    const long e_lo = cs_part_cut(n_all, part, split), n = cs_part_cut(n_all, part + 1, split);
     int np = 0;
     const int plen = cs_pass_len(n - e_lo);
     for (long e0 = e_lo, e1; e0 < n; e0 = e1, ++np) {
@@ -152,9 +166,14 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
         }
       }
       for (int t = 0; t < kCsThreads; ++t) {
-        unsigned long long w = (unsigned long long)start[cs_row_key(t, rpt)];  // first slot of the lane's run
-        for (int j = 0; j < rpt; ++j) w |= (unsigned long long)cnt[cs_row_key(j * kCsThreads + t, rpt)] << (16 + cb * j);
+        unsigned long long w = (unsigned long long)start[cs_row_key(t, rpt)], w1 = 0;  // first slot of the lane's run
+        for (int j = 0; j < rpt; ++j) {
+          const unsigned long long n_j = (unsigned long long)cnt[cs_row_key(j * kCsThreads + t, rpt)];
+          if (j < 8 || rpt < 16) w |= n_j << (16 + cb * j);
+          else w1 |= n_j << (cb * (j - 8));
+        }
         out.meta.push_back(w);
+        if (rpt == 16) out.meta.push_back(w1);
       }
     }
     out.passptr[(size_t)c * split + part + 1] = out.passptr[(size_t)c * split + part] + np;
@@ -186,13 +205,14 @@ __device__ __forceinline__ void cs_epilogue(const Epi &epi, int split, int part,
 // (Measured alternative: level by level — the L-th product of several rows as one batch of independent LDS reads,
 // +0.0 for rows without one — is not faster than the plain per-row loops: 100-102 vs 99 us on the K1 shape.)
 template <int RPT>
-__device__ __forceinline__ void cs_row_sums(const double *__restrict__ pb, unsigned long long m, double (&acc)[RPT]) {
-  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+__device__ __forceinline__ void cs_row_sums(const double *__restrict__ pb, unsigned long long m, unsigned long long m1, double (&acc)[RPT]) {
+  constexpr int CB = RPT == 16 ? 6 : (48 / RPT < 13 ? 48 / RPT : 13);
   constexpr unsigned CM = (1u << CB) - 1;
   int o = (int)(m & 0xffff);
   unsigned long long w = m >> 16;
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
+    if (RPT == 16 && j == 8) w = m1;
     const int n = (int)((unsigned)w & CM);
     w >>= CB;
     double t = acc[j];
@@ -223,11 +243,11 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
   const int g0 = A.passptr[wg], g1 = A.passptr[wg + 1];
   uint4 ic[NQ], in[NQ];
   double2 va[NQ], vb[NQ], na[NQ], nb[NQ];
-  unsigned long long mc = 0, mn = 0;
+  unsigned long long mc = 0, mn = 0, mc1 = 0, mn1 = 0;
   int2 pc{0, 0}, pn{0, 0};
   // a lane's i-th quad belongs to the block of 256 sorted nonzeros (tid >> 6) + 16 i: blocks beyond the pass's
   // nonzero count hold only padding and are skipped (wave-uniform)
-  auto load = [&](int g, uint4(&ii)[NQ], double2(&a)[NQ], double2(&b)[NQ], unsigned long long &m, int2 &pi) {
+  auto load = [&](int g, uint4(&ii)[NQ], double2(&a)[NQ], double2(&b)[NQ], unsigned long long &m, unsigned long long &m1, int2 &pi) {
     const uint4 *i4 = reinterpret_cast<const uint4 *>(A.idx + (size_t)g * kCsPass);
     const double2 *v2 = reinterpret_cast<const double2 *>(A.val + (size_t)g * kCsPass);
     pi = A.pinfo[g];
@@ -240,9 +260,10 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
         b[i] = v2[2 * q + 1];
       }
     }
-    m = A.meta[(size_t)g * kCsThreads + tid];
+    m = A.meta[((size_t)g * kCsThreads + tid) * (RPT == 16 ? 2 : 1)];
+    if (RPT == 16) m1 = A.meta[((size_t)g * kCsThreads + tid) * 2 + 1];
   };
-  if (g0 < g1) load(g0, ic, va, vb, mc, pc);
+  if (g0 < g1) load(g0, ic, va, vb, mc, mc1, pc);
   int buf = 0;
   for (int g = g0; g < g1; ++g) {
     // gathers of this pass first, then the streaming loads of the next one: the in-order return queue hands the
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
         xg[i][3] = xb[ic[i].w >> kCsSlotBits];
       }
     }
-    if (g + 1 < g1) load(g + 1, in, na, nb, mn, pn);
+    if (g + 1 < g1) load(g + 1, in, na, nb, mn, mn1, pn);
     double *pb = prod[buf];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -270,11 +291,12 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
       }
     }
     __syncthreads();
-    cs_row_sums<RPT>(pb, mc, acc);
+    cs_row_sums<RPT>(pb, mc, mc1, acc);
     buf ^= 1;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) { ic[i] = in[i]; va[i] = na[i]; vb[i] = nb[i]; }
     mc = mn;
+    mc1 = mn1;
     pc = pn;
   }
 #pragma unroll
@@ -305,7 +327,7 @@ template <int NQ>
 struct CsSet {
   uint4 ic[NQ];
   double2 va[NQ], vb[NQ];
-  unsigned long long meta;
+  unsigned long long meta, meta1;
   int2 pi;
 };
 
@@ -344,7 +366,8 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
         else { S.va[i] = v2[2 * q]; S.vb[i] = v2[2 * q + 1]; }
       }
     }
-    S.meta = A.meta[(size_t)g * kCsThreads + tid];
+    S.meta = A.meta[((size_t)g * kCsThreads + tid) * (RPT == 16 ? 2 : 1)];
+    if (RPT == 16) S.meta1 = A.meta[((size_t)g * kCsThreads + tid) * 2 + 1];
   };
   auto gather = [&](const CsSet<NQ> &S) {
     const double *xb = x + S.pi.x;
@@ -375,12 +398,12 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
         }
       }
     }
-    const unsigned long long mc = X.meta;
+    const unsigned long long mc = X.meta, mc1 = RPT == 16 ? X.meta1 : 0;
     __syncthreads();
     if (g + 1 < g1) gather(Y);
     if (g + 2 < g1) load(g + 2, X);
     if (ABL == 2 || ABL == 3) { acc[0] += (double)(mc & 0xffffff); return; }
-    cs_row_sums<RPT>(pb, mc, acc);
+    cs_row_sums<RPT>(pb, mc, mc1, acc);
   };
   if (g0 < g1) {
     load(g0, S0);
@@ -440,10 +463,11 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
   if (done_flag && *done_flag) return;
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
   constexpr int NQ = kCsQuads;
-  constexpr int CB = 48 / RPT < 13 ? 48 / RPT : 13;
+  constexpr int CB = RPT == 16 ? 6 : (48 / RPT < 13 ? 48 / RPT : 13);
   constexpr unsigned CM = (1u << CB) - 1;
   __shared__ __attribute__((aligned(16))) double prod[2][kCsPass];
   __shared__ double red[kCsThreads / 64];
+  __shared__ unsigned ticket_sm;
   const int tid = threadIdx.x, wg = blockIdx.x, c = wg / A.split, part = wg - c * A.split;
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
   double sums[NS], maxs[NM], acc[RPT];
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     // Issue order inside a braid: the gathers of pass g + 1 FIRST, the stream loads of pass g + 2 behind them — a
     // wave's loads return in order, and gathered lines that had to wait in the 32 KB L1 behind an HBM-latency load
     // of the same wave would be evicted before they are consumed.
-    struct Set { uint4 ic[NQ]; double2 va[NQ], vb[NQ]; unsigned long long meta; };
+    struct Set { uint4 ic[NQ]; double2 va[NQ], vb[NQ]; unsigned long long meta, meta1; };
     Set S0, S1;
     double xg[NQ][4];
     auto ld_idx = [&](int s, Set &S, int gl) {
@@ -477,7 +501,15 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
       const double2 v = reinterpret_cast<const double2 *>(A.val + (size_t)gl * kCsPass)[2 * (tid + i * kCsThreads) + h];
       if (h == 0) S.va[i] = v; else S.vb[i] = v;
     };
-    auto ld_meta = [&](Set &S, int gl) { S.meta = A.meta[(size_t)gl * kCsThreads + tid]; };
+    auto ld_meta = [&](Set &S, int gl) {
+      if constexpr (RPT == 16) {  // two words: one 16-byte load
+        const ulonglong2 m2 = reinterpret_cast<const ulonglong2 *>(A.meta)[(size_t)gl * kCsThreads + tid];
+        S.meta = m2.x;
+        S.meta1 = m2.y;
+      } else {
+        S.meta = A.meta[(size_t)gl * kCsThreads + tid];
+      }
+    };
     auto gat = [&](int k, const Set &S, int col0) {  // k in [0, 4 NQ)
       const int i = k >> 2, e = k & 3;
       const unsigned id = e == 0 ? S.ic[i].x : e == 1 ? S.ic[i].y : e == 2 ? S.ic[i].z : S.ic[i].w;
@@ -507,18 +539,20 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
         pb[X.ic[i].z & (kCsPass - 1)] = X.vb[i].x * xg[i][2];
         pb[X.ic[i].w & (kCsPass - 1)] = X.vb[i].y * xg[i][3];
       }
-      const unsigned long long mc = X.meta;
+      const unsigned long long mc = X.meta, mc1 = RPT == 16 ? X.meta1 : 0;
       CS_TL_STAMP(1);
       __syncthreads();
       CS_TL_STAMP(2);
       int o = (int)(mc & 0xffff);
       unsigned long long w = mc >> 16;
-      constexpr int PER = (NMEM + RPT - 1) / RPT;  // memory instructions per row
+      // memory instructions per row: at least two, so that the gathers are all with the addresser after a few rows
+      constexpr int PER = (NMEM + RPT - 1) / RPT > 2 ? (NMEM + RPT - 1) / RPT : 2;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
 #pragma unroll
         for (int k = j * PER; k < (j + 1) * PER && k < NMEM; ++k) mem_op(tail, k, g, Y, c1, X);
         __builtin_amdgcn_sched_barrier(0);
+        if (RPT == 16 && j == 8) w = mc1;
         const int n = (int)((unsigned)w & CM);
         w >>= CB;
         double t = acc[j];
@@ -569,29 +603,73 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
       cn = get_pi(g + 3).x;
     }
   }
+  const bool combine = A.split > 1 && A.ticket != nullptr;
+  if (combine) {
+    // Publish the partial row sums with write-through (sc1) 16-byte stores — acknowledged stores are visible to every
+    // XCD, no L2 write-back fence needed, and 8-byte sc1 stores would cost one fabric write each — then one ticket per
+    // workgroup; the last of the chunk's `split` arrivals finishes the rows.  Scratch order: pairs of a lane's rows.
+    double *mine = A.scratch + (size_t)wg * (kCsThreads * RPT);
+    if constexpr (RPT >= 2) {
+      typedef double cs_d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int j = 0; j < RPT; j += 2) {
+        cs_d2 v;
+        v.x = acc[j];
+        v.y = acc[j + 1];
+        cs_d2 *dst = reinterpret_cast<cs_d2 *>(mine) + (size_t)(j >> 1) * kCsThreads + tid;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+      }
+    } else {
+      __hip_atomic_store(mine + tid, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ticket_sm = __hip_atomic_fetch_add(A.ticket + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket_sm % (unsigned)A.split != (unsigned)A.split - 1) return;
+    // parts in fixed order 0 .. split - 1 (whoever combines): ((p0 + p1) + p2) + p3; the others' parts through
+    // agent-scope (sc1) loads, which bypass this CU's L1
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      double t = 0.;
+      for (int p = 0; p < A.split; ++p) {
+        const size_t o = RPT >= 2 ? ((size_t)(j >> 1) * kCsThreads + tid) * 2 + (j & 1) : (size_t)tid;
+        const double v = p == part ? acc[j]
+                                   : __hip_atomic_load(A.scratch + (size_t)(c * A.split + p) * (kCsThreads * RPT) + o, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        t = p == 0 ? v : t + v;
+      }
+      acc[j] = t;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    if (rl < A.R && r < A.rows) {
+      if (combine) epi(r, acc[j], sums, maxs);  // finished rows: the plain epilogue
+      else cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    }
   }
   CS_TL_STAMP(4);
   CS_TL_FLUSH();
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+    // reduction partials: one slot per workgroup, or — combine mode — one per chunk (written by its last arriver)
+    const int slot = combine ? c : wg, nslot = combine ? A.nchunks : (int)gridDim.x;
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)i * nslot + slot] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kCsThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * nslot + slot] = t;
     }
   }
 }
 
 inline int cs_schedule() {  // 2 = braided gathers / row sums (k_spmv_cs_il); 1 = gather-ahead (k_spmv_cs_ga); 0 = k_spmv_cs
-  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 2; }();
   return v;
 }
 
@@ -600,7 +678,7 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
                            int *step_counter) {
   if (A.nchunks <= 0) return;
   const dim3 g(A.nchunks * A.split), b(kCsThreads);
-  if (cs_schedule() == 2) {
+  if (cs_schedule() == 2 || (A.split > 1 && A.ticket != nullptr)) {  // (the in-kernel combine lives in k_spmv_cs_il only)
     switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
       case 2: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 2>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

@@ -37,15 +37,17 @@ def test_layout_walk_matches_oracle_bits(hip, oracle, shape, per_col, rpt):
     np.testing.assert_array_equal(got_t, oracle.spmv(A, y, trans=True))
 
 
+@pytest.mark.parametrize("split", [2, 4])
 @pytest.mark.parametrize("shape,per_col", [((70000, 20000), 5), ((3000, 1700), 6), ((20000, 50000), 12)])
-def test_layout_split_in_two_workgroups_per_chunk(hip, oracle, shape, per_col):
-    """split = 2 (what scs_init uses for A'): each half of a chunk's column-sorted stream is summed on its own and the
-    two partial sums are added — not the oracle's sequential order any more, but within 1 ulp-ish of it"""
+def test_layout_split_workgroups_per_chunk(hip, oracle, shape, per_col, split):
+    """split = 2, 4 (what scs_init uses for the large matrices): every part of a chunk's column-sorted stream is summed
+    on its own and the partial sums are added in part order — not the oracle's sequential order any more, but within
+    1 ulp-ish of it"""
     rng = np.random.default_rng(43)
     A = pg.random_sparse(*shape, per_col, rng)
     x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
     for trans, vec in ((False, x), (True, y)):
-        got = hip.cs_layout_host_spmv(A, vec, transpose=trans, split=2)
+        got = hip.cs_layout_host_spmv(A, vec, transpose=trans, split=split)
         ref = oracle.spmv(A, vec, trans=trans)
         assert got is not None
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
@@ -69,12 +71,13 @@ def test_layout_empty_rows_and_columns(hip, oracle):
 
 def test_layout_rejects_what_its_bit_fields_cannot_hold(hip):
     rng = np.random.default_rng(5)
-    # 16 rows per lane: 3-bit counts per (row, pass) — a dense 40 x 40 block puts 40 nonzeros of a row into one pass
+    # 8 and 16 rows per lane: 6-bit counts per (row, pass) — a dense 70 x 70 block puts 70 nonzeros of a row into one pass
     A = pg.random_sparse(40000, 30000, 4, rng)
-    ii, jj = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
-    B = (A + sparse.csc_matrix((rng.standard_normal(1600), (ii.ravel(), jj.ravel())), shape=A.shape)).tocsc()
+    ii, jj = np.meshgrid(np.arange(70), np.arange(70), indexing="ij")
+    B = (A + sparse.csc_matrix((rng.standard_normal(4900), (ii.ravel(), jj.ravel())), shape=A.shape)).tocsc()
     B.sort_indices()
     assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=16) is None
+    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=8) is None
     assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=4) is not None      # 12-bit counts hold it
     # very wide and very sparse: every pass is cut at 2^19 columns => mostly padding => rejected
     W = pg.random_sparse(20000, 3000000, 1, rng)

@@ -566,9 +566,9 @@ def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt
     monkeypatch.setenv("SCS_HIP_CS_SPLIT", split)
     rng = np.random.default_rng(23)
     A = pg.random_sparse(*shape, per_col, rng)
-    if dense:  # 40 nonzeros of one row inside one pass: more than a 3-bit count holds
-        ii, jj = np.meshgrid(np.arange(40), np.arange(40), indexing="ij")
-        A = (A + sparse.csc_matrix((rng.standard_normal(1600), (ii.ravel(), jj.ravel())), shape=shape)).tocsc()
+    if dense:  # 70 nonzeros of one row inside one pass: more than a 6-bit count holds
+        ii, jj = np.meshgrid(np.arange(70), np.arange(70), indexing="ij")
+        A = (A + sparse.csc_matrix((rng.standard_normal(4900), (ii.ravel(), jj.ravel())), shape=shape)).tocsc()
         A.sort_indices()
     if rpt:
         monkeypatch.setenv("SCS_HIP_CS_RPT", rpt)
@@ -585,6 +585,43 @@ def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt
             np.testing.assert_allclose(got[mode][1], ref[1], rtol=0, atol=1e-13 * np.abs(ref[1]).max(), err_msg=mode)
     np.testing.assert_array_equal(got["device"][1], got["host"][1])
     np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), got["host"][1])  # run-to-run
+
+
+@pytest.mark.parametrize("split_a,split_at", [("2", "4"), ("4", "2")])
+def test_spmv_in_kernel_combine(hip, oracle, monkeypatch, split_a, split_at):
+    """SCS_HIP_CS_COMBINE=1: every workgroup of a row chunk publishes its partial row sums and the LAST one to arrive adds
+    them (fixed part order) and runs the epilogue — no combine pass, no spinning.  Against the oracle at 1e-13 (the parts
+    are summed separately), device and host builders identical, run-to-run identical bits whichever workgroup arrived
+    last, and a full solve through the fused CG epilogues agreeing with the default layout's."""
+    monkeypatch.setenv("SCS_HIP_CS_COMBINE", "1")
+    monkeypatch.setenv("SCS_HIP_CS_SPLIT_A", split_a)
+    monkeypatch.setenv("SCS_HIP_CS_SPLIT_AT", split_at)
+    rng = np.random.default_rng(29)
+    A = pg.random_sparse(600000, 450000, 6, rng)
+    x, y = rng.standard_normal(A.shape[1]), rng.standard_normal(A.shape[0])
+    ref = (oracle.spmv(A, x), oracle.spmv(A, y, trans=True))
+    got = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SCS_HIP_SETUP", mode)
+        got[mode] = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
+        for k in (0, 1):
+            np.testing.assert_allclose(got[mode][k], ref[k], rtol=0, atol=1e-13 * np.abs(ref[k]).max(), err_msg=mode)
+    for k in (0, 1):
+        np.testing.assert_array_equal(got["device"][k], got["host"][k])
+    for rep in range(5):  # arrival order varies from launch to launch; the bits must not
+        np.testing.assert_array_equal(hip.spmv(A, x), got["host"][0])
+        np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), got["host"][1])
+    monkeypatch.delenv("SCS_HIP_SETUP")
+    K, n, k, seed = pg.workload("config2_lp_soc")
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    stg = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False)
+    a = hip.SCS(*helpers.raw_args(data, K), **stg).solve(False, None, None, None)
+    monkeypatch.delenv("SCS_HIP_CS_COMBINE")
+    b = hip.SCS(*helpers.raw_args(data, K), **stg).solve(False, None, None, None)
+    assert a["info"]["status"] == "solved" and b["info"]["status"] == "solved", (a["info"], b["info"])
+    assert abs(a["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
+    for key in ("x", "y", "s"):
+        np.testing.assert_allclose(a[key], b[key], rtol=0, atol=2e-4 * np.abs(b[key]).max(), err_msg=key)
 
 
 def test_device_setup_long_rows_fall_back(hip, oracle):

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cs_timed(CsView A, const double 
       const int q = tid + i * kCsThreads;
       if (((q >> 6) << 8) < S.pi.y) { S.ic[i] = i4[q]; S.va[i] = v2[2 * q]; S.vb[i] = v2[2 * q + 1]; }
     }
-    S.meta = A.meta[(size_t)g * kCsThreads + tid];
+    S.meta = A.meta[((size_t)g * kCsThreads + tid) * (RPT == 16 ? 2 : 1)]; if (RPT == 16) S.meta1 = A.meta[((size_t)g * kCsThreads + tid) * 2 + 1];
   };
   auto gather = [&](const CsSet<NQ> &S) {
     const double *xb = x + S.pi.x;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kCsThreads) void k_cs_timed(CsView A, const double 
     if (g + 1 < g1) gather(Y);
     if (g + 2 < g1) load(g + 2, X);
     STAMP(T_ISSUE);
-    cs_row_sums<RPT>(pb, mc, acc);
+    cs_row_sums<RPT>(pb, mc, RPT == 16 ? X.meta1 : 0ull, acc);
     STAMP(T_ROWSUM);
   };
   if (g0 < g1) {
@@ -153,10 +153,17 @@ struct EpiRaw2 {
 
 struct DevCs {
   int *passptr; int2 *pinfo; unsigned *idx; double *val; unsigned long long *meta; CsView v; HostCs hc;
-  bool build(const Csr &M, int rpt, int split) {
+  double *scratch = nullptr; unsigned *ticket = nullptr;
+  bool build(const Csr &M, int rpt, int split, bool combine = false) {
     if (!build_cs(M.rowptr.data(), M.col.data(), M.val.data(), M.rows, M.cols, hc, rpt, split)) return false;
     passptr = to_dev(hc.passptr); pinfo = to_dev(hc.pinfo); idx = to_dev(hc.idx); val = to_dev(hc.val); meta = to_dev(hc.meta);
     v = CsView{passptr, pinfo, idx, val, meta, hc.rows, hc.cols, hc.nchunks, hc.R, hc.npass, hc.rpt, hc.split};
+    if (combine && split > 1) {
+      HIP_CHECK(hipMalloc(&scratch, (size_t)hc.nchunks * split * kCsThreads * hc.rpt * 8));
+      HIP_CHECK(hipMalloc(&ticket, (size_t)hc.nchunks * 4));
+      HIP_CHECK(hipMemset(ticket, 0, (size_t)hc.nchunks * 4));
+      v.scratch = scratch; v.ticket = ticket;
+    }
     return true;
   }
   void free() { hipFree(passptr); hipFree(pinfo); hipFree(idx); hipFree(val); hipFree(meta); }
@@ -252,6 +259,62 @@ static void bench_matrix(const char *name, const Csr &M, int split) {
   hipFree(dx); hipFree(dy); hipFree(dy1);
 }
 
+// in-kernel combine: correctness of EVERY row over many launches (stale partials of the previous launch sit in the L2s),
+// with changing x so that a stale read cannot go unnoticed
+static void bench_combine(const char *name, const Csr &M, int split) {
+  DevCs D;
+  if (!D.build(M, 0, split, true)) { std::printf("%s split %d: build failed\n", name, split); return; }
+  std::printf("%s: combine mode split %d  R=%d rpt=%d wgs=%d passes=%d\n", name, split, D.hc.R, D.hc.rpt, D.hc.nchunks * split, D.hc.npass);
+  std::mt19937_64 g(11);
+  std::normal_distribution<double> nd;
+  double *dy; HIP_CHECK(hipMalloc(&dy, M.rows * sizeof(double)));
+  long bad_total = 0; double worst = 0;
+  std::vector<double> x(M.cols), ref(M.rows), h(M.rows);
+  double *dx; HIP_CHECK(hipMalloc(&dx, M.cols * 8));
+  for (int rep = 0; rep < 6; ++rep) {
+    for (auto &v : x) v = nd(g) * (rep + 1);
+    HIP_CHECK(hipMemcpy(dx, x.data(), M.cols * 8, hipMemcpyHostToDevice));
+    for (int r = 0; r < M.rows; ++r) { double s = 0.; for (int p = M.rowptr[r]; p < M.rowptr[r + 1]; ++p) s += M.val[p] * x[M.col[p]]; ref[r] = s; }
+    HIP_CHECK(hipMemset(dy, 0xff, M.rows * 8));
+    for (int k = 0; k < 3; ++k) launch_spmv_cs(D.v, dx, EpiStore{dy, 0}, nullptr, 0, nullptr);
+    HIP_CHECK(hipMemcpy(h.data(), dy, M.rows * 8, hipMemcpyDeviceToHost));
+    double scl = 0, err = 0;
+    for (int r = 0; r < M.rows; ++r) { scl = std::max(scl, std::fabs(ref[r])); const double e = std::fabs(h[r] - ref[r]); if (!(e <= 1e300)) err = 1e300; else err = std::max(err, e); }
+    long bad = 0;
+    for (int r = 0; r < M.rows; ++r) bad += !(std::fabs(h[r] - ref[r]) <= 1e-12 * scl);
+    bad_total += bad; worst = std::max(worst, err / scl);
+  }
+  auto launch = [&] { launch_spmv_cs(D.v, dx, EpiStore{dy, 0}, nullptr, 0, nullptr); };
+  std::printf("  braided + in-kernel combine: %.1f us   rows off by > 1e-12: %ld   worst rel err %.2e\n", time_us(launch, 30), bad_total, worst);
+  {
+    const int nwg = D.hc.nchunks * D.hc.split, nw = kCsThreads / 64;
+    std::vector<unsigned long long> hh((size_t)256 * 16 * 8);
+    HIP_CHECK(hipMemcpyFromSymbol(hh.data(), HIP_SYMBOL(cs_lab_tl), hh.size() * 8));
+    double avg[7] = {0}, mx[7] = {0};
+    for (int w = 0; w < nwg * nw; ++w)
+      for (int i = 0; i < 7; ++i) { avg[i] += (double)hh[(size_t)w * 8 + i]; mx[i] = std::max(mx[i], (double)hh[(size_t)w * 8 + i]); }
+    const char *names[7] = {"prologue", "wait+scatter", "barrier", "braid", "combine+epilogue", "-", "total"};
+    std::printf("    timeline, kcycles per wave: ");
+    for (int i = 0; i < 7; ++i) if (i != 5) std::printf("%s %.1f (max %.1f)  ", names[i], avg[i] / (nwg * nw) * 1e-3, mx[i] * 1e-3);
+    std::printf("\n");
+  }
+  {  // the same layout without the combine: partial outputs
+    CsView v2 = D.v; v2.scratch = nullptr; v2.ticket = nullptr;
+    double *dy1; HIP_CHECK(hipMalloc(&dy1, M.rows * 8));
+    auto l2 = [&] { launch_spmv_cs(v2, dx, EpiRaw2{dy, dy1}, nullptr, 0, nullptr); };
+    if (split == 2) std::printf("    same layout, partial outputs (no combine): %.1f us\n", time_us(l2, 30));
+    const dim3 gg(D.hc.nchunks * D.hc.split), bb(kCsThreads);
+    if (D.hc.rpt == 16) {
+      auto a0 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 16, 0>), gg, bb, 0, 0, v2, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+      auto a1 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 16, 1>), gg, bb, 0, 0, v2, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+      auto a2 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 16, 2>), gg, bb, 0, 0, v2, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+      std::printf("    no combine (parts write to 2 vectors): %.1f us; gathers from 2 KB table %.1f us; no row sums %.1f us\n", time_us(a0, 20), time_us(a1, 20), time_us(a2, 20));
+    }
+    hipFree(dy1);
+  }
+  D.free(); hipFree(dx); hipFree(dy);
+}
+
 int main(int argc, char **argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 2000000, n = argc > 2 ? atoi(argv[2]) : 1000000;
   const int k = argc > 3 ? atoi(argv[3]) : 20;
@@ -272,7 +335,13 @@ int main(int argc, char **argv) {
   }
   Csr Ar;
   transpose(At, Ar);
-  bench_matrix("K1 shape  CSR(A)", Ar, 1);
-  bench_matrix("K2 shape  CSR(A')", At, 2);
+  if (getenv("LAB_BASE")) {
+    bench_matrix("K1 shape  CSR(A)", Ar, 1);
+    bench_matrix("K2 shape  CSR(A')", At, 2);
+  }
+  bench_combine("K1 shape  CSR(A)", Ar, 2);
+  bench_combine("K2 shape  CSR(A')", At, 2);
+  bench_combine("K2 shape  CSR(A')", At, 4);
+  if (Ar.rows <= 1000000) bench_combine("K1 shape  CSR(A)", Ar, 4);
   return 0;
 }

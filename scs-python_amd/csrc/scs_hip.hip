@@ -422,6 +422,8 @@ struct ScsHipWork {
   DevBuf<int> soc_off, soc_dim, soc_big;
   int n_soc = 0, n_soc_big = 0;
   DevBuf<double> pow_a, box_bl, box_bu;
+  DevBuf<double> box_bl_orig, box_bu_orig, box_parts;
+  DevBuf<unsigned> box_ticket;  // the caller's bounds (the working copies follow the row scaling): footer diagnostics
   DevBuf<int> psd_off, psd_order;    // orders > kPsdSmallMax first (n_psd_big of them), then the small ones
   DevBuf<long> psd_woff;
   DevBuf<double> psd_scratch;
@@ -873,7 +875,16 @@ struct ScsHipWork {
 
   // in-place projection of the m-slice y onto K (dual=0) or K* (dual=1), rows z/l excluded (handled by caller)
   void project_nonlinear_cones(double *y, int dual) {
-    if (cone.bsize > 0) {
+    if (cone.bsize > kBoxMultiMin) {  // large box cone: one launch per Newton round over many workgroups (cones.hpp)
+      if (!box_parts.p) { box_parts.alloc_zero(2 * kBoxMultiMaxWgs, stream); box_ticket.alloc_zero(1, stream); }
+      const int wgs = box_multi_wgs(cone.bsize);
+      double *state = sc.p + S_BOX_T;  // {t (warm start of the next call), stop flag}
+      for (int round = 0; round < kBoxRounds; ++round)
+        hipLaunchKernelGGL(k_proj_box_round, dim3(wgs), dim3(kBoxMultiThreads), 0, stream, (const double *)(y + cone.off_box), box_bl.p,
+                           box_bu.p, cone.bsize, state, box_parts.p, box_ticket.p, dual, round, stall);
+      hipLaunchKernelGGL(k_proj_box_apply, dim3(wgs), dim3(kBoxMultiThreads), 0, stream, y + cone.off_box, box_bl.p, box_bu.p, cone.bsize,
+                         state, dual, stall);
+    } else if (cone.bsize > 0) {
       hipLaunchKernelGGL(k_proj_box, dim3(1), dim3(kBoxThreads), 0, stream, y + cone.off_box, box_bl.p, box_bu.p, cone.bsize,
                          sc.p + S_BOX_T, dual, stall);
     }
@@ -1023,6 +1034,37 @@ struct ScsHipWork {
     v_norm_fresh = false;
   }
 
+  // ||v - Pi(v)||_2 for a host vector in ORIGINAL units: Pi = projection onto K (dual = 0) or K* (dual = 1), with the
+  // hot-path cone kernels (footer diagnostics of a verbose solve: "dist(s, K)", "dist(y, K*)").  The box-cone warm start
+  // is saved and restored; PSD eigenvector warm starts are not used (and are left as the projection leaves them).
+  double cone_dist(const double *hv, int dual) {
+    if (!std::isfinite(hv[0])) return NAN;
+    HIP_CHECK(hipMemcpyAsync(sols.p, hv, sizeof(double) * m, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(tmp_m.p, sols.p, sizeof(double) * m, hipMemcpyDeviceToDevice, stream));
+    double box_t = 1.0;
+    HIP_CHECK(hipMemcpyAsync(&box_t, sc.p + S_BOX_T, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::swap(box_bl.p, box_bl_orig.p);
+    std::swap(box_bu.p, box_bu_orig.p);
+    const int warm_keep = psd_warm;
+    psd_warm = 0;
+    if (cone.z + cone.l > 0)
+      hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(cone.z + cone.l, kConeThreads)), dim3(kConeThreads), 0, stream, tmp_m.p, cone.z, cone.l, dual);
+    project_nonlinear_cones(tmp_m.p, dual);
+    psd_warm = warm_keep;
+    std::swap(box_bl.p, box_bl_orig.p);
+    std::swap(box_bu.p, box_bu_orig.p);
+    const int nb = vb(m);
+    hipLaunchKernelGGL(k_aa_diffsq, dim3(nb), dim3(kVecThreads), 0, stream, (const double *)sols.p, (const double *)tmp_m.p, (long)m, part.p);
+    std::vector<double> hp(nb);
+    HIP_CHECK(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(sc.p + S_BOX_T, &box_t, sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double ss = 0.;
+    for (double v : hp) ss += v;
+    return std::sqrt(ss);
+  }
+
   // one CSV row: residuals of this iteration are already in `r`; diff norms are reduced here
   void log_csv_row(FILE *f, int iter, double elapsed_ms) {
     const int nbl = vb(l);
@@ -1051,7 +1093,14 @@ static void upload_cone_meta(ScsHipWork *w) {
   if (w->n_soc) { w->soc_off.upload(off.data(), off.size(), s); w->soc_dim.upload(dim.data(), dim.size(), s); }
   if (w->n_soc_big) w->soc_big.upload(big.data(), big.size(), s);
   if (!c.p.empty()) w->pow_a.upload(c.p.data(), c.p.size(), s);
-  if (c.bsize > 1) { w->box_bl.upload(c.bl.data(), c.bl.size(), s); w->box_bu.upload(c.bu.data(), c.bu.size(), s); }
+  if (c.bsize > 1) {
+    w->box_bl.upload(c.bl.data(), c.bl.size(), s);
+    w->box_bu.upload(c.bu.data(), c.bu.size(), s);
+    if (!w->box_bl_orig.p) {  // (scs_init uploaded the originals before the row scaling; the standalone entry points have none)
+      w->box_bl_orig.upload(c.bl.data(), c.bl.size(), s);
+      w->box_bu_orig.upload(c.bu.data(), c.bu.size(), s);
+    }
+  }
   std::vector<int> poff, pord;
   std::vector<long> woff;
   long wtot = 0;
@@ -1285,6 +1334,11 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     sym_expand(n, d->P->p, d->P->i, d->P->x, pf, pdiag);
     w->Pf.upload(n, n, pf.rowptr.data(), pf.col.data(), pf.val.data(), s, /*allow_slab=*/host_build);
     w->px.alloc_zero(n, s);
+  }
+  if (w->cone.bsize > 1) {  // the caller's box bounds, before the row scaling touches the working copies
+    w->box_bl_orig.upload(w->cone.bl.data(), w->cone.bl.size(), s);
+    w->box_bu_orig.upload(w->cone.bu.data(), w->cone.bu.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
   }
   // ---- K12: equilibrate on the device, in place in all resident layouts ----
   if (w->normalized) {
@@ -1656,6 +1710,28 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
                 info->status, (info->setup_time + info->solve_time) / 1e3, info->setup_time / 1e3, info->solve_time / 1e3,
                 t_lin / 1e3, t_cone / 1e3, t_acc / 1e3);
     std::printf("lin-sys: avg cg its: %.2f\n", info->iter > 0 ? (double)w->tot_cg_iters / (info->iter + 1) : 0.0);
+    std::printf("------------------------------------------------------------------\n");
+    // solution / certificate quality, the block the reference prints here (R:notebooks/scs_benchmarks.ipynb cells 2, 3)
+    switch (info->status_val) {
+      case SCS_SOLVED:
+      case SCS_SOLVED_INACCURATE: {
+        double sy = 0., ns = 0., ny = 0.;
+        for (int j = 0; j < m; ++j) { sy += sol->s[j] * sol->y[j]; ns += sol->s[j] * sol->s[j]; ny += sol->y[j] * sol->y[j]; }
+        std::printf("cones: dist(s, K) = %.2e, dist(y, K*) = %.2e\n", w->cone_dist(sol->s, 0), w->cone_dist(sol->y, 1));
+        std::printf("comp slack: s'y/|s||y| = %.2e, gap: |x'Px+c'x+b'y| = %.2e\n", safediv_pos(sy, std::sqrt(ns) * std::sqrt(ny)), info->gap);
+        std::printf("pri res: |Ax+s-b| = %.2e, dua res: |Px+A'y+c| = %.2e\n", info->res_pri, info->res_dual);
+        break;
+      }
+      case SCS_INFEASIBLE:
+      case SCS_INFEASIBLE_INACCURATE:
+        std::printf("cone: dist(y, K*) = %.2e\n", w->cone_dist(sol->y, 1));
+        std::printf("cert: |A'y| = %.2e\n      b'y = %.2f\n", info->res_infeas, -1.0);
+        break;
+      default:
+        std::printf("cone: dist(s, K) = %.2e\n", w->cone_dist(sol->s, 0));
+        std::printf("cert: |Ax+s| = %.2e\n      |Px| = %.2e\n      c'x = %.2f\n", info->res_unbdd_a, info->res_unbdd_p, -1.0);
+        break;
+    }
     std::printf("------------------------------------------------------------------\n");
     std::printf("objective = %.6f\n", info->pobj);
     std::printf("------------------------------------------------------------------\n");

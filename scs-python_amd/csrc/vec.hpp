@@ -21,7 +21,7 @@ constexpr int kMaxVecBlocks = 2048;
 // device scalar slots (double)
 enum : int {
   S_ZTR = 0, S_ZTR_B, S_ALPHA, S_BETA, S_TOL, S_RNORM, S_TAUT, S_VSCALE, S_GG, S_WSNORM, S_AA_NORMG, S_AA_NORMD,
-  S_AA_NORM, S_AA_REG, S_BOX_T, S_TMP0, S_TMP1, S_TMP2, S_TMP3, S_COUNT = 32
+  S_AA_NORM, S_AA_REG, S_BOX_T, S_BOX_STOP, S_TMP1, S_TMP2, S_TMP3, S_COUNT = 32
 };
 // device flag slots (int)
 enum : int {

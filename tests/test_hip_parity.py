@@ -109,6 +109,24 @@ def test_cone_projection_large_mixed(hip, oracle):
             np.testing.assert_allclose(got, ref, rtol=0, atol=2e-8 * scl)
 
 
+@pytest.mark.parametrize("nb,scl,shift", [(20000, 1.0, 0.0), (50001, 10.0, 5.0), (17000, 1.0, -1e5), (100000, 0.3, 2.0)])
+def test_box_cone_many_workgroups_vs_oracle(hip, oracle, nb, scl, shift):
+    """box cones beyond 16384 bounds run the Newton iteration on t as one launch per round over many workgroups
+    (last-arriver reduction); same answer as the oracle's sequential Newton, primal and dual, incl. t* = 0
+    (shift << 0) and a repeated call (device-side warm start of t)"""
+    rng = np.random.RandomState(nb % 97)
+    K = {"l": 7, "bu": (rng.rand(nb) * 2 + 0.1).tolist(), "bl": (-rng.rand(nb) * 2 - 0.1).tolist(), "q": [5]}
+    z = scl * rng.randn(pg.cone_dims(K))
+    z[7] += shift  # the t entry
+    for dual in (False, True):
+        ref = oracle.proj_cone(z, K, dual=dual)
+        got = hip.proj_cone(z, K, dual=dual)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-8 * max(1.0, np.abs(z).max()))
+        np.testing.assert_array_equal(hip.proj_cone(z, K, dual=dual), got)  # run-to-run: fixed-order reduction
+    if shift < -10:
+        assert hip.proj_cone(z, K)[7] == 0.0 and oracle.proj_cone(z, K)[7] == 0.0
+
+
 @pytest.mark.parametrize("with_P", [False, True])
 def test_kkt_solve_vs_direct_ldl(hip, oracle, with_P):
     m, n = 600, 250

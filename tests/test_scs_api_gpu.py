@@ -20,32 +20,37 @@ def scs():
     return _scs
 
 
-SOLVERS = ["hip_indirect", "auto"]
-
-c = np.array([-1.0])
-b = np.array([1.0, 0.0])
-A = sp.csc_matrix([1.0, -1.0]).T.tocsc()
-data = {"A": A, "b": b, "c": c}
+BACKENDS = ("hip_indirect", "auto")
 
 
-@pytest.mark.parametrize("cone,expected", [({"q": [], "l": 2}, 1), ({"q": [2], "l": 0}, 0.5)])
-@pytest.mark.parametrize("ls", SOLVERS)
-def test_problems(scs, cone, ls, expected):
-    # R:test/test_scs_basic.py:57-72
-    sol = scs.SCS(data, cone=cone, linear_solver=ls, verbose=False).solve()
-    assert_almost_equal(sol["x"][0], expected, decimal=2)
+def _one_variable_problem():
+    """maximise x subject to x <= 1, x >= 0 — written as  min -x,  [1; -1] x + s = [1; 0],  s in K.
+    (the one-variable instance the reference's smoke tests use, R:test/test_scs_basic.py:36-72)"""
+    return {"A": sp.csc_matrix(np.array([[1.0], [-1.0]])), "b": np.array([1.0, 0.0]), "c": np.array([-1.0])}
 
 
-def test_failures(scs):
-    # R:test/test_scs_basic.py:95-114
-    with pytest.raises(TypeError):
-        scs.solve()
-    with pytest.raises(ValueError):
-        scs.solve(data, {"q": [4], "l": -2})
-    with pytest.raises(TypeError):
-        scs.solve(data, {"q": [], "l": 2}, max_iters=1.1)
-    with pytest.raises(ValueError):
-        scs.solve(data, {"q": [1], "l": 0}, verbose=False)
+data = _one_variable_problem()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_one_variable_lp_and_soc(scs, backend):
+    """K = R^2_+ : x* = 1.  K = Q^2 (s_1 >= |s_2|, i.e. 1 - x >= x): x* = 1/2."""
+    for K, x_star in (({"l": 2, "q": []}, 1.0), ({"l": 0, "q": [2]}, 0.5)):
+        out = scs.SCS(data, cone=K, linear_solver=backend, verbose=False).solve()
+        assert out["info"]["status"] == "solved"
+        assert abs(out["x"][0] - x_star) < 5e-3, (K, out["x"])
+
+
+def test_bad_calls_are_rejected(scs):
+    """argument errors surface as the exception types the reference raises (R:test/test_scs_basic.py:95-114)"""
+    for exc, call in (
+        (TypeError, lambda: scs.solve()),                                           # no data at all
+        (ValueError, lambda: scs.solve(data, {"l": -2, "q": [4]})),                 # negative cone size
+        (TypeError, lambda: scs.solve(data, {"l": 2, "q": []}, max_iters=1.1)),     # float where an int is required
+        (ValueError, lambda: scs.solve(data, {"l": 0, "q": [1]}, verbose=False)),   # cone dimensions do not add up to m
+    ):
+        with pytest.raises(exc):
+            call()
 
 
 def test_legacy_solve_with_warm_start_in_data(scs):
@@ -199,6 +204,33 @@ def test_verbose_false_prints_nothing(scs, capfd):
     assert out.out == "" and out.err == ""
     scs.SCS(data, {"l": 2}, verbose=True).solve()
     assert "status" in capfd.readouterr().out
+
+
+def test_verbose_footer_reports_solution_quality_and_certificates(scs, capfd):
+    """the block the reference prints under the timings (R:notebooks/scs_benchmarks.ipynb cells 2, 3 outputs): cone
+    distances, complementary slackness, residuals for a solved problem; the certificate lines for an infeasible and an
+    unbounded one"""
+    import re
+    dat, K, p_star = helpers.load_problem("problems_std.npz", "std_feas_")
+    scs.SCS(dat, K, verbose=True, eps_abs=1e-6, eps_rel=1e-6).solve()
+    out = capfd.readouterr().out
+    m_ = re.search(r"cones: dist\(s, K\) = (\S+), dist\(y, K\*\) = (\S+)", out)
+    assert m_ and float(m_.group(1)) < 1e-6 and float(m_.group(2)) < 1e-6, out[-900:]
+    assert re.search(r"comp slack: s'y/\|s\|\|y\| = \S+, gap: \|x'Px\+c'x\+b'y\| = \S+", out)
+    assert re.search(r"pri res: \|Ax\+s-b\| = \S+, dua res: \|Px\+A'y\+c\| = \S+", out)
+    dat, K, _ = helpers.load_problem("problems_std.npz", "std_infeas_")
+    scs.SCS(dat, K, verbose=True).solve()
+    out = capfd.readouterr().out
+    assert "status:  infeasible" in out and re.search(r"cone: dist\(y, K\*\) = \S+", out)
+    m_ = re.search(r"cert: \|A'y\| = (\S+)\n\s+b'y = -1.00", out)
+    assert m_ and float(m_.group(1)) < 1e-3, out[-600:]
+    dat, K, _ = helpers.load_problem("problems_std.npz", "std_unbdd_")
+    scs.SCS(dat, K, verbose=True).solve()
+    out = capfd.readouterr().out
+    assert "status:  unbounded" in out and re.search(r"cone: dist\(s, K\) = \S+", out)
+    m_ = re.search(r"cert: \|Ax\+s\| = (\S+)\n\s+\|Px\| = (\S+)\n\s+c'x = -1.00", out)
+    assert m_ and float(m_.group(1)) < 1e-3, out[-600:]
+    assert "objective = -inf" in out
 
 
 def test_independent_instances_run_concurrently(scs):

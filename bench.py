@@ -128,7 +128,7 @@ def main():
     # ---------------- synthetic instance (per rank) ----------------
     K, n, k, seed = pg.workload(args.workload)
     t0 = time.perf_counter()
-    data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, proj)
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, proj, pattern=pg.workload_pattern(args.workload))
     m = data["A"].shape[0]
     nnz = int(data["A"].nnz)
     t_gen = time.perf_counter() - t0

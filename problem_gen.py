@@ -48,14 +48,48 @@ def random_sparse(m, n, nnz_per_col, rng):
                               np.arange(0, n * k + 1, k, dtype=np.int32)), shape=(m, n))
 
 
-def gen_feasible(K, n, nnz_per_col, seed, proj_dual):
-    """Returns (data, p_star, (x, y, s)).  proj_dual(z, K) must return Pi_{K*}(z)."""
+def powerlaw_sparse(m, n, nnz_per_row, rng, shape=1.3, cap=20000):
+    """m x n CSC whose ROW lengths are heavy-tailed (Pareto, mean ~ nnz_per_row, capped), columns uniform: a few rows
+    with thousands of nonzeros next to many short ones (budget / coupling constraints of real LPs look like this)."""
+    raw = rng.pareto(shape, m) + 0.05
+    lens = np.minimum(np.maximum((raw * (nnz_per_row / raw.mean())).astype(np.int64), 1), min(cap, n))
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
+    A = sparse.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def banded_sparse(m, n, nnz_per_row, rng):
+    """m x n CSC with a band of nnz_per_row entries around the (stretched) diagonal: row i touches columns
+    floor(i n / m) + (-k/2 .. k/2) — perfect gather locality, the opposite extreme of the uniform pattern."""
+    k = int(nnz_per_row)
+    base = (np.arange(m, dtype=np.int64) * n) // m
+    cols = base[:, None] + np.arange(-(k // 2), k - k // 2, dtype=np.int64)[None, :]
+    ok = (cols >= 0) & (cols < n)
+    rows = np.broadcast_to(np.arange(m, dtype=np.int64)[:, None], cols.shape)[ok]
+    A = sparse.csc_matrix((rng.standard_normal(int(ok.sum())), (rows, cols[ok])), shape=(m, n))
+    A.sort_indices()
+    return A
+
+
+def gen_feasible(K, n, nnz_per_col, seed, proj_dual, pattern="uniform"):
+    """Returns (data, p_star, (x, y, s)).  proj_dual(z, K) must return Pi_{K*}(z).
+    pattern: "uniform" (nnz_per_col random rows per column), "powerlaw" / "banded" (nnz_per_col * n / m per row)."""
     rng = np.random.default_rng(seed)
     m = cone_dims(K)
     z = rng.standard_normal(m)
     y = np.asarray(proj_dual(z, K), dtype=np.float64)
     s = y - z
-    A = random_sparse(m, n, nnz_per_col, rng)
+    if pattern == "uniform":
+        A = random_sparse(m, n, nnz_per_col, rng)
+    elif pattern == "powerlaw":
+        A = powerlaw_sparse(m, n, nnz_per_col * n / m, rng)
+    elif pattern == "banded":
+        A = banded_sparse(m, n, max(1, int(round(nnz_per_col * n / m))), rng)
+    else:
+        raise KeyError(pattern)
     x = rng.standard_normal(n)
     c = -(A.T @ y)
     b = A @ x + s
@@ -73,11 +107,20 @@ def workload(name):
         return {"l": 1000000, "q": [10] * 100000}, 1000000, 20, 5
     if name == "target_lp":
         return {"l": 2000000}, 1000000, 20, 5
+    if name == "powerlaw_lp":     # layout robustness: metric size, heavy-tailed row lengths (pattern: workload_pattern)
+        return {"l": 2000000}, 1000000, 20, 11
+    if name == "banded_lp":       # layout robustness: metric size, banded
+        return {"l": 2000000}, 1000000, 20, 12
     if name == "small_lp_soc":    # smoke / CI size
         return {"l": 2000, "q": [10] * 200}, 2000, 20, 7
     if name == "config5_small":   # one problem of the 512-problem batch
         return {"l": 2000, "q": [50] * 20, "s": [20] * 5}, 1350, 40, 1000
     raise KeyError(name)
+
+
+def workload_pattern(name):
+    """sparsity pattern family of a named workload (gen_feasible's `pattern`)"""
+    return {"powerlaw_lp": "powerlaw", "banded_lp": "banded"}.get(name, "uniform")
 
 
 def gen_feasible_qp(K, n, nnz_per_col, seed, proj_dual, p_diag=1.0):

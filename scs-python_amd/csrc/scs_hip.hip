@@ -67,6 +67,34 @@ struct DeviceCsr {
     const char *e = getenv("SCS_HIP_CS");
     return !(e && e[0] == '0');
   }
+  // rows too long for the layout's count fields are peeled off it (spmv_cs.hpp CsView::peel) and done over the plain CSR
+  DevBuf<unsigned> peel_mask;
+  DevBuf<int4> peel_blk;
+  int npeel = 0;
+  // host: mark rows longer than `thresh`; one row block {row, row + 1, first nonzero, end} each.  false: nothing to peel
+  bool make_peel(const int *rp_host, int thresh, hipStream_t s) {
+    peel_mask.release(); peel_blk.release(); npeel = 0;
+    if (getenv("SCS_HIP_CS_PEEL") && getenv("SCS_HIP_CS_PEEL")[0] == '0') return false;  // A/B: reject such patterns as round 1 did
+    std::vector<int4> blk;
+    std::vector<unsigned> mask;
+    for (int r = 0; r < rows; ++r)
+      if (rp_host[r + 1] - rp_host[r] > thresh) {
+        if (mask.empty()) mask.assign(((size_t)rows + 31) / 32, 0u);
+        mask[r >> 5] |= 1u << (r & 31);
+        blk.push_back(int4{r, r + 1, rp_host[r], rp_host[r + 1]});
+      }
+    if (blk.empty()) return false;
+    npeel = (int)blk.size();
+    peel_mask.upload(mask.data(), mask.size(), s);
+    peel_blk.upload(blk.data(), blk.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    return true;
+  }
+  int peel_threshold(int split) const {
+    int R, rpt;
+    cs_pick_geometry(rows, R, rpt, split);
+    return cs_peel_threshold(rpt);
+  }
   DevBuf<double> cs_part0, cs_part1;  // cs.split == 2 without the in-kernel combine: partial row sums (spmv.hpp EpiPartial / EpiGp::split)
   static bool cs_split_enabled() {  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (bit-exact sequential row sums; A/B)
     const char *e = getenv("SCS_HIP_CS_SPLIT");
@@ -111,25 +139,52 @@ struct DeviceCsr {
   // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays.
   bool build_cs_dev(const DeviceCsr &T, hipStream_t s, int kind) {
     cs.release();
+    peel_mask.release(); peel_blk.release(); npeel = 0;
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     bool ok = false;
     const int sp = cs_pick_split(kind);
-    if (sp > 1) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, sp);
-    if (!ok) ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1);
+    std::vector<int> rp((size_t)rows + 1);  // row lengths decide what is peeled (O(rows) at init)
+    rowptr.download(rp.data(), rp.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (sp > 1) {
+      make_peel(rp.data(), peel_threshold(sp), s);
+      ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, sp, peel_mask.p);
+    }
+    if (!ok) {
+      make_peel(rp.data(), peel_threshold(1), s);
+      ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1, peel_mask.p);
+    }
+    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; }
     cs_after_build(s);
     return ok;
   }
   bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, int kind) {
     cs.release();
+    peel_mask.release(); peel_blk.release(); npeel = 0;
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
     bool ok = false;
     const int sp = cs_pick_split(kind);
-    if (sp > 1) ok = build_cs(rp, ci, v, rows, cols, h, 0, sp);
-    if (!ok) ok = build_cs(rp, ci, v, rows, cols, h, 0, 1);
-    if (!ok) return false;
+    auto host_mask = [&](int split) {  // the same rows make_peel marks
+      std::vector<unsigned> mk;
+      if (make_peel(rp, peel_threshold(split), s)) {
+        mk.assign(((size_t)rows + 31) / 32, 0u);
+        for (int r = 0; r < rows; ++r)
+          if (rp[r + 1] - rp[r] > peel_threshold(split)) mk[r >> 5] |= 1u << (r & 31);
+      }
+      return mk;
+    };
+    if (sp > 1) {
+      const std::vector<unsigned> mk = host_mask(sp);
+      ok = build_cs(rp, ci, v, rows, cols, h, 0, sp, mk.empty() ? nullptr : mk.data());
+    }
+    if (!ok) {
+      const std::vector<unsigned> mk = host_mask(1);
+      ok = build_cs(rp, ci, v, rows, cols, h, 0, 1, mk.empty() ? nullptr : mk.data());
+    }
+    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; return false; }
     cs.from_host(h, s);
     cs_after_build(s);
     return true;
@@ -247,10 +302,15 @@ struct DeviceCsr {
     M.use_slab = has_slab;
     if (has_slab) M.slab = SlabView{s_segptr.p, s_roff.p, s_col.p, s_val.p, rows, cols, s_nchunks, s_S, s_R, s_max_seg};
     M.use_cs = cs.ok;
-    if (cs.ok) { M.cs = cs.view(); M.part0 = cs_part0.p; M.part1 = cs_part1.p; }
+    if (cs.ok) {
+      M.cs = cs.view(); M.part0 = cs_part0.p; M.part1 = cs_part1.p;
+      M.cs.peel = npeel > 0 ? peel_mask.p : nullptr;
+      M.peel_blk = peel_blk.p;
+      M.npeel = npeel;
+    }
     return M;
   }
-  int nwg() const { return cs.ok ? (cs.combine() ? cs.nchunks : cs.nchunks * cs.split) : has_slab ? s_nchunks : nblk; }
+  int nwg() const { return cs.ok ? (cs.combine() ? cs.nchunks : cs.nchunks * cs.split) + npeel : has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
     if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)
@@ -1974,7 +2034,29 @@ int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_floa
     }
     HostCs h;
     if (split != 1 && split != 2 && split != 4) throw std::runtime_error("split must be 1, 2 or 4");
-    if (!build_cs(rp, ci, v, rows, cols, h, rpt, split)) return 1;
+    // rows the count fields cannot hold are peeled off the layout, as scs_init does, and summed from the plain CSR
+    std::vector<unsigned> mk;
+    {
+      int R0, rpt0;
+      cs_pick_geometry(rows, R0, rpt0, split);
+      if (rpt > 0) rpt0 = rpt;
+      const int thresh = cs_peel_threshold(rpt0);
+      const char *pe = getenv("SCS_HIP_CS_PEEL");
+      if (!(pe && pe[0] == '0'))
+        for (int r = 0; r < rows; ++r)
+          if (rp[r + 1] - rp[r] > thresh) {
+            if (mk.empty()) mk.assign(((size_t)rows + 31) / 32, 0u);
+            mk[r >> 5] |= 1u << (r & 31);
+          }
+    }
+    if (!build_cs(rp, ci, v, rows, cols, h, rpt, split, mk.empty() ? nullptr : mk.data())) return 1;
+    if (!mk.empty())
+      for (int r = 0; r < rows; ++r)
+        if (cs_is_peeled(mk.data(), r)) {
+          double sacc = 0.;
+          for (int q = rp[r]; q < rp[r + 1]; ++q) sacc += v[q] * x[ci[q]];
+          y[r] += sacc;
+        }
     const int cb = cs_count_bits(h.rpt), mw = cs_meta_words(h.rpt);
     std::vector<double> prod(kCsPass), acc((size_t)kCsThreads * h.rpt), tot((size_t)kCsThreads * h.rpt);
     for (int c = 0; c < h.nchunks; ++c) {

@@ -39,14 +39,15 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned *k) {
 }
 
 // hist[chunk * nblocks + block]
-__global__ __launch_bounds__(1024) void k_cs_hist(const int *__restrict__ trow, long nnz, int R, int nchunks, int nblocks, int *hist) {
+__global__ __launch_bounds__(1024) void k_cs_hist(const int *__restrict__ trow, long nnz, int R, int nchunks, int nblocks, int *hist,
+                                                  const unsigned *__restrict__ peel) {
   __shared__ int cnt[kCsMaxChunks];
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < nchunks; c += blockDim.x) cnt[c] = 0;
   __syncthreads();
   for (int l = threadIdx.x; l < kCsBlock; l += blockDim.x) {
     const long p = (long)b * kCsBlock + l;
-    if (p < nnz) atomicAdd(&cnt[trow[p] / R], 1);
+    if (p < nnz && !cs_is_peeled(peel, trow[p])) atomicAdd(&cnt[trow[p] / R], 1);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < nchunks; c += blockDim.x) hist[(size_t)c * nblocks + b] = cnt[c];
@@ -54,13 +55,13 @@ __global__ __launch_bounds__(1024) void k_cs_hist(const int *__restrict__ trow, 
 
 __global__ __launch_bounds__(1024) void k_cs_scatter(const int *__restrict__ tptr, const int *__restrict__ trow, int trows, long nnz, int R,
                                                      int nchunks, int nblocks, const int *__restrict__ hoff, int *s_row, int *s_col,
-                                                     int *s_src) {
+                                                     int *s_src, const unsigned *__restrict__ peel) {
   __shared__ unsigned key[kCsBlock];
   __shared__ int first[kCsMaxChunks];
   const int b = blockIdx.x;
   for (int l = threadIdx.x; l < kCsBlock; l += blockDim.x) {
     const long p = (long)b * kCsBlock + l;
-    key[l] = p < nnz ? ((unsigned)(trow[p] / R) << 12) | (unsigned)l : 0xffffffffu;
+    key[l] = (p < nnz && !cs_is_peeled(peel, trow[p])) ? ((unsigned)(trow[p] / R) << 12) | (unsigned)l : 0xffffffffu;
   }
   bitonic_sort_lds<kCsBlock>(key);
   for (int i = threadIdx.x; i < kCsBlock; i += blockDim.x) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, i
   __shared__ int carry_sm;
   auto cut = [&](int v, int4 *out) {  // passes of workgroup v = chunk * split + part (written from out[0] on when out != nullptr)
     const int c = v / split, part = v - c * split;
-    const long c_begin = hoff[(size_t)c * nblocks], c_end = c + 1 < nchunks ? hoff[(size_t)(c + 1) * nblocks] : nnz;
+    const long c_begin = hoff[(size_t)c * nblocks], c_end = hoff[(size_t)(c + 1) * nblocks];  // (the scan's total closes the last chunk)
     // the chunk's stream cut into `split` parts at (multiples of 256 near) k * n / split
     const long e_begin = c_begin + cs_part_cut(c_end - c_begin, part, split), e_end = c_begin + cs_part_cut(c_end - c_begin, part + 1, split);
     int np = 0;
@@ -239,7 +240,7 @@ struct DeviceCs {
   // layout for the matrix M (rows_ x cols_) whose TRANSPOSE is the CSR (tptr, trow, tval) with cols_ rows.
   // false (and nothing kept) when the pattern does not fit the format: the caller keeps its other layouts.
   bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s,
-                            int split_ = 1) {
+                            int split_ = 1, const unsigned *peel = nullptr) {
     release();
     rows = rows_; cols = cols_; split = split_;
     cs_pick_geometry(rows, R, rpt, split);
@@ -254,10 +255,10 @@ struct DeviceCs {
     tmp.alloc_zero((size_t)(nh / kScanTile + 4), s);
     flag.alloc_zero(1, s);
     s_row.alloc((size_t)nnz); s_col.alloc((size_t)nnz); s_src.alloc((size_t)nnz);
-    hipLaunchKernelGGL(k_cs_hist, dim3(nblocks), dim3(1024), 0, s, trow, nnz, R, nchunks, nblocks, hist.p);
+    hipLaunchKernelGGL(k_cs_hist, dim3(nblocks), dim3(1024), 0, s, trow, nnz, R, nchunks, nblocks, hist.p, peel);
     device_exclusive_scan(hist.p, hoff.p, nh, tmp.p, s);
     hipLaunchKernelGGL(k_cs_scatter, dim3(nblocks), dim3(1024), 0, s, tptr, trow, cols, nnz, R, nchunks, nblocks, hoff.p, s_row.p,
-                       s_col.p, s_src.p);
+                       s_col.p, s_src.p, peel);
     // acceptance bound of build_cs: more passes than this means too much padding
     const long max_pass_l = (nnz + nnz / 4) / kCsPass + (long)nchunks * split + 1;
     const int max_pass = (int)std::min<long>(max_pass_l, 2000000000L / kCsPass);

@@ -36,6 +36,7 @@ struct CsrView {
   const int4 *blk;    // per row block {first row, end row, first nonzero, end nonzero}: one load instead of a dependent pair
   int rows, cols, nblk;
   long nnz;
+  int pstride = 0, pbase = 0;  // reduction partials: slot stride / first slot (0: this launch's own workgroup count / 0)
 };
 
 // Host-side: split rows into blocks of <= kNnzPerWg nonzeros (a longer row is alone in its block).
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const d
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
   __shared__ double prod[kNnzPerWg];
   __shared__ double red[kSpmvThreads / 64];
-  spmv_stream_block(A, x, epi, (int)blockIdx.x, (int)gridDim.x, prod, red, (int)threadIdx.x, BlockSync{});
+  // (blocks are addressed by blockIdx; the partial slots may be offset: side launches of the column-sorted layouts)
+  CsrView B = A;
+  B.blk = A.blk - A.pbase;
+  spmv_stream_block(B, x, epi, A.pbase + (int)blockIdx.x, A.pstride > 0 ? A.pstride : (int)gridDim.x, prod, red, (int)threadIdx.x, BlockSync{});
 }
 
 // ---------------------------------------------------------------------------
@@ -594,8 +598,13 @@ struct SpmvMat {
   CsView cs{};
   bool use_slab = false, use_cs = false;  // use_cs wins (spmv_cs.hpp: column-sorted passes)
   double *part0 = nullptr, *part1 = nullptr;  // cs.split == 2: scratch for the partial row sums of epilogues without split()
+  // rows peeled off the column-sorted layout (too long for its count fields): one row block each over the plain CSR,
+  // done by a CSR-stream launch right behind the main one (bit r of cs.peel marks them)
+  const int4 *peel_blk = nullptr;
+  int npeel = 0;
   bool cs_combine() const { return use_cs && cs.split > 1 && cs.ticket != nullptr; }
-  int nblk() const { return use_cs ? (cs_combine() ? cs.nchunks : cs.nchunks * cs.split) : use_slab ? slab.nchunks : csr.nblk; }
+  int cs_main_wgs() const { return cs_combine() ? cs.nchunks : cs.nchunks * cs.split; }
+  int nblk() const { return use_cs ? cs_main_wgs() + npeel : use_slab ? slab.nchunks : csr.nblk; }
 };
 
 // split layouts: the epilogue of a product whose functor is not linear in the row sum — rows finished from the two
@@ -603,7 +612,7 @@ struct SpmvMat {
 constexpr int kEpiFinishThreads = 1024;  // few workgroups (their count is the stride of the partials): many lanes each
 template <class Epi>
 __global__ __launch_bounds__(kEpiFinishThreads) void k_epi_finish(const double *__restrict__ y0, const double *__restrict__ y1, int rows, Epi epi,
-                                                              const int *done_flag) {
+                                                              const int *done_flag, const unsigned *__restrict__ peel, int pstride) {
   if (done_flag && *done_flag) return;
   __shared__ double red[kEpiFinishThreads / 64];
   constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
@@ -613,17 +622,18 @@ __global__ __launch_bounds__(kEpiFinishThreads) void k_epi_finish(const double *
 #pragma unroll
   for (int i = 0; i < NM; ++i) maxs[i] = 0.;
   for (long r = (long)blockIdx.x * kEpiFinishThreads + threadIdx.x; r < rows; r += (long)gridDim.x * kEpiFinishThreads)
-    epi((int)r, y0[r] + y1[r], sums, maxs);
+    if (!cs_is_peeled(peel, (int)r)) epi((int)r, y0[r] + y1[r], sums, maxs);  // (peeled rows: the side launch runs their epilogue)
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+    const int nslot = pstride > 0 ? pstride : (int)gridDim.x;
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kEpiFinishThreads>(sums[i], red);
-      if (threadIdx.x == 0) epi.partial[(size_t)i * gridDim.x + blockIdx.x] = t;
+      if (threadIdx.x == 0) epi.partial[(size_t)i * nslot + blockIdx.x] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kEpiFinishThreads>(maxs[i], red);
-      if (threadIdx.x == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + blockIdx.x] = t;
+      if (threadIdx.x == 0) epi.partial[(size_t)(Epi::kSums + i) * nslot + blockIdx.x] = t;
     }
   }
 }
@@ -632,19 +642,30 @@ template <class Epi>
 inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                         int *step_counter = nullptr) {
   if (M.use_cs) {
-    if (M.cs_combine()) {  // partial sums are added inside the kernel: finished rows for any epilogue
-      launch_spmv_cs(M.cs, x, epi, done_flag, s, step_counter);
-      return;
-    }
-    if constexpr (!epi_has_split<Epi>::value) {
-      if (M.cs.split > 1) {
-        if (M.cs.nchunks <= 0) return;
-        launch_spmv_cs(M.cs, x, EpiPartial{M.part0, M.part1}, done_flag, s, step_counter);
-        hipLaunchKernelGGL(k_epi_finish<Epi>, dim3(M.nblk()), dim3(kEpiFinishThreads), 0, s, M.part0, M.part1, M.cs.rows, epi, done_flag);
-        return;
+    if (M.cs.nchunks <= 0) return;
+    CsView V = M.cs;
+    const int nmain = M.cs_main_wgs();
+    if (M.npeel > 0) V.pstride = nmain + M.npeel;  // the side launch's partials follow the main launch's
+    bool finished = false;
+    if (!M.cs_combine()) {  // (combine mode: partial sums are added inside the kernel, finished rows for any epilogue)
+      if constexpr (!epi_has_split<Epi>::value) {
+        if (M.cs.split > 1) {
+          launch_spmv_cs(V, x, EpiPartial{M.part0, M.part1}, done_flag, s, step_counter);
+          hipLaunchKernelGGL(k_epi_finish<Epi>, dim3(nmain), dim3(kEpiFinishThreads), 0, s, M.part0, M.part1, M.cs.rows, epi, done_flag,
+                             M.cs.peel, V.pstride);
+          finished = true;
+        }
       }
     }
-    launch_spmv_cs(M.cs, x, epi, done_flag, s, step_counter);
+    if (!finished) launch_spmv_cs(V, x, epi, done_flag, s, step_counter);
+    if (M.npeel > 0) {  // the peeled rows, whole, through the plain epilogue (EpiGp: Gp2 stays 0 for them)
+      CsrView S = M.csr;
+      S.blk = M.peel_blk;
+      S.nblk = M.npeel;
+      S.pstride = nmain + M.npeel;
+      S.pbase = nmain;
+      hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(M.npeel), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag, (int *)nullptr);
+    }
     return;
   }
   if (M.use_slab) {

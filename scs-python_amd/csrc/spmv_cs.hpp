@@ -50,11 +50,21 @@ struct CsView {
   // parts in fixed order and runs the epilogue on the finished rows.  No spinning: nothing ever waits for a workgroup.
   double *scratch = nullptr;   // nchunks * split * 1024 * rpt doubles
   unsigned *ticket = nullptr;  // nchunks counters, monotone: split arrivals per launch
+  // Peeled rows: rows with more nonzeros than a run-descriptor count holds are left out of the passes (bit r of `peel`)
+  // and done by a CSR-stream side launch on the plain CSR (spmv.hpp launch_spmv); their epilogue is skipped here.
+  const unsigned *peel = nullptr;
+  int pstride = 0, pbase = 0;  // reduction partials: slot stride / first slot (0: this launch's own workgroup count / 0)
 };
+__host__ __device__ inline bool cs_is_peeled(const unsigned *peel, int r) { return peel && ((peel[r >> 5] >> (r & 31)) & 1u); }
 
 // bits per row count in a run descriptor; 16 rows per lane use two words (8 counts each)
 __host__ __device__ inline int cs_count_bits(int rpt) { return rpt == 16 ? 6 : (48 / rpt < 13 ? 48 / rpt : 13); }
 __host__ __device__ inline int cs_meta_words(int rpt) { return rpt == 16 ? 2 : 1; }
+// longest row the passes take: what a count field holds, and not more than one CSR-stream LDS stage
+__host__ __device__ inline int cs_peel_threshold(int rpt) {
+  const int mx = (1 << cs_count_bits(rpt)) - 1;
+  return mx < 2048 ? mx : 2048;
+}
 
 // Chunk geometry: R rows per workgroup so that the launch is ONE wave of workgroups on the 256 CUs (every CU busy,
 // as many rows per CU as possible: the distinct lines per gather instruction fall with R), R a multiple of 64;
@@ -113,7 +123,7 @@ __host__ __device__ inline int cs_store_pos(int q) {
 // format's bit fields (a pass wider than 2^19 columns, or more nonzeros of one row in one pass than the count
 // field holds): the caller keeps the slab / CSR-stream layout.
 inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0,
-                     int split = 1) {
+                     int split = 1, const unsigned *peel = nullptr) {
   int R, rpt;
   cs_pick_geometry(rows, R, rpt, split);
   if (force_rpt > 0) { rpt = force_rpt; R = kCsThreads * rpt; }
@@ -131,8 +141,10 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
     struct Ent { int col, rl, p; };
     std::vector<Ent> ents;
     ents.reserve((size_t)(rowptr[r1] - rowptr[r0]));
-    for (int r = r0; r < r1; ++r)
+    for (int r = r0; r < r1; ++r) {
+      if (cs_is_peeled(peel, r)) continue;  // done by the side launch
       for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ents.push_back(Ent{col[p], r - r0, p});
+    }
     std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.col != b.col ? a.col < b.col : a.rl < b.rl; });
     const long n_all = (long)ents.size();
     // split > 1: the chunk's stream is cut into `split` parts at (multiples of 256 near) k * n / split, one workgroup each
@@ -302,18 +314,19 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+    const int nslot = A.pstride > 0 ? A.pstride : (int)gridDim.x, slot = A.pbase + wg;
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)i * nslot + slot] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kCsThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * nslot + slot] = t;
     }
   }
 }
@@ -417,18 +430,19 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+    const int nslot = A.pstride > 0 ? A.pstride : (int)gridDim.x, slot = A.pbase + wg;
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);
-      if (tid == 0) epi.partial[(size_t)i * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)i * nslot + slot] = t;
     }
 #pragma unroll
     for (int i = 0; i < Epi::kMaxs; ++i) {
       const double t = block_max<kCsThreads>(maxs[i], red);
-      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * gridDim.x + wg] = t;
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + i) * nslot + slot] = t;
     }
   }
 }
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows) {
+    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) {
       if (combine) epi(r, acc[j], sums, maxs);  // finished rows: the plain epilogue
       else cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
     }
@@ -654,7 +668,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
   CS_TL_FLUSH();
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
     // reduction partials: one slot per workgroup, or — combine mode — one per chunk (written by its last arriver)
-    const int slot = combine ? c : wg, nslot = combine ? A.nchunks : (int)gridDim.x;
+    const int slot = A.pbase + (combine ? c : wg), nslot = A.pstride > 0 ? A.pstride : (combine ? A.nchunks : (int)gridDim.x);
 #pragma unroll
     for (int i = 0; i < Epi::kSums; ++i) {
       const double t = block_sum<kCsThreads>(sums[i], red);

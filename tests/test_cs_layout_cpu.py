@@ -69,16 +69,66 @@ def test_layout_empty_rows_and_columns(hip, oracle):
     np.testing.assert_array_equal(hip.cs_layout_host_spmv(Z, np.ones(200)), np.zeros(300))
 
 
-def test_layout_rejects_what_its_bit_fields_cannot_hold(hip):
-    rng = np.random.default_rng(5)
-    # 8 and 16 rows per lane: 6-bit counts per (row, pass) — a dense 70 x 70 block puts 70 nonzeros of a row into one pass
-    A = pg.random_sparse(40000, 30000, 4, rng)
-    ii, jj = np.meshgrid(np.arange(70), np.arange(70), indexing="ij")
-    B = (A + sparse.csc_matrix((rng.standard_normal(4900), (ii.ravel(), jj.ravel())), shape=A.shape)).tocsc()
+def _with_dense_block(rng, shape, per_col, k):
+    A = pg.random_sparse(*shape, per_col, rng)
+    ii, jj = np.meshgrid(np.arange(k), np.arange(k), indexing="ij")
+    B = (A + sparse.csc_matrix((rng.standard_normal(k * k), (ii.ravel(), jj.ravel())), shape=A.shape)).tocsc()
     B.sort_indices()
-    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=16) is None
-    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=8) is None
-    assert hip.cs_layout_host_spmv(B, np.ones(30000), rpt=4) is not None      # 12-bit counts hold it
+    return B
+
+
+def test_rows_too_long_for_the_count_fields_are_peeled(hip, oracle, monkeypatch):
+    """8 and 16 rows per lane: 6-bit counts per (row, pass).  A dense 70 x 70 block puts 70 nonzeros of a row into one
+    pass: those rows are peeled off the layout and summed from the plain CSR (sequential order: still the oracle's
+    bits), the rest of the matrix keeps the column-sorted passes.  SCS_HIP_CS_PEEL=0 restores round 1's behaviour —
+    the whole matrix is refused."""
+    rng = np.random.default_rng(5)
+    B = _with_dense_block(rng, (40000, 30000), 4, 70)
+    x, y = rng.standard_normal(30000), rng.standard_normal(40000)
+    for rpt in (16, 8, 4, 0):
+        for split in (1, 2):
+            got = hip.cs_layout_host_spmv(B, x, rpt=rpt, split=split)
+            assert got is not None
+            if split == 1:
+                np.testing.assert_array_equal(got, oracle.spmv(B, x))
+            else:
+                np.testing.assert_allclose(got, oracle.spmv(B, x), rtol=0, atol=1e-13 * np.abs(got).max())
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(B, y, transpose=True, rpt=16), oracle.spmv(B, y, trans=True))
+    monkeypatch.setenv("SCS_HIP_CS_PEEL", "0")
+    assert hip.cs_layout_host_spmv(B, x, rpt=16) is None
+    assert hip.cs_layout_host_spmv(B, x, rpt=8) is None
+    assert hip.cs_layout_host_spmv(B, x, rpt=4) is not None      # 12-bit counts hold it
+
+
+def test_power_law_and_banded_patterns(hip, oracle):
+    """skewed row lengths (a few rows with thousands of nonzeros, Zipf-like) and a banded matrix: the layout is kept
+    (long rows peeled), bit for bit the oracle's sums for rows up to 2048 nonzeros"""
+    rng = np.random.default_rng(8)
+    m, n = 60000, 50000
+    lens = np.minimum((rng.pareto(1.2, m) * 3 + 1).astype(np.int64), 6000)
+    rows = np.repeat(np.arange(m), lens)
+    cols = rng.integers(0, n, size=rows.size)
+    A = sparse.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    assert np.diff(A.tocsr().indptr).max() > 2048
+    x = rng.standard_normal(n)
+    got, ref = hip.cs_layout_host_spmv(A, x), oracle.spmv(A, x)
+    assert got is not None
+    short = np.diff(A.tocsr().indptr) <= 2048
+    np.testing.assert_array_equal(got[short], ref[short])
+    np.testing.assert_allclose(got[~short], ref[~short], rtol=1e-12, atol=1e-12)
+    # banded: 21 diagonals
+    offs = np.arange(-10, 11)
+    Bd = sparse.diags([rng.standard_normal(40000 - abs(o)) for o in offs], offs, shape=(40000, 40000), format="csc")
+    Bd.sort_indices()
+    xb = rng.standard_normal(40000)
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(Bd, xb), oracle.spmv(Bd, xb))
+    np.testing.assert_array_equal(hip.cs_layout_host_spmv(Bd, xb, transpose=True), oracle.spmv(Bd, xb, trans=True))
+
+
+def test_layout_rejects_very_wide_sparse_chunks(hip):
+    rng = np.random.default_rng(5)
     # very wide and very sparse: every pass is cut at 2^19 columns => mostly padding => rejected
     W = pg.random_sparse(20000, 3000000, 1, rng)
     assert hip.cs_layout_host_spmv(W, np.ones(W.shape[1]), rpt=0) is None

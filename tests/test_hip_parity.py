@@ -576,8 +576,8 @@ def test_device_setup_matches_host_setup(hip, oracle, monkeypatch, cs):
                                                      ((400000, 300000), 5, "16", True)])
 def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt, dense, split):
     """spmv_cs.hpp: every chunk size (rows per lane 1 .. 16), both orientations, device and host builders, against the
-    oracle's sequential loops — bit for bit.  A pattern that does not fit the format's count fields (16 rows per
-    lane: 3-bit counts; here a dense block) must fall back to the slab kernel with the same bits.
+    oracle's sequential loops — bit for bit.  A pattern that does not fit the format's count fields (8 / 16 rows per
+    lane: 6-bit counts; here a dense block) has the offending rows peeled off and keeps the same bits.
     split: A' products use two workgroups per row chunk (each sums its half of the chunk's column-sorted stream, the
     two partial sums are added) — still deterministic and identical between the builders, but (a + b) + (c + d) is not
     the oracle's sequential order: 1e-13 relative instead of bits."""
@@ -640,6 +640,78 @@ def test_spmv_in_kernel_combine(hip, oracle, monkeypatch, split_a, split_at):
     assert abs(a["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
     for key in ("x", "y", "s"):
         np.testing.assert_allclose(a[key], b[key], rtol=0, atol=2e-4 * np.abs(b[key]).max(), err_msg=key)
+
+
+@pytest.mark.parametrize("pattern", ["powerlaw", "banded", "dense_rows"])
+@pytest.mark.parametrize("split", ["0", "1"], ids=["one-wg-per-chunk", "split"])
+def test_spmv_skewed_patterns_keep_the_layout(hip, oracle, monkeypatch, pattern, split):
+    """Heavy-tailed row lengths, a banded matrix, a few fully dense rows and columns: the column-sorted layout is kept
+    — rows longer than a count field holds are peeled off it and done by a CSR-stream side launch over the plain CSR —
+    with the oracle's bits for every row of up to 2048 nonzeros (longer ones: fixed-order tree, 1e-12), identical
+    between the device and host builders, in both orientations."""
+    monkeypatch.setenv("SCS_HIP_CS_SPLIT", split)
+    rng = np.random.default_rng(77)
+    m, n = 400000, 300000
+    if pattern == "powerlaw":
+        A = pg.powerlaw_sparse(m, n, 8, rng)
+    elif pattern == "banded":
+        A = pg.banded_sparse(m, n, 9, rng)
+    else:
+        A = pg.random_sparse(m, n, 6, rng).tolil()
+        A[7, :] = rng.standard_normal(n)            # a budget row: every variable
+        A[123456, :40000] = rng.standard_normal(40000)
+        A[:, 11] = rng.standard_normal(m).reshape(-1, 1)   # and a variable in every constraint
+        A = A.tocsc()
+        A.sort_indices()
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    ref = (oracle.spmv(A, x), oracle.spmv(A, y, trans=True))
+    lens = (np.diff(A.tocsr().indptr), np.diff(A.indptr))
+    got = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SCS_HIP_SETUP", mode)
+        got[mode] = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
+        for k in (0, 1):
+            short = lens[k] <= 2048
+            if split == "0" or k == 0:
+                np.testing.assert_array_equal(got[mode][k][short], ref[k][short], err_msg="%s %d" % (mode, k))
+            else:
+                np.testing.assert_allclose(got[mode][k][short], ref[k][short], rtol=0, atol=1e-13 * np.abs(ref[k]).max())
+            np.testing.assert_allclose(got[mode][k][~short], ref[k][~short], rtol=1e-12, atol=1e-12 * np.abs(ref[k]).max())
+    for k in (0, 1):
+        np.testing.assert_array_equal(got["device"][k], got["host"][k])
+
+
+def test_solve_with_dense_rows_stays_on_the_column_sorted_layout(hip, oracle, monkeypatch):
+    """an LP with a budget row (all variables) and a dense column: round 1 threw the whole matrix back to the slab /
+    CSR-stream layouts; now it keeps the column-sorted passes (info says so) and solves to the same answer as the
+    CSR-stream path, with the fused CG epilogues running on the peeled rows too"""
+    K = {"l": 120000, "q": [10] * 2000}
+    data, p_star, _ = pg.gen_feasible(K, 70000, 16, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    rng = np.random.default_rng(3)
+    A = data["A"].tolil()
+    A[5, :] = 0.05 * rng.standard_normal(A.shape[1])
+    A[:, 9] = 0.05 * rng.standard_normal(A.shape[0]).reshape(-1, 1)
+    A = A.tocsc()
+    A.sort_indices()
+    x0 = rng.standard_normal(A.shape[1])
+    z = rng.standard_normal(A.shape[0])
+    y0 = oracle.proj_cone(z, K, dual=True)
+    s0 = y0 - z
+    dat = {"A": A, "b": A @ x0 + s0, "c": -(A.T @ y0)}
+    stg = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False)
+    got = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
+    assert "column-sorted" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]
+    monkeypatch.setenv("SCS_HIP_SLAB", "0")
+    ref = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
+    assert "CSR-stream" in ref["info"]["lin_sys_solver"]
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    p_opt = float(dat["c"] @ x0)
+    assert abs(got["info"]["pobj"] - p_opt) <= 1e-5 * max(1.0, abs(p_opt))
+    pri, dual, gap = helpers.kkt_certificate(dat, got)
+    assert pri < 1e-5 and dual < 1e-5 and gap < 1e-4 * max(1.0, abs(p_opt))
+    for key in ("x", "s"):  # (the dense column's variable is only weakly determined: allow a handful of loose entries)
+        bad = np.abs(got[key] - ref[key]) > 2e-4 * np.abs(ref[key]).max()
+        assert bad.sum() <= 3, (key, int(bad.sum()))
 
 
 def test_device_setup_long_rows_fall_back(hip, oracle):

@@ -102,6 +102,11 @@ double scs_hip_copy_bandwidth(size_t bytes, int reps);
  * where K1 = z <- R_y^{-1} A p  and  K2 = Gp <- A' z + R_x p (+ P p). */
 void scs_hip_set_profiling(ScsWork *w, int on);
 void scs_hip_kernel_times(const ScsWork *w, double *out);
+/* The final (x, y, s) of the last scs_solve, copied from the workspace's HBM buffers to caller-provided DEVICE pointers
+ * (any may be NULL; n, m, m doubles) on the workspace's stream, complete on return.  Same values, bit for bit, as the
+ * host copies scs_solve returned (NaN where the status leaves a vector undefined).  scs/batch.py gathers from these. */
+int scs_hip_solution_to_device(ScsWork *w, scs_float *x_dev, scs_float *y_dev, scs_float *s_dev);
+
 /* bench.py: a timestamp inside the next scs_solve calls.  When ADMM iteration `iter` is about to start, the stream is
  * drained and out[4] = {ms since the start of the solve, CG steps so far, Anderson calls so far, accepted so far} is
  * recorded (out[0] < 0: the solve ended before that iteration); iter < 0 switches it off. */

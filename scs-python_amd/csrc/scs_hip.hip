@@ -476,6 +476,7 @@ struct ScsHipWork {
   bool v_norm_fresh = false;
   DevBuf<int> fl;
   DevBuf<double> solx, soly, sols;
+  bool sol_on_device = false;  // solx/soly/sols hold the final (x, y, s) of the last solve
   int part_len = 0;
 
   // cones
@@ -1758,6 +1759,20 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       break;
     }
   }
+  {
+    // the device copies get the same final scaling (same products, same bits): scs_hip_solution_to_device hands them to
+    // a caller that wants the answer in HBM (scs/batch.py: the RCCL gather starts from where the solutions live)
+    double fx = 1., fy = 1., fs = 1.;
+    switch (info->status_val) {
+      case SCS_SOLVED:
+      case SCS_SOLVED_INACCURATE: fx = fy = fs = safediv_pos(1.0, r.tau); break;
+      case SCS_INFEASIBLE:
+      case SCS_INFEASIBLE_INACCURATE: fy = -1. / r.bty_tau; fx = fs = NAN; break;
+      default: fx = fs = -1. / r.ctx_tau; fy = NAN; break;
+    }
+    hipLaunchKernelGGL(k_scale3, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->solx.p, w->soly.p, w->sols.p, n, m, fx, fy, fs);
+    w->sol_on_device = true;
+  }
   info->lin_sys_time = t_lin;
   info->cone_time = t_cone;
   info->accel_time = t_acc;
@@ -1942,6 +1957,23 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     HIP_CHECK(hipEventElapsedTime(&b, w->ev[1], w->ev[2]));
     out[0] = a / reps;
     out[1] = b / reps;
+    return 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
+int scs_hip_solution_to_device(ScsWork *w, scs_float *x_dev, scs_float *y_dev, scs_float *s_dev) {
+  if (!w) return -1;
+  try {
+    std::lock_guard<std::mutex> lock(w->mtx);
+    if (!w->sol_on_device) throw std::runtime_error("no solution yet: call scs_solve first");
+    HIP_CHECK(hipSetDevice(w->device));
+    if (x_dev) HIP_CHECK(hipMemcpyAsync(x_dev, w->solx.p, sizeof(double) * w->n, hipMemcpyDeviceToDevice, w->stream));
+    if (y_dev) HIP_CHECK(hipMemcpyAsync(y_dev, w->soly.p, sizeof(double) * w->m, hipMemcpyDeviceToDevice, w->stream));
+    if (s_dev) HIP_CHECK(hipMemcpyAsync(s_dev, w->sols.p, sizeof(double) * w->m, hipMemcpyDeviceToDevice, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
     return 0;
   } catch (const std::exception &e) {
     set_last_error(e.what());

@@ -500,6 +500,18 @@ __global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__res
   }
 }
 
+// in-place final scaling of the device copies of the solution (a NaN factor marks a vector the status leaves undefined)
+__global__ __launch_bounds__(kVecThreads) void k_scale3(double *x, double *y, double *s, int n, int m, double fx, double fy, double fs) {
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads) {
+    if (i < n) x[i] = (fx != fx) ? fx : x[i] * fx;
+    else {
+      const long k = i - n;
+      y[k] = (fy != fy) ? fy : y[k] * fy;
+      s[k] = (fs != fs) ? fs : s[k] * fs;
+    }
+  }
+}
+
 // per-iteration CSV diagnostics: [||u-u_t||_2^2, ||v-v_prev||_2^2, ||u-u_t||_inf, ||v-v_prev||_inf]
 __global__ __launch_bounds__(kVecThreads) void k_diff_norms(const double *__restrict__ u, const double *__restrict__ ut,
                                                             const double *__restrict__ v, const double *__restrict__ vp,

@@ -159,6 +159,8 @@ def _load():
     lib.scs_hip_set_profiling.argtypes = [C.c_void_p, c_int]
     lib.scs_hip_kernel_times.restype = None
     lib.scs_hip_kernel_times.argtypes = [C.c_void_p, _PD]
+    lib.scs_hip_solution_to_device.restype = c_int
+    lib.scs_hip_solution_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.scs_hip_set_mark.restype = None
     lib.scs_hip_set_mark.argtypes = [C.c_void_p, c_int]
     lib.scs_hip_get_mark.restype = None
@@ -564,6 +566,16 @@ class SCS(object):
             _lib.scs_hip_kernel_times(self._work, _pd(out))
         return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
                 "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7])}
+
+    def solution_to_device(self, x_ptr=None, y_ptr=None, s_ptr=None):
+        """copy the last solve's (x, y, s) from the workspace's HBM buffers to DEVICE addresses (ints, e.g.
+        torch.Tensor.data_ptr() of float64 tensors on the same GPU); None skips a vector"""
+        with self._lock:
+            if not self._work:
+                raise ValueError("Workspace not initialized!")
+            rc = _lib.scs_hip_solution_to_device(self._work, x_ptr or None, y_ptr or None, s_ptr or None)
+        if rc != 0:
+            raise RuntimeError("libscs_hip: " + last_error())
 
     def _set_mark(self, it):
         _lib.scs_hip_set_mark(self._work, int(it))

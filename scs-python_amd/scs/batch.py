@@ -6,6 +6,9 @@ not shard internally without a per-CG-step all-reduce, but a BATCH of independen
 shards perfectly: problem i -> rank i mod world, no data-path collective, and ONE gather of the
 padded [header | x | y | s] blocks to rank 0 at the end (RCCL over xGMI when the process group
 is "nccl"; every rank sends one message straight to rank 0 — point-to-point links, no ring).
+With RCCL the payload lives in HBM from the start: every solve copies its (x, y, s) device to
+device from the solver's buffers into its row of the payload tensor (scs_hip_solution_to_device)
+and only the 8 header scalars go up from the host — the gather reads the solutions where they are.
 
     results = solve_sharded(problems)            # under torchrun, one rank per GPU
     # rank 0: list of dicts (x, y, s, info-subset) in the original order; other ranks: None
@@ -48,6 +51,23 @@ def unpack_result(row):
                      "dobj": float(row[5]), "solve_time": float(row[6]), "cg_iters": int(row[7])}}
 
 
+def _solve_into_row(data, cone, settings, row):
+    """default backend, device-resident result: solve, then x | y | s straight from the solver's HBM buffers into
+    `row` (a float64 CUDA tensor slice), header from the host.  Returns the info dict."""
+    import scs
+    import torch
+    solver = scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
+    sol = solver.solve()
+    info = sol["info"]
+    n, m = sol["x"].size, sol["y"].size
+    base = row.data_ptr() + 8 * _HDR
+    solver._solver.solution_to_device(base, base + 8 * n, base + 8 * (n + m))
+    hdr = torch.tensor([n, m, info["status_val"], info["iter"], info["pobj"], info["dobj"], info["solve_time"],
+                        info.get("cg_iters", 0)], dtype=torch.float64)
+    row[:_HDR].copy_(hdr)
+    return info
+
+
 def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
     """problems: list of (data, cone, settings) — every rank passes the same list (or at least the
     same length and `dims` = [(n, m), ...]); only its own shard is touched.  Returns the ordered
@@ -60,6 +80,7 @@ def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
     import torch
     import torch.distributed as dist
 
+    device_rows = solve_fn is None  # the product backend can hand its result over in HBM
     solve_fn = solve_fn or _default_solve
     use_dist = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if use_dist else 0
@@ -70,6 +91,32 @@ def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
     width = _HDR + max(n + 2 * m for n, m in dims)
     per_rank = (N + world - 1) // world
     mine = shard_indices(N, rank, world)
+    if use_dist and device_rows and dist.get_backend() == "nccl":
+        # RCCL: the payload is a device tensor from the start; the solves fill their rows device to device
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        payload = torch.zeros((per_rank, width), dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)
+        if threads > 1 and len(mine) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                futs = [pool.submit(_solve_into_row, *problems[i], payload[slot]) for slot, i in enumerate(mine)]
+                for f in futs:
+                    f.result()
+        else:
+            for slot, i in enumerate(mine):
+                _solve_into_row(*problems[i], payload[slot])
+        torch.cuda.synchronize(device)
+        bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, bufs, dst=0)  # the single collective of the whole batch, HBM to HBM
+        if rank != 0:
+            return None
+        out = [None] * N
+        for r in range(world):
+            arr = bufs[r].cpu().numpy()
+            for slot, i in enumerate(shard_indices(N, r, world)):
+                out[i] = unpack_result(arr[slot])
+        return out
     block = np.zeros((per_rank, width), dtype=np.float64)
     if threads > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor

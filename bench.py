@@ -136,22 +136,32 @@ def main():
     common = dict(eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False,
                   acceleration_lookback=10, linear_solver=scs.LinearSolver.HIP_INDIRECT)
     # ---------------- warm-up ----------------
+    # (the warm-up workspace is released only AFTER the timed region: freeing 1.5 GB of HBM leaves the runtime with
+    # deferred work that the first device-wide synchronize afterwards pays for — 25 ms measured — and that synchronize
+    # is the one closing the timed region)
+    wsolver = None
     if args.warmup > 0:
         wsolver = scs.SCS(data, K, max_iters=args.warmup, **common)
         wsolver.solve()
-        del wsolver
     solver = scs.SCS(data, K, max_iters=args.steps, **common)
-    solver._solver._set_profiling(True)
+    if not os.environ.get("BENCH_NO_INSITU"):
+        solver._solver._set_profiling(True)
 
     # ---------------- timed region: exactly K ADMM iterations ----------------
     barrier()
     t0 = time.perf_counter()
     sol = solver.solve(warm_start=False)
+    t_a = time.perf_counter()
     torch.cuda.synchronize()
+    t_b = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_DEBUG_TIMING"):
+        print("timed region: solve() %.1f ms, synchronize %.1f ms, barrier %.1f ms" % ((t_a - t0) * 1e3, (t_b - t_a) * 1e3,
+              (time.perf_counter() - t_b) * 1e3), file=sys.stderr)
     info = sol["info"]
     assert info["iter"] == args.steps, (info["iter"], args.steps, info["status"])
+    del wsolver
     kt = solver._solver._kernel_times()          # in-situ samples (one CG step per host sync)
     kb = solver._solver._time_matvec(reps=30)    # back-to-back batch, event overhead amortised
     elapsed_max, total_iters = reduce_max_sum(elapsed, info["iter"])
@@ -331,7 +341,7 @@ def main():
             "world_size_seen": world, "backend": args.dist_backend if world > 1 else None,
             "cg_steps_per_admm_iter": round(info["cg_iters"] / max(info["iter"], 1), 2),
             "cg_steps_per_s": round(cg_per_s, 1), "ms_per_cg_step": round(1e3 / cg_per_s * world, 4),
-            "admm_iters_timed": int(info["iter"]),
+            "admm_iters_timed": int(info["iter"]), "solve_ms_inside_scs_solve": round(info["solve_time"], 2),
             "aa_extrapolations_in_timed_region": int(info["aa_stats"]["n_accept"]),
             "lin_sys_ms": round(info["lin_sys_time"], 1), "cone_ms": round(info["cone_time"], 1),
             "accel_ms": round(info["accel_time"], 1), "setup_ms": round(info["setup_time"], 1),

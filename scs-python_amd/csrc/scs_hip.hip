@@ -1771,6 +1771,9 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       default: fx = fs = -1. / r.ctx_tau; fy = NAN; break;
     }
     hipLaunchKernelGGL(k_scale3, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->solx.p, w->soly.p, w->sols.p, n, m, fx, fy, fs);
+    // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
+    // un-synchronised 13 us kernel was measured to take 25 ms on this runtime)
+    HIP_CHECK(hipStreamSynchronize(s));
     w->sol_on_device = true;
   }
   info->lin_sys_time = t_lin;

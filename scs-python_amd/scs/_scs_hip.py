@@ -596,7 +596,7 @@ class SCS(object):
     def __del__(self):
         lock = getattr(self, "_lock", None)
         work = getattr(self, "_work", None)
-        if work and lock is not None:
+        if work and lock is not None and _lib is not None:  # (_lib is None while the interpreter shuts down)
             with lock:
                 _lib.scs_finish(self._work)
                 self._work = None

@@ -1100,8 +1100,9 @@ struct ScsHipWork {
   // is saved and restored; PSD eigenvector warm starts are not used (and are left as the projection leaves them).
   double cone_dist(const double *hv, int dual) {
     if (!std::isfinite(hv[0])) return NAN;
-    HIP_CHECK(hipMemcpyAsync(sols.p, hv, sizeof(double) * m, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(tmp_m.p, sols.p, sizeof(double) * m, hipMemcpyDeviceToDevice, stream));
+    // scratch: rsk (recomputed by every iteration that needs it) holds the vector, tmp_m its projection
+    HIP_CHECK(hipMemcpyAsync(rsk.p, hv, sizeof(double) * m, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(tmp_m.p, rsk.p, sizeof(double) * m, hipMemcpyDeviceToDevice, stream));
     double box_t = 1.0;
     HIP_CHECK(hipMemcpyAsync(&box_t, sc.p + S_BOX_T, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1116,7 +1117,7 @@ struct ScsHipWork {
     std::swap(box_bl.p, box_bl_orig.p);
     std::swap(box_bu.p, box_bu_orig.p);
     const int nb = vb(m);
-    hipLaunchKernelGGL(k_aa_diffsq, dim3(nb), dim3(kVecThreads), 0, stream, (const double *)sols.p, (const double *)tmp_m.p, (long)m, part.p);
+    hipLaunchKernelGGL(k_aa_diffsq, dim3(nb), dim3(kVecThreads), 0, stream, (const double *)rsk.p, (const double *)tmp_m.p, (long)m, part.p);
     std::vector<double> hp(nb);
     HIP_CHECK(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(sc.p + S_BOX_T, &box_t, sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1550,9 +1551,10 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
 
   // ---- initial iterate ----
   {
-    std::vector<double> v0(l, 0.0);
+    const double one = 1.0;
     if (warm_start) {
       // v = [x_hat; y_hat + s_hat / r_y; 1] with the normalised warm start (boundary work, O(l) on the host)
+      std::vector<double> v0(l, 0.0);
       const double sg = w->normalized ? w->scal.sigma : 1.0;
       for (int i = 0; i < n; ++i) v0[i] = w->normalized ? sol->x[i] / (w->scal.E[i] / sg) : sol->x[i];
       for (int i = 0; i < m; ++i) {
@@ -1563,12 +1565,15 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       }
       for (long i = 0; i < l; ++i)
         if (!std::isfinite(v0[i])) v0[i] = 0.;
+      v0[l - 1] = 1.0;
+      HIP_CHECK(hipMemcpyAsync(w->v.p, v0.data(), sizeof(double) * l, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));  // v0 is a local
+    } else {  // cold start: v = [0; 0; 1], nothing crosses PCIe
+      HIP_CHECK(hipMemsetAsync(w->v.p, 0, sizeof(double) * l, s));
+      HIP_CHECK(hipMemcpyAsync(w->v.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, s));
     }
-    v0[l - 1] = 1.0;
-    HIP_CHECK(hipMemcpyAsync(w->v.p, v0.data(), sizeof(double) * l, hipMemcpyHostToDevice, s));
     w->v_norm_fresh = false;
     HIP_CHECK(hipMemsetAsync(w->u.p, 0, sizeof(double) * l, s));
-    const double one = 1.0;
     HIP_CHECK(hipMemcpyAsync(w->u.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
   }
@@ -1700,10 +1705,11 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   hipLaunchKernelGGL(k_unnormalize, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->u.p, w->rsk.p,
                      w->normalized ? w->D.p : (const double *)nullptr, w->normalized ? w->E.p : (const double *)nullptr, sg, 1.0,
                      1.0, 1.0, n, m, w->solx.p, w->soly.p, w->sols.p);
-  w->solx.download(sol->x, n, s);
-  w->soly.download(sol->y, m, s);
-  w->sols.download(sol->s, m, s);
-  HIP_CHECK(hipStreamSynchronize(s));
+  // complementary slackness s'y of the un-rescaled pair (fixed-order two-stage sum), then status and its scaling
+  const int nbm = w->vb(m);
+  hipLaunchKernelGGL(k_dot_part, dim3(nbm), dim3(kVecThreads), 0, s, (const double *)w->sols.p, (const double *)w->soly.p, (long)m, w->part.p);
+  std::vector<double> cs_part((size_t)nbm);
+  HIP_CHECK(hipMemcpyAsync(cs_part.data(), w->part.p, sizeof(double) * nbm, hipMemcpyDeviceToHost, s));
   info->iter = i;
   info->res_infeas = r.res_infeas;
   info->res_unbdd_a = r.res_unbdd_a;
@@ -1712,69 +1718,55 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   info->scale_updates = w->scale_updates;
   info->rejected_accel_steps = w->rejected_accel;
   info->accepted_accel_steps = w->accepted_accel;
-  {
-    double cs = 0.;
-    for (int j = 0; j < m; ++j) cs += sol->s[j] * sol->y[j];
-    info->comp_slack = std::fabs(cs);
-  }
   if (info->status_val == SCS_UNFINISHED) {
     if (r.tau > r.kap) info->status_val = SCS_SOLVED_INACCURATE;
     else if (r.bty_tau < r.ctx_tau) info->status_val = SCS_INFEASIBLE_INACCURATE;
     else info->status_val = SCS_UNBOUNDED_INACCURATE;
   }
+  // final scaling on the device (a NaN factor marks a vector the status leaves undefined); the host copies are plain
+  // downloads of the finished vectors, and the device copies stay behind for scs_hip_solution_to_device (scs/batch.py:
+  // the RCCL gather starts from where the solutions live)
+  double fx = 1., fy = 1., fs = 1.;
   switch (info->status_val) {
     case SCS_SOLVED:
-    case SCS_SOLVED_INACCURATE: {
-      const double it = safediv_pos(1.0, r.tau);
-      for (int j = 0; j < n; ++j) sol->x[j] *= it;
-      for (int j = 0; j < m; ++j) { sol->y[j] *= it; sol->s[j] *= it; }
+    case SCS_SOLVED_INACCURATE:
+      fx = fy = fs = safediv_pos(1.0, r.tau);
       info->gap = r.gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual;
       info->pobj = r.xt_p_x / 2. + r.ctx;
       info->dobj = -r.xt_p_x / 2. - r.bty;
       std::snprintf(info->status, sizeof(info->status), "%s",
                     info->status_val == SCS_SOLVED ? "solved" : "solved (inaccurate - reached max_iters)");
       break;
-    }
     case SCS_INFEASIBLE:
-    case SCS_INFEASIBLE_INACCURATE: {
-      const double f = -1. / r.bty_tau;
-      for (int j = 0; j < m; ++j) sol->y[j] *= f;
-      fill_nan(sol->x, n);
-      fill_nan(sol->s, m);
+    case SCS_INFEASIBLE_INACCURATE:
+      fy = -1. / r.bty_tau;
+      fx = fs = NAN;
       info->gap = info->res_pri = info->res_dual = NAN;
       info->pobj = INFINITY; info->dobj = INFINITY;
       std::snprintf(info->status, sizeof(info->status), "%s",
                     info->status_val == SCS_INFEASIBLE ? "infeasible" : "infeasible (inaccurate - reached max_iters)");
       break;
-    }
-    default: {
-      const double f = -1. / r.ctx_tau;
-      for (int j = 0; j < n; ++j) sol->x[j] *= f;
-      for (int j = 0; j < m; ++j) sol->s[j] *= f;
-      fill_nan(sol->y, m);
+    default:
+      fx = fs = -1. / r.ctx_tau;
+      fy = NAN;
       info->gap = info->res_pri = info->res_dual = NAN;
       info->pobj = -INFINITY; info->dobj = -INFINITY;
       std::snprintf(info->status, sizeof(info->status), "%s",
                     info->status_val == SCS_UNBOUNDED ? "unbounded" : "unbounded (inaccurate - reached max_iters)");
       break;
-    }
   }
+  hipLaunchKernelGGL(k_scale3, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->solx.p, w->soly.p, w->sols.p, n, m, fx, fy, fs);
+  w->solx.download(sol->x, n, s);
+  w->soly.download(sol->y, m, s);
+  w->sols.download(sol->s, m, s);
+  // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
+  // un-synchronised kernel was measured to take 25 ms on this runtime)
+  HIP_CHECK(hipStreamSynchronize(s));
+  w->sol_on_device = true;
   {
-    // the device copies get the same final scaling (same products, same bits): scs_hip_solution_to_device hands them to
-    // a caller that wants the answer in HBM (scs/batch.py: the RCCL gather starts from where the solutions live)
-    double fx = 1., fy = 1., fs = 1.;
-    switch (info->status_val) {
-      case SCS_SOLVED:
-      case SCS_SOLVED_INACCURATE: fx = fy = fs = safediv_pos(1.0, r.tau); break;
-      case SCS_INFEASIBLE:
-      case SCS_INFEASIBLE_INACCURATE: fy = -1. / r.bty_tau; fx = fs = NAN; break;
-      default: fx = fs = -1. / r.ctx_tau; fy = NAN; break;
-    }
-    hipLaunchKernelGGL(k_scale3, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->solx.p, w->soly.p, w->sols.p, n, m, fx, fy, fs);
-    // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
-    // un-synchronised 13 us kernel was measured to take 25 ms on this runtime)
-    HIP_CHECK(hipStreamSynchronize(s));
-    w->sol_on_device = true;
+    double cs = 0.;
+    for (double v : cs_part) cs += v;
+    info->comp_slack = std::fabs(cs);
   }
   info->lin_sys_time = t_lin;
   info->cone_time = t_cone;

@@ -500,6 +500,15 @@ __global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__res
   }
 }
 
+// partials of a'b (fixed-order two-stage sum: the consumer adds part[0 .. gridDim) in order)
+__global__ __launch_bounds__(kVecThreads) void k_dot_part(const double *__restrict__ a, const double *__restrict__ b, long n, double *part) {
+  __shared__ double sm[kVecThreads / 64];
+  double s = 0.;
+  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += a[i] * b[i];
+  s = block_sum<kVecThreads>(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
 // in-place final scaling of the device copies of the solution (a NaN factor marks a vector the status leaves undefined)
 __global__ __launch_bounds__(kVecThreads) void k_scale3(double *x, double *y, double *s, int n, int m, double fx, double fy, double fs) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads) {

@@ -257,8 +257,8 @@ def main():
     k1_situ = kt["k1_ms"] / max(kt["k1_n"], 1)
     k2_situ = kt["k2_ms"] / max(kt["k2_n"], 1)
     k1_avg, k2_avg = kb["k1_ms"], kb["k2_ms"]
-    b1 = spmv_bytes(nnz, m, n) + 8 * m      # + R_y read fused in the epilogue
-    b2 = spmv_bytes(nnz, n, m) + 16 * n     # + R_x, p reads fused in the epilogue
+    b1 = spmv_bytes(nnz, m, n)              # SURVEY 8(d) formula (R_y comes as two scalars: nothing else is read)
+    b2 = spmv_bytes(nnz, n, m) + 8 * n      # + p read by the fused epilogue (R_x is a scalar)
     gb1 = b1 / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
     gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
     lss = info.get("lin_sys_solver", "")

@@ -572,19 +572,28 @@ struct ScsHipWork {
   int vb(long nelem) const { return vec_blocks(nelem); }
 
   void set_diag_r() {
+    diag_r_structured = true;
     hipLaunchKernelGGL(k_set_diag_r, dim3(vb(l)), dim3(kVecThreads), 0, stream, diag_r.p, n, m, cone.z, stgs.rho_x, scale);
     hipLaunchKernelGGL(k_precond, dim3(vb(n)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, At.val.p, diag_r.p,
                        has_P ? Pdiag.p : (const double *)nullptr, cg_M.p, n);
   }
 
+  // R_x / R_y as the SpMV epilogues take them: two scalars inside the ADMM workspace (set_diag_r built diag_r), the
+  // vector for the standalone KKT entry point (arbitrary diag_r)
+  // (not when the iteration is replayed from captured hipGraphs — SCS_HIP_PIPELINE=0: kernel arguments are frozen at
+  // capture and `scale` changes with every adaptive scale update; the vector is updated in place)
+  bool diag_r_structured = false;
+  bool r_scalars() const { return diag_r_structured && pipelined; }
+  RDiag rdx() const { return r_scalars() ? RDiag(stgs.rho_x, stgs.rho_x, 0) : RDiag(diag_r.p); }
+  RDiag rdy() const { return r_scalars() ? RDiag(1.0 / (1000. * scale), 1.0 / scale, cone.z) : RDiag(diag_r.p + n); }
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
   // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
   // second half of Gp when A' has the split layout (EpiGp::split): Gp = cg_Gp + gp2()
   double *gp2() const { return At.cs.ok && At.cs.split > 1 && !At.cs.combine() ? At.cs_part1.p : nullptr; }
   void matvec(const double *x, const int *done, int *step_counter = nullptr) {
-    launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, diag_r.p + n}, done, stream, step_counter);
+    launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, rdy()}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
-    launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, x, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, done, stream);
+    launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, x, rdx(), has_P ? 1 : 0, part.p, gp2()}, done, stream);
   }
 
   void read_flags() {
@@ -661,10 +670,10 @@ struct ScsHipWork {
         for (int it = 0; it < chunk; ++it) {
           if (profile && it == sample_it) {
             HIP_CHECK(hipEventRecord(ev[0], stream));
-            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream, fl.p + F_STEP);
+            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
             HIP_CHECK(hipEventRecord(ev[1], stream));
             if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
+            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
             HIP_CHECK(hipEventRecord(ev[2], stream));
             const int nb = vb(std::max(n, yacc ? m : 0));
             hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
@@ -733,10 +742,10 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
                        d_params, part_v.p, nbl, sc.p, part2.p, stall);
     // y0 = v_y + R_y^{-1} A ws   (start of the y recurrence, lives in ut_y)
-    launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, diag_r.p + n, v.p + n}, stall, stream);
+    launch_spmv(Ar.view(), ws.p, EpiY{ut.p + n, rdy(), v.p + n}, stall, stream);
     // r0 = R_x (v_x - ws) - P ws - A' y0 ; p0 = M r0 ; partials for ||r0||_inf and r0'M r0
     if (has_P) launch_spmv(Pf.view(), ws.p, EpiStore{cg_Gp.p, 0}, stall, stream);
-    launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, diag_r.p, v.p, ws.p, has_P ? cg_Gp.p : nullptr, part.p},
+    launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, rdx(), v.p, ws.p, has_P ? cg_Gp.p : nullptr, part.p},
                 stall, stream);
     // tolerance, ||r0||, r0'M r0, step counter, zero-rhs short circuit: one finalize launch
     hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
@@ -809,10 +818,10 @@ struct ScsHipWork {
       if (profile && k == chunk / 2) {  // one CG step of the queued iteration bracketed by events: nothing waits for them here
         for (auto &e : ev_prof[slot]) if (!e) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventRecord(ev_prof[slot][0], stream));
-        launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, diag_r.p + n}, fl.p + F_DONE, stream, fl.p + F_STEP);
+        launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
         HIP_CHECK(hipEventRecord(ev_prof[slot][1], stream));
         if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-        launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, diag_r.p, has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
+        launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
         HIP_CHECK(hipEventRecord(ev_prof[slot][2], stream));
         const int nb = vb(std::max(n, m));
         hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, ut.p, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, ut.p + n,
@@ -1941,10 +1950,10 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     const int n = w->n;
     for (int i = 0; i < 2; ++i) w->matvec(w->cg_p.p, nullptr);
     HIP_CHECK(hipEventRecord(w->ev[0], s));
-    for (int i = 0; i < reps; ++i) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->diag_r.p + n}, nullptr, s);
+    for (int i = 0; i < reps; ++i) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, nullptr, s);
     HIP_CHECK(hipEventRecord(w->ev[1], s));
     for (int i = 0; i < reps; ++i)
-      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->diag_r.p, 0, w->part.p, w->gp2()}, nullptr, s);
+      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), 0, w->part.p, w->gp2()}, nullptr, s);
     HIP_CHECK(hipEventRecord(w->ev[2], s));
     HIP_CHECK(hipEventSynchronize(w->ev[2]));
     float a = 0, b = 0;

@@ -63,6 +63,19 @@ inline std::vector<int4> build_rowblocks(const int *rowptr, int rows) {
   return out;
 }
 
+// A diagonal block of R = diag(diag_r) as the epilogues see it: the vector itself, or — inside the ADMM workspace, where
+// R_x = rho_x I and R_y takes two values (zero-cone rows, the rest) — two scalars and the boundary: the same quotients
+// and products bit for bit, without streaming 8 bytes per row for them.
+struct RDiag {
+  const double *vec = nullptr;
+  double head = 0., rest = 0.;  // value of rows < nhead / of the others (vec == nullptr)
+  int nhead = 0;
+  RDiag() = default;
+  __host__ __device__ RDiag(const double *v) : vec(v) {}
+  __host__ __device__ RDiag(double head_, double rest_, int nhead_) : head(head_), rest(rest_), nhead(nhead_) {}
+  __device__ __forceinline__ double operator[](int r) const { return vec ? vec[r] : (r < nhead ? head : rest); }
+};
+
 // ---- epilogues -------------------------------------------------------------
 // operator()(row, sum, acc) consumes one finished row; kPartial > 0 means the
 // block reduces acc[] and stores kPartial partial results at partial[k*nblk + b].
@@ -76,14 +89,15 @@ struct EpiStore {  // y[r] = s   or  y[r] += s
 
 struct EpiDivR {  // z[r] = s / ry[r]            (CG step a: z = R_y^{-1} A p)
   double *z;
-  const double *ry;
+  RDiag ry;
   static constexpr int kSums = 0, kMaxs = 0;
   __device__ void operator()(int r, double s, double *, double *) const { z[r] = s / ry[r]; }
 };
 
 struct EpiGp {  // Gp[r] = (Pp)[r] + s + rx[r] p[r];  partial sum of p.Gp   (CG step b)
   double *Gp;
-  const double *p, *rx;
+  const double *p;
+  RDiag rx;
   int has_P;
   double *partial;
   double *Gp2 = nullptr;  // split layouts (spmv_cs.hpp, two workgroups per row chunk): the second half's partial sums
@@ -122,7 +136,9 @@ struct EpiPartial {  // split layouts: raw partial row sums of the two halves (f
 // p0 = M r0; partials [sum r0 M r0 | max |r0|]
 struct EpiR0 {
   double *r, *p;
-  const double *M, *rx, *vx, *ws, *Pws;  // Pws nullable
+  const double *M;
+  RDiag rx;
+  const double *vx, *ws, *Pws;  // Pws nullable
   double *partial;
   static constexpr int kSums = 1, kMaxs = 1;
   __device__ void operator()(int j, double s, double *sums, double *maxs) const {
@@ -145,7 +161,8 @@ struct EpiRhs {  // b_x[r] = rx_part[r] + s          (rhs: r_x + A' R_y^{-1} r_y
 
 struct EpiY {  // y[r] = s / ry[r] + vy[r]        (y = R_y^{-1}(A x - r_y), r_y = -R_y v_y)
   double *y;
-  const double *ry, *vy;
+  RDiag ry;
+  const double *vy;
   static constexpr int kSums = 0, kMaxs = 0;
   __device__ void operator()(int r, double s, double *, double *) const { y[r] = s / ry[r] + vy[r]; }
 };

@@ -70,10 +70,10 @@ struct DeviceCsr {
   // rows too long for the layout's count fields are peeled off it (spmv_cs.hpp CsView::peel) and done over the plain CSR
   DevBuf<unsigned> peel_mask;
   DevBuf<int4> peel_blk;
-  int npeel = 0;
+  int npeel = 0, npeel_long = 0;
   // host: mark rows longer than `thresh`; one row block {row, row + 1, first nonzero, end} each.  false: nothing to peel
   bool make_peel(const int *rp_host, int thresh, hipStream_t s) {
-    peel_mask.release(); peel_blk.release(); npeel = 0;
+    peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
     if (getenv("SCS_HIP_CS_PEEL") && getenv("SCS_HIP_CS_PEEL")[0] == '0') return false;  // A/B: reject such patterns as round 1 did
     std::vector<int4> blk;
     std::vector<unsigned> mask;
@@ -84,6 +84,10 @@ struct DeviceCsr {
         blk.push_back(int4{r, r + 1, rp_host[r], rp_host[r + 1]});
       }
     if (blk.empty()) return false;
+    // the longest rows first (a whole workgroup each in k_spmv_peeled), original order inside the two groups
+    std::stable_partition(blk.begin(), blk.end(), [](const int4 &b) { return b.w - b.z > kPeelLongRow; });
+    npeel_long = 0;
+    for (const int4 &b : blk) npeel_long += (b.w - b.z > kPeelLongRow) ? 1 : 0;
     npeel = (int)blk.size();
     peel_mask.upload(mask.data(), mask.size(), s);
     peel_blk.upload(blk.data(), blk.size(), s);
@@ -139,7 +143,7 @@ struct DeviceCsr {
   // T = this matrix transposed (device CSR with the CURRENT values); host: build from this matrix's own host arrays.
   bool build_cs_dev(const DeviceCsr &T, hipStream_t s, int kind) {
     cs.release();
-    peel_mask.release(); peel_blk.release(); npeel = 0;
+    peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     bool ok = false;
@@ -155,13 +159,13 @@ struct DeviceCsr {
       make_peel(rp.data(), peel_threshold(1), s);
       ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1, peel_mask.p);
     }
-    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; }
+    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; }
     cs_after_build(s);
     return ok;
   }
   bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, int kind) {
     cs.release();
-    peel_mask.release(); peel_blk.release(); npeel = 0;
+    peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
@@ -184,7 +188,7 @@ struct DeviceCsr {
       const std::vector<unsigned> mk = host_mask(1);
       ok = build_cs(rp, ci, v, rows, cols, h, 0, 1, mk.empty() ? nullptr : mk.data());
     }
-    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; return false; }
+    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; return false; }
     cs.from_host(h, s);
     cs_after_build(s);
     return true;
@@ -307,10 +311,11 @@ struct DeviceCsr {
       M.cs.peel = npeel > 0 ? peel_mask.p : nullptr;
       M.peel_blk = peel_blk.p;
       M.npeel = npeel;
+      M.nlong = npeel_long;
     }
     return M;
   }
-  int nwg() const { return cs.ok ? (cs.combine() ? cs.nchunks : cs.nchunks * cs.split) + npeel : has_slab ? s_nchunks : nblk; }
+  int nwg() const { return cs.ok ? (cs.combine() ? cs.nchunks : cs.nchunks * cs.split) + peel_wgs_for(npeel, npeel_long) : has_slab ? s_nchunks : nblk; }
   // after the CSR values were rescaled on the device: refresh the slab copy and drop the index map
   void refresh_slab(hipStream_t s, bool drop_perm) {
     if (!has_slab || s_perm.n == 0) return;  // (device-built slabs are made from the already equilibrated values)

@@ -37,6 +37,7 @@ struct CsrView {
   int rows, cols, nblk;
   long nnz;
   int pstride = 0, pbase = 0;  // reduction partials: slot stride / first slot (0: this launch's own workgroup count / 0)
+  int nlong = 0;               // k_spmv_peeled: the first nlong row blocks get a whole workgroup each
 };
 
 // Host-side: split rows into blocks of <= kNnzPerWg nonzeros (a longer row is alone in its block).
@@ -607,6 +608,57 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
   }
 }
 
+// Side launch of the column-sorted layouts: the rows peeled off the passes (longer than a count field holds).
+// blk[i] = {row, row + 1, first nonzero, end}, the nlong longest rows (> kPeelLongRow nonzeros) first: those get a whole
+// workgroup each, the others one WAVEFRONT each, four to a workgroup.  Lanes stride over the row with eight loads in
+// flight, then a fixed shuffle tree.  (A row this long is no longer summed in the oracle's sequential order: 1e-13 rel.)
+constexpr int kPeelRowsPerWg = kSpmvThreads / 64, kPeelLongRow = 2048;
+inline int peel_wgs_for(int npeel, int nlong) { return nlong + (npeel - nlong + kPeelRowsPerWg - 1) / kPeelRowsPerWg; }
+template <class Epi>
+__global__ __launch_bounds__(kSpmvThreads) void k_spmv_peeled(CsrView A, const double *__restrict__ x, Epi epi, const int *done_flag) {
+  if (done_flag && *done_flag) return;
+  __shared__ double red[kSpmvThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int NS = Epi::kSums > 0 ? Epi::kSums : 1, NM = Epi::kMaxs > 0 ? Epi::kMaxs : 1;
+  double sums[NS], maxs[NM];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sums[k] = 0.;
+#pragma unroll
+  for (int k = 0; k < NM; ++k) maxs[k] = 0.;
+  const bool whole_wg = (int)blockIdx.x < A.nlong;
+  const int i = whole_wg ? (int)blockIdx.x : A.nlong + ((int)blockIdx.x - A.nlong) * kPeelRowsPerWg + (tid >> 6);
+  const int step = whole_wg ? kSpmvThreads : 64, first = whole_wg ? tid : lane;
+  double acc = 0.;
+  int row = -1;
+  if (i < A.nblk) {
+    const int4 bi = A.blk[i];
+    row = bi.x;
+#pragma unroll 8
+    for (int k = bi.z + first; k < bi.w; k += step) acc += A.val[k] * x[A.col[k]];
+  }
+  if (whole_wg) {
+    acc = block_sum<kSpmvThreads>(acc, red);
+    __syncthreads();
+    if (tid == 0) epi(row, acc, sums, maxs);
+  } else {
+    acc = wave_sum(acc);
+    if (lane == 0 && row >= 0) epi(row, acc, sums, maxs);
+  }
+  if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
+    const int nslot = A.pstride > 0 ? A.pstride : (int)gridDim.x, slot = A.pbase + (int)blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < Epi::kSums; ++k) {
+      const double t = block_sum<kSpmvThreads>(sums[k], red);
+      if (tid == 0) epi.partial[(size_t)k * nslot + slot] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < Epi::kMaxs; ++k) {
+      const double t = block_max<kSpmvThreads>(maxs[k], red);
+      if (tid == 0) epi.partial[(size_t)(Epi::kSums + k) * nslot + slot] = t;
+    }
+  }
+}
+
 // One matrix, whichever layout init chose for it.  nblk = number of workgroups = number of
 // reduction partials an epilogue writes.
 struct SpmvMat {
@@ -618,10 +670,11 @@ struct SpmvMat {
   // rows peeled off the column-sorted layout (too long for its count fields): one row block each over the plain CSR,
   // done by a CSR-stream launch right behind the main one (bit r of cs.peel marks them)
   const int4 *peel_blk = nullptr;
-  int npeel = 0;
+  int npeel = 0, nlong = 0;
   bool cs_combine() const { return use_cs && cs.split > 1 && cs.ticket != nullptr; }
   int cs_main_wgs() const { return cs_combine() ? cs.nchunks : cs.nchunks * cs.split; }
-  int nblk() const { return use_cs ? cs_main_wgs() + npeel : use_slab ? slab.nchunks : csr.nblk; }
+  int peel_wgs() const { return peel_wgs_for(npeel, nlong); }
+  int nblk() const { return use_cs ? cs_main_wgs() + peel_wgs() : use_slab ? slab.nchunks : csr.nblk; }
 };
 
 // split layouts: the epilogue of a product whose functor is not linear in the row sum — rows finished from the two
@@ -662,7 +715,7 @@ inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const
     if (M.cs.nchunks <= 0) return;
     CsView V = M.cs;
     const int nmain = M.cs_main_wgs();
-    if (M.npeel > 0) V.pstride = nmain + M.npeel;  // the side launch's partials follow the main launch's
+    if (M.npeel > 0) V.pstride = nmain + M.peel_wgs();  // the side launch's partials follow the main launch's
     bool finished = false;
     if (!M.cs_combine()) {  // (combine mode: partial sums are added inside the kernel, finished rows for any epilogue)
       if constexpr (!epi_has_split<Epi>::value) {
@@ -679,9 +732,10 @@ inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const
       CsrView S = M.csr;
       S.blk = M.peel_blk;
       S.nblk = M.npeel;
-      S.pstride = nmain + M.npeel;
+      S.nlong = M.nlong;
+      S.pstride = nmain + M.peel_wgs();
       S.pbase = nmain;
-      hipLaunchKernelGGL(k_spmv_stream<Epi>, dim3(M.npeel), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag, (int *)nullptr);
+      hipLaunchKernelGGL(k_spmv_peeled<Epi>, dim3(M.peel_wgs()), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag);
     }
     return;
   }

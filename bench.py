@@ -162,6 +162,7 @@ def main():
     info = sol["info"]
     assert info["iter"] == args.steps, (info["iter"], args.steps, info["status"])
     del wsolver
+    psd_t = solver._solver._time_psd(reps=20)    # None unless the workload has PSD cones
     kt = solver._solver._kernel_times()          # in-situ samples (one CG step per host sync)
     kb = solver._solver._time_matvec(reps=30)    # back-to-back batch, event overhead amortised
     elapsed_max, total_iters = reduce_max_sum(elapsed, info["iter"])
@@ -290,6 +291,27 @@ def main():
                "in_situ_event_ms": round(k2_situ, 5)},
     }
 
+    if psd_t is not None:
+        # PSD-heavy workloads: the batched eigen-solve (K9) is the dominant kernel and the matrix cores bound it.
+        # achieved = reference flop count of a LAPACK-style symmetric eigensolve + reconstruction of the same matrices
+        # ((16/3 + 2) n^3 each) / measured time; the Jacobi method spends more (the MFMA instruction count is in
+        # profiles/r02_psd_mfma.txt).  Peak: MI355X fp64 matrix rate, 78.6 TFLOP/s (spec, dense).
+        MFMA_F64_PEAK = 78.6
+        # duration: in situ — the cone kernels of the timed solve's queued iterations between two HIP events on the
+        # solver's stream (K9 is all of it but the one-launch `l` / `q` kernels); the stand-alone re-projection of one
+        # iterate (psd_t["ms"]) is the fully warm lower bound, quoted beside it
+        cone_ms = kt["cone_ms"] / max(kt["cone_n"], 1)
+        if cone_ms > 0:
+            psd_t = dict(psd_t, ms_same_vector=round(psd_t["ms"], 4), ms=cone_ms)
+        tf = psd_t["ref_flops"] / (psd_t["ms"] * 1e-3) / 1e12
+        spmv_roofline = roofline
+        roofline = {"bound": "mfma", "achieved": round(tf, 4), "peak": MFMA_F64_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK, 5),
+                    "traffic": None, "kernel": "K9 batched PSD projection (k_proj_psd + k_psd_gemm + k_psd_apply_v), %d matrices of order <= %d, "
+                    "warm-started" % (psd_t["matrices"], psd_t["max_order"]),
+                    "algorithmic_flops_per_launch": psd_t["ref_flops"], "avg_launch_ms": round(psd_t["ms"], 4),
+                    "samples": kt["cone_n"], "ms_reprojecting_the_same_vector": psd_t.get("ms_same_vector"),
+                    "spmv": {k_: spmv_roofline[k_] for k_ in ("k1", "k2")}}
+
     # ---------------- CPU baseline (oracle, 1 thread, bounded samples) ----------------
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -327,7 +349,8 @@ def main():
 
     cg_per_s = total_cg / elapsed_max
     out = {
-        "metric": "ADMM iters/sec (random LP+SOC cone program, indirect CG linsys, AA lookback 10)",
+        "metric": "ADMM iters/sec (random %s cone program, indirect CG linsys, AA lookback 10)" % (
+            "LP+SOC" if "lp_soc" in args.workload else args.workload),
         "value": round(total_iters / elapsed_max, 4),
         "unit": "ADMM iters/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -97,8 +97,9 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
 double scs_hip_copy_bandwidth(size_t bytes, int reps);
 
 /* Live timing of the two dominant kernels inside scs_solve: when enabled, one CG step per
- * host sync is bracketed by HIP events on the solver's own stream.  out[8] =
- * {K1 total ms, K1 samples, K2 total ms, K2 samples, nnz(A), K1 workgroups, K2 workgroups, nnz(P full)}
+ * host sync is bracketed by HIP events on the solver's own stream.  out[10] =
+ * {K1 total ms, K1 samples, K2 total ms, K2 samples, nnz(A), K1 workgroups, K2 workgroups, nnz(P full),
+ *  nonlinear cone projections total ms, samples (one per queued iteration)}
  * where K1 = z <- R_y^{-1} A p  and  K2 = Gp <- A' z + R_x p (+ P p). */
 void scs_hip_set_profiling(ScsWork *w, int on);
 void scs_hip_kernel_times(const ScsWork *w, double *out);
@@ -134,6 +135,11 @@ void scs_hip_aa_reset(ScsHipAa *a);
 void scs_hip_aa_get_stats(const ScsHipAa *a, ScsAaStats *st);
 scs_int scs_hip_aa_last_gamma(const ScsHipAa *a, scs_float *gamma);
 void scs_hip_aa_finish(ScsHipAa *a);
+
+/* bench.py --workload config4_psd: average duration of one batched PSD projection (all `s` cones, warm-started as inside
+ * the ADMM loop) on the solver's stream; out[4] = {ms per projection, matrices, largest order, reference flop count
+ * ((16/3 + 2) n^3 per matrix)}.  0 on success, 1 when the problem has no PSD cone. */
+int scs_hip_time_psd(ScsWork *w, int reps, double *out);
 
 /* last error message of the calling thread ("" if none) */
 const char *scs_hip_last_error(void);

@@ -111,6 +111,10 @@ def workload(name):
         return {"l": 2000000}, 1000000, 20, 11
     if name == "banded_lp":       # layout robustness: metric size, banded
         return {"l": 2000000}, 1000000, 20, 12
+    if name == "config4_psd":     # BASELINE.json configs[3]: PSD-heavy, 50 matrices of order 200 + l
+        return {"l": 1000, "s": [200] * 50}, 335000, 30, 4
+    if name == "config3_mixed":   # BASELINE.json configs[2] without the box cone (bench leg; the tests add it)
+        return {"z": 100000, "l": 300000, "q": [20] * 5000, "ep": 50000, "ed": 50000, "p": [0.5, -0.5, 0.3] * 11111}, 500000, 20, 3
     if name == "small_lp_soc":    # smoke / CI size
         return {"l": 2000, "q": [10] * 200}, 2000, 20, 7
     if name == "config5_small":   # one problem of the 512-problem batch

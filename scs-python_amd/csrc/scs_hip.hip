@@ -456,6 +456,10 @@ struct ScsHipWork {
   hipEvent_t ev_iter[2] = {nullptr, nullptr};
   hipEvent_t ev_prof[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // in-situ K1/K2 samples of the run-ahead loop
   int prof_step[2] = {-1, -1};  // CG step (0-based) bracketed by ev_prof[slot], -1 = none
+  hipEvent_t ev_cone[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // in-situ: the cone kernels of a queued iteration
+  bool cone_sampled[2] = {false, false};
+  double prof_cone_ms = 0;
+  long prof_cone_n = 0;
 
   // hipGraphs of the launch-bound inner loop (built lazily at the first solve):
   //   g_pre[i] : iterate normalisation, rhs, CG start + kGraphSteps[i] CG steps + flag read-back
@@ -569,6 +573,7 @@ struct ScsHipWork {
     for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
     for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
     for (auto &es : ev_prof) for (auto &e : es) if (e) (void)hipEventDestroy(e);
+    for (auto &es : ev_cone) for (auto &e : es) if (e) (void)hipEventDestroy(e);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
@@ -838,7 +843,18 @@ struct ScsHipWork {
       }
     }
     enqueue_lin_sys_tail();
-    enqueue_cones();
+    cone_sampled[slot] = false;
+    if (profile) {  // the nonlinear cone projections of this queued iteration between two events (read when it is finished)
+      for (auto &e : ev_cone[slot]) if (!e) HIP_CHECK(hipEventCreate(&e));
+      hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
+                         d_params, sc.p, part.p, vb(l - 1), diag_r.p, stall_fl);
+      HIP_CHECK(hipEventRecord(ev_cone[slot][0], stream));
+      project_nonlinear_cones(u.p + n, 1);
+      HIP_CHECK(hipEventRecord(ev_cone[slot][1], stream));
+      cone_sampled[slot] = true;
+    } else {
+      enqueue_cones();
+    }
     enqueue_v_update();
     stall = nullptr;
     stall_fl = nullptr;
@@ -857,6 +873,10 @@ struct ScsHipWork {
     last_cg_iters = hf[F_ITERS];
     note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
+    if (profile && cone_sampled[slot]) {
+      float c = 0;
+      if (hipEventElapsedTime(&c, ev_cone[slot][0], ev_cone[slot][1]) == hipSuccess) { prof_cone_ms += c; prof_cone_n++; }
+    }
     if (profile && prof_step[slot] >= 0 && last_cg_iters > prof_step[slot]) {  // the sampled step really ran
       float a = 0, b = 0;
       if (hipEventElapsedTime(&a, ev_prof[slot][0], ev_prof[slot][1]) == hipSuccess &&
@@ -1561,6 +1581,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   w->tot_cg_iters = 0;
   w->prof_ms[0] = w->prof_ms[1] = 0;
   w->prof_n[0] = w->prof_n[1] = 0;
+  w->prof_cone_ms = 0; w->prof_cone_n = 0;
   double t_lin = 0, t_cone = 0, t_acc = 0;
 
   // ---- initial iterate ----
@@ -1998,6 +2019,44 @@ void scs_hip_get_mark(const ScsWork *w, double *out) {
   out[0] = w->mark_ms; out[1] = (double)w->mark_cg; out[2] = (double)w->mark_aa_calls; out[3] = (double)w->mark_aa_accept;
 }
 
+/* bench.py --workload config4_psd: average duration of one batched PSD projection (K9, all s-cones of the problem) on the
+ * solver's own stream and resident state — the current dual iterate is copied to a scratch vector and projected `reps`
+ * times (warm-started eigenvectors, as inside the ADMM loop); the copies are timed separately and subtracted.
+ * out[4] = {ms per projection, number of matrices, largest order, flops of a LAPACK-style eigensolve of them all
+ * (16/3 n^3 + 2 n^3 per matrix)}.  Returns 0 on success, 1 when the problem has no PSD cone. */
+int scs_hip_time_psd(ScsWork *w, int reps, double *out) {
+  if (!w || !out || reps <= 0) return -1;
+  try {
+    std::lock_guard<std::mutex> lock(w->mtx);
+    HIP_CHECK(hipSetDevice(w->device));
+    if (w->n_psd <= 0) return 1;
+    hipStream_t s = w->stream;
+    const size_t bytes = sizeof(double) * w->m;
+    auto copy = [&] { HIP_CHECK(hipMemcpyAsync(w->tmp_m.p, w->u.p + w->n, bytes, hipMemcpyDeviceToDevice, s)); };
+    for (int i = 0; i < 2; ++i) { copy(); w->launch_psd(w->tmp_m.p, w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd, w->n_psd_big); }
+    HIP_CHECK(hipEventRecord(w->ev[0], s));
+    for (int i = 0; i < reps; ++i) copy();
+    HIP_CHECK(hipEventRecord(w->ev[1], s));
+    for (int i = 0; i < reps; ++i) { copy(); w->launch_psd(w->tmp_m.p, w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd, w->n_psd_big); }
+    HIP_CHECK(hipEventRecord(w->ev[2], s));
+    HIP_CHECK(hipEventSynchronize(w->ev[2]));
+    float a = 0, b = 0;
+    HIP_CHECK(hipEventElapsedTime(&a, w->ev[0], w->ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&b, w->ev[1], w->ev[2]));
+    double flops = 0.;
+    int mx = 0;
+    for (int sd : w->cone.s) { flops += (16. / 3. + 2.) * (double)sd * sd * sd; mx = std::max(mx, sd); }
+    out[0] = (b - a) / reps;
+    out[1] = (double)w->cone.s.size();
+    out[2] = (double)mx;
+    out[3] = flops;
+    return 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
 void scs_hip_set_profiling(ScsWork *w, int on) {
   if (w) w->profile = on != 0;
 }
@@ -2007,6 +2066,7 @@ void scs_hip_kernel_times(const ScsWork *w, double *out) {
   out[2] = w->prof_ms[1]; out[3] = (double)w->prof_n[1];
   out[4] = (double)w->At.nnz; out[5] = (double)w->Ar.nwg(); out[6] = (double)w->At.nwg();
   out[7] = w->has_P ? (double)w->Pf.nnz : 0.0;
+  out[8] = w->prof_cone_ms; out[9] = (double)w->prof_cone_n;
 }
 
 // ---- kernel-level entry points (tests / bench) ----

@@ -165,6 +165,8 @@ def _load():
     lib.scs_hip_set_mark.argtypes = [C.c_void_p, c_int]
     lib.scs_hip_get_mark.restype = None
     lib.scs_hip_get_mark.argtypes = [C.c_void_p, _PD]
+    lib.scs_hip_time_psd.restype = c_int
+    lib.scs_hip_time_psd.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_time_matvec.restype = c_int
     lib.scs_hip_time_matvec.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
@@ -561,11 +563,12 @@ class SCS(object):
             _lib.scs_hip_set_profiling(self._work, 1 if on else 0)
 
     def _kernel_times(self):
-        out = np.zeros(8)
+        out = np.zeros(10)
         with self._lock:
             _lib.scs_hip_kernel_times(self._work, _pd(out))
         return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
-                "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7])}
+                "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7]),
+                "cone_ms": out[8], "cone_n": int(out[9])}
 
     def solution_to_device(self, x_ptr=None, y_ptr=None, s_ptr=None):
         """copy the last solve's (x, y, s) from the workspace's HBM buffers to DEVICE addresses (ints, e.g.
@@ -584,6 +587,15 @@ class SCS(object):
         out = np.zeros(4)
         _lib.scs_hip_get_mark(self._work, _pd(out))
         return {"ms": float(out[0]), "cg_iters": int(out[1]), "aa_calls": int(out[2]), "aa_accept": int(out[3])}
+
+    def _time_psd(self, reps=20):
+        out = np.zeros(4)
+        with self._lock:
+            rc = _lib.scs_hip_time_psd(self._work, int(reps), _pd(out))
+        if rc == 1:
+            return None
+        _check(rc)
+        return {"ms": float(out[0]), "matrices": int(out[1]), "max_order": int(out[2]), "ref_flops": float(out[3])}
 
     def _time_matvec(self, reps=20):
         out = np.zeros(2)

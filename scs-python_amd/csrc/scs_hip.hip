@@ -84,8 +84,9 @@ struct DeviceCsr {
         blk.push_back(int4{r, r + 1, rp_host[r], rp_host[r + 1]});
       }
     if (blk.empty()) return false;
-    // the longest rows first (a whole workgroup each in k_spmv_peeled), original order inside the two groups
-    std::stable_partition(blk.begin(), blk.end(), [](const int4 &b) { return b.w - b.z > kPeelLongRow; });
+    // the longest rows first (those > kPeelLongRow get a whole workgroup each in k_spmv_peeled; starting the long ones early
+    // keeps the tail of the launch short), ties in row order: a fixed order, so the reduction partials are deterministic
+    std::stable_sort(blk.begin(), blk.end(), [](const int4 &a, const int4 &b) { return a.w - a.z > b.w - b.z; });
     npeel_long = 0;
     for (const int4 &b : blk) npeel_long += (b.w - b.z > kPeelLongRow) ? 1 : 0;
     npeel = (int)blk.size();

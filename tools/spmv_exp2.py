@@ -1,5 +1,7 @@
-import sys, numpy as np, time
-sys.path.insert(0, "/root/repo/scs-python_amd"); sys.path.insert(0, "/root/repo")
+"""stand-alone products of the bench matrix through the C-ABI (tools/prof_spmv.sh profiles this)"""
+import os, sys, numpy as np, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scs-python_amd")); sys.path.insert(0, ROOT)
 from scs import _scs_hip as hip
 import problem_gen as pg
 rng = np.random.default_rng(0)

@@ -864,16 +864,26 @@ struct ScsHipWork {
   }
   // Wait for iteration `iter` of the run-ahead queue.  Returns false if its CG chunk was too short: the rest of that
   // iteration and everything queued behind it did nothing; the caller finishes the iteration synchronously.
+  // SCS_HIP_DEBUG_PIPE=1: per-iteration CG step counts and run-ahead stalls on stderr.
+  static bool debug_pipe() {
+    static const bool on = getenv("SCS_HIP_DEBUG_PIPE") != nullptr;
+    return on;
+  }
   bool finish_plain_iteration(int iter) {
     const int slot = iter & 1;
     HIP_CHECK(hipEventSynchronize(ev_iter[slot]));
     const int *hf = h_flags_slot[slot];
-    if (hf[F_STALL]) { ++pipe_stalls; return false; }
+    if (hf[F_STALL]) {
+      ++pipe_stalls;
+      if (debug_pipe()) std::fprintf(stderr, "[scs-hip] iter %d: STALL after %d CG steps\n", iter, hf[F_ITERS]);
+      return false;
+    }
     std::memcpy(h_flags, hf, sizeof(int) * F_COUNT);
     process_pending_flags();  // e.g. the verdict of the Anderson safeguard enqueued in the iteration before
     last_cg_iters = hf[F_ITERS];
     note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
+    if (debug_pipe()) std::fprintf(stderr, "[scs-hip] iter %d: %d CG steps (queued ahead)\n", iter, last_cg_iters);
     if (profile && cone_sampled[slot]) {
       float c = 0;
       if (hipEventElapsedTime(&c, ev_cone[slot][0], ev_cone[slot][1]) == hipSuccess) { prof_cone_ms += c; prof_cone_n++; }
@@ -1732,6 +1742,11 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     }
   }
   if (csv) std::fclose(csv);
+  if (ScsHipWork::debug_pipe()) {
+    std::fprintf(stderr, "[scs-hip] iterations %d, run-ahead stalls %d, CG steps of the last 8 solves:", i, w->pipe_stalls);
+    for (int v : w->cg_hist) std::fprintf(stderr, " %d", v);
+    std::fprintf(stderr, "\n");
+  }
   // ---- finalize ----
   if (i == max_iters) i = max_iters;  // loop ran out: rsk of the last iteration was computed
   w->read_flags();

@@ -516,7 +516,10 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
   }  // !resumed
-  if (MODE == 2) return;
+  if (MODE == 2) {
+    if (tid == 0) state[3] = state[4] = state[5] = state[6] = 0.;  // barrier counters of k_psd_sweep_mc, one per round
+    return;
+  }
   int nlog = 0;  // split mode: steps logged in this round
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_sw0);
@@ -693,6 +696,215 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   PSD_ACC(6, t_swept, t_end);
   if (tid == 0)
     for (int i = 1; i < 8; ++i) state[i] = prof[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Split mode, sweeps of ONE matrix over G workgroups (G CUs): same rotations and MFMA sequences as MODE 1 — bit-identical
+// A, rotation log and state — but the 16x16 pivot solves of a step (VALU-bound: 13 wavefronts on the 4 SIMDs of one CU
+// at order 200, 17 us per step) run one per SIMD on G CUs and the A-update tasks over 16 G wavefronts.
+//   step = [pivot k -> workgroup k % G, wave k / G: load, solve, W -> log]  barrier  [A tasks, W from the log]  barrier
+// The barrier is a monotonic counter per (matrix, round) in state[3 + round] (zeroed by the front kernel); a store is
+// acknowledged (s_waitcnt vmcnt(0)) before its workgroup arrives.  Data exchange (tools/xcd_coherence_lab.hip):
+//   * the G workgroups of a matrix get workgroup ids of the same residue mod 8, which the dispatcher deals to the same
+//     XCD: one shared L2.  Plain stores (write-through L1, acknowledged by the L2) + agent-scope (sc1) loads (L1 bypassed,
+//     L2 hit) are coherent there: 0 stale values in 5e8, 4.0 us per 32 KB ping-pong;
+//   * every member publishes its HW_REG_XCC_ID first; a group that is NOT on one XCD (other partition modes, a
+//     different dispatcher) falls back to sc1 (write-through to memory) stores, which are coherent across XCDs
+//     (6.2 us per ping-pong) — plain stores would be 100 % stale there.
+// Launched with hipLaunchCooperativeKernel: co-residency of every spinning workgroup is the runtime's guarantee,
+// not an assumption about what else runs on the GPU; a spin budget still turns a would-be hang into an error flag.
+// ---------------------------------------------------------------------------
+constexpr int kPsdMcMaxG = 8;
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ unsigned psd_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+__host__ __device__ inline int psd_mc_grid(int count, int G) { return 8 * G * ((count + 7) / 8); }
+
+__global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int *err, const int *stall) {
+  SCS_STALL_GUARD(stall);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  double *red = lds + kPsdWaves * kPsdWaveLds;
+  double *bc = red + 16;
+  int *osch = reinterpret_cast<int *>(bc + 2);
+  // workgroup id -> (matrix, member): ids are dealt round-robin to the 8 XCDs
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cidx = (slot / G) * 8 + xcd, g = slot % G;
+  if (cidx >= B.count) return;
+  const int n = B.order[cidx];
+  if (n < 2) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP;
+  double *A = scratch + B.woff[cidx];
+  double *Wlog = A + 4 * (size_t)NP * NP + (size_t)H * kPsdWsz;
+  double *state = Wlog + psd_log_doubles(n) + NP;
+  unsigned *bar = reinterpret_cast<unsigned *>(state + 3 + round);
+  const bool finished = round > 0 && state[1] != 0.;  // written by the previous round's launch
+  if (g == 0 && tid == 0) {
+    state[2] = 0.;
+    if (round == 0) state[1] = 0.;
+  }
+  if (finished) return;
+  double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
+  const int nblk = H * (H + 1) / 2;
+  unsigned bar_target = 0;
+  auto gbar = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
+    __syncthreads();
+    if (G > 1) {
+      bar_target += (unsigned)G;
+      if (tid == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1L << 25)) { *err = 1; break; }  // seconds: a member never arrived
+        }
+      }
+      __syncthreads();
+    }
+  };
+
+  // one XCD for the whole group?  (state[6]: OR of the members' XCD bits, zeroed by the front kernel)
+  bool wt = false;  // write-through (sc1) stores
+  if (G > 1) {
+    unsigned *xmask = reinterpret_cast<unsigned *>(state + 6);
+    if (tid == 0) __hip_atomic_fetch_or(xmask, 1u << psd_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gbar();
+    if (tid == 0) bc[1] = (double)__popc(__hip_atomic_load(xmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    wt = bc[1] != 1.;
+#ifdef PSD_MC_FORCE_WT
+    wt = true;
+#endif
+  }
+  auto st_shared = [&](double *p, double v) {
+    if (wt) st_agent(p, v);
+    else *p = v;
+  };
+  int nlog = 0;
+#if PSD_PROFILE
+  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};  // [1] norms [2] pivot load+solve+store [3] barrier 1 [4] A tasks [5] barrier 2
+#endif
+  for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
+    PSD_TICK(t_n0);
+    // every member evaluates the stopping test on the same data in the same order: the same decision everywhere
+    double off = 0., tot = 0.;
+    for (int e = tid; e < n * n; e += kPsdThreads) {
+      const int i = e % n, j = e / n;
+      const double a = ld_agent(&A[i + (size_t)ld * j]);
+      tot += a * a;
+      if (i != j) off += a * a;
+    }
+    off = block_sum<kPsdThreads>(off, red);
+    tot = block_sum<kPsdThreads>(tot, red);
+    if (tid == 0) bc[0] = (off <= kPsdOffTol2 * tot || off == 0.) ? 1. : 0.;
+    __syncthreads();
+    const bool done = bc[0] != 0.;
+    __syncthreads();
+    PSD_TICK(t_n1);
+    PSD_ACC(1, t_n0, t_n1);
+    if (done) {
+      if (g == 0 && tid == 0) state[1] = 1.;
+      break;
+    }
+    if (sweep >= kPsdLogSweeps) break;  // log full: the next round continues
+
+    for (int r = 0; r < NB - 1; ++r) {
+      for (int k = tid; k < H; k += kPsdThreads) {
+        int p, q;
+        rr_pair(r, k, NB, p, q);
+        if (k < kPsdMaxH) { osch[2 * k] = p; osch[2 * k + 1] = q; }
+      }
+      __syncthreads();
+      PSD_TICK(t_p0);
+      // ---------------- phase 1: pivot k on workgroup k % G, wave k / G ----------------
+      for (int k = g + G * wave; k < H; k += G * kPsdWaves) {
+        const int p = osch[2 * k], q = osch[2 * k + 1];
+        for (int e = lane; e < 256; e += 64) {
+          const int i = e & 15, j = e >> 4;
+          Sw[i + kPsdLd * j] = ld_agent(&A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)]);
+        }
+        wave_sync();
+        wave_jacobi16(Sw, Ww, lane);
+        double *Wk = Wlog + ((size_t)nlog * H + k) * kPsdWsz;
+        for (int e = lane; e < kPsdWsz; e += 64) st_shared(&Wk[e], Ww[e]);
+      }
+      __syncthreads();
+      PSD_TICK(t_p1);
+      gbar();
+      PSD_TICK(t_p2);
+      // ---------------- phase 2: A <- W' A W over block pairs k <= k2, 16 G wavefronts ----------------
+      // Two tasks per trip: the (L2-bypassing) loads of both are in flight together — the phase is one load latency
+      // deep instead of two at order 200 (91 tasks on 64 wavefronts).
+      for (int task0 = g + G * wave; task0 < nblk; task0 += 2 * G * kPsdWaves) {
+        int tk[2], tk2[2], trow[2], tp[2], tq[2], tp2[2], tq2[2];
+        bool live[2];
+        double av[2][4], w1[2][4], w2[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int task = task0 + u * G * kPsdWaves;
+          live[u] = task < nblk;
+          int k = 0, rem = live[u] ? task : 0;
+          while (rem >= H - k) { rem -= H - k; ++k; }
+          tk[u] = k;
+          tk2[u] = k + rem;
+          tp[u] = osch[2 * k]; tq[u] = osch[2 * k + 1]; tp2[u] = osch[2 * tk2[u]]; tq2[u] = osch[2 * tk2[u] + 1];
+          trow[u] = pq_index(li, tp[u], tq[u]);
+          if (live[u]) {
+            const double *W1 = Wlog + ((size_t)nlog * H + k) * kPsdWsz, *W2 = Wlog + ((size_t)nlog * H + tk2[u]) * kPsdWsz;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              av[u][kk] = ld_agent(&A[trow[u] + (size_t)ld * pq_index(4 * kk + lk, tp2[u], tq2[u])]);
+              w2[u][kk] = ld_agent(&W2[(4 * kk + lk) + kPsdWLd * li]);
+              w1[u][kk] = ld_agent(&W1[(4 * kk + lk) + kPsdWLd * li]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!live[u]) break;
+          f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][kk], w2[u][kk], T, 0, 0, 0);
+          f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[u][t], T[t], Rr, 0, 0, 0);
+          const int gi = pq_index(li, tp2[u], tq2[u]);
+          if (tk[u] != tk2[u]) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) st_shared(&A[gi + (size_t)ld * pq_index(lk + 4 * t, tp[u], tq[u])], Rr[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
+          wave_sync();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) st_shared(&A[trow[u] + (size_t)ld * pq_index(lk + 4 * t, tp2[u], tq2[u])], Sw[li + 17 * (lk + 4 * t)]);
+          wave_sync();
+        }
+      }
+      __syncthreads();
+      PSD_TICK(t_p3);
+      gbar();
+      PSD_TICK(t_p4);
+      PSD_ACC(2, t_p0, t_p1);
+      PSD_ACC(3, t_p1, t_p2);
+      PSD_ACC(4, t_p2, t_p3);
+      PSD_ACC(5, t_p3, t_p4);
+      ++nlog;
+    }
+  }
+  if (g == 0 && tid == 0) state[2] = (double)nlog;
+#if PSD_PROFILE
+  if (cidx == 0 && tid == 0 && nlog > 0)
+    printf("  mc member %d round %d: %d steps; per step (us): norms %.2f  pivots %.2f  barrier %.2f  A tasks %.2f  barrier %.2f\n", g, round, nlog,
+           prof[1] / 100 / nlog, prof[2] / 100 / nlog, prof[3] / 100 / nlog, prof[4] / 100 / nlog, prof[5] / 100 / nlog);
 #endif
 }
 

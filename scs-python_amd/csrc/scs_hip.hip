@@ -519,7 +519,21 @@ struct ScsHipWork {
         hipLaunchKernelGGL(k_proj_psd<2>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+        const int mc = in_capture ? 1 : psd_mc_members(big);
         for (int round = 0; round < kPsdSplitRounds; ++round) {
+          if (mc > 1) {  // sweeps of one matrix over `mc` CUs (k_psd_sweep_mc): cooperative launch, spinning barriers
+            double *scr = psd_scratch.p;
+            int G = mc, rnd = round;
+            int *err = fl.p + F_PERSIST_ERR;
+            const int *st = stall;
+            void *args[] = {&B, &scr, &rnd, &G, &err, &st};
+            if (psd_mc_coop)
+              HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
+                                                   dim3(kPsdThreads), args, (unsigned)kPsdLdsBytes, stream));
+            else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
+              hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdLdsBytes, stream, B, scr, rnd, G,
+                                 err, st);
+          } else
           hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
@@ -535,6 +549,32 @@ struct ScsHipWork {
       hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall);
     }
   }
+  // Members (CUs) per matrix for the split-mode sweeps: as many as fit when every matrix gets the same number and a
+  // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
+  // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
+  bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return !(e && e[0] == '0'); }();
+  int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
+  int psd_mc_members(int big) {
+    if (psd_mc_cap < 0) {
+      int coop = 0, per_cu = 0, cus = 0;
+      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_psd_sweep_mc), kPsdThreads, kPsdLdsBytes) != hipSuccess)
+        per_cu = 0;
+      psd_mc_cap = coop ? std::min(per_cu, 1) * cus : 0;  // one member per CU: the pivot solves want a SIMD each
+    }
+    const int groups = 8 * ((big + 7) / 8);
+    // at least ~3 pivots per member and step: below that the barriers cost more than the spread saves
+    // (tools/psd_mc_lab.sh: order 200 x 50, G = 4: 3.57 -> 2.24 ms per projection; order 64 x 100, G = 2: 0.29 -> 0.42 ms)
+    const int pivots = psd_max_np / (2 * kPsdB);
+    int G = std::min(std::min(psd_mc_cap / groups, kPsdMcMaxG), pivots / 3);
+    if (const char *env = getenv("SCS_HIP_PSD_MC")) {
+      G = atoi(env);
+      if (G > kPsdMcMaxG || (long)G * groups > (long)psd_mc_cap) G = 1;
+    }
+    return std::max(G, 1);
+  }
+  bool in_capture = false;
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
   // AA (aa.hpp): f = v (map output), x = v_prev (map input); the safeguard verdict rides along with the CG flags
@@ -614,6 +654,7 @@ struct ScsHipWork {
   }
 
   void process_pending_flags() {
+    if (h_flags[F_PERSIST_ERR]) throw std::runtime_error("a spinning multi-workgroup kernel (persistent CG / PSD sweeps) timed out at its barrier");
     if (aa.pending_safeguard) {
       const bool bad = h_flags[F_SAFE_BAD] != 0;
       aa.safeguard_verdict(bad);
@@ -920,13 +961,16 @@ struct ScsHipWork {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    in_capture = true;
     try {
       body();
     } catch (...) {
+      in_capture = false;
       (void)hipStreamEndCapture(stream, &graph);
       if (graph) (void)hipGraphDestroy(graph);
       throw;
     }
+    in_capture = false;
     HIP_CHECK(hipStreamEndCapture(stream, &graph));
     HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_CHECK(hipGraphDestroy(graph));

@@ -512,6 +512,43 @@ def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
 
 
+# ---- K9 split mode, sweeps of one matrix spread over G CUs (k_psd_sweep_mc) vs the one-workgroup sweep kernel ----
+@pytest.mark.parametrize("coop", ["1", "0"])
+def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coop):
+    """Same rotations, same MFMA sequences, spinning barriers between the members of a matrix's group: every bit of the
+    projection — and of a whole solve with warm starts, re-orthogonalisation and several [sweep, apply] rounds — must
+    be the one the single-workgroup sweeps give.  G = 3 leaves members without a pivot at order 40; G = 8 is the cap."""
+    monkeypatch.setenv("SCS_HIP_PSD_SPLIT", "1")
+    monkeypatch.setenv("SCS_HIP_PSD_COOP", coop)  # 0: ordinary launch (profilers)
+    rng = np.random.RandomState(12)
+    K = {"l": 5, "s": [200, 130, 40, 96, 64, 33, 177, 50, 150], "cs": [60, 20]}
+    z = rng.randn(pg.cone_dims(K))
+    out = {}
+    for G in ("1", "2", "3", "4", "8"):
+        monkeypatch.setenv("SCS_HIP_PSD_MC", G)
+        out[G] = hip.proj_cone(z, K)
+    for G in ("2", "3", "4", "8"):
+        np.testing.assert_array_equal(out["1"], out[G], err_msg="G=" + G)
+    o = 5
+    for k in K["s"]:  # and it is the projection: numpy's eigensolver
+        d = k * (k + 1) // 2
+        S = helpers.svec_to_sym(z[o:o + d], k)
+        w, V = np.linalg.eigh(S)
+        np.testing.assert_allclose(out["4"][o:o + d], helpers.sym_to_svec((V * np.maximum(w, 0)) @ V.T), rtol=0, atol=1e-10 * k)
+        o += d
+    K = {"l": 30, "s": [100, 128, 40]}
+    data, _, _ = pg.gen_feasible_qp(K, pg.cone_dims(K) + 2, 6, 23, helpers.proj_dual_l_s_numpy)
+    args = helpers.raw_args(data, K)
+    sols = {}
+    for G in ("1", "4"):
+        monkeypatch.setenv("SCS_HIP_PSD_MC", G)
+        sols[G] = hip.SCS(*args, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iters=5000).solve(False, None, None, None)
+    assert sols["1"]["info"]["iter"] == sols["4"]["info"]["iter"] and sols["1"]["info"]["iter"] > 64
+    assert sols["1"]["info"]["status"] == sols["4"]["info"]["status"] == "solved", sols["1"]["info"]
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(sols["1"][key], sols["4"][key], err_msg=key)
+
+
 # ---- run-ahead ADMM loop (whole iterations enqueued ahead of the host) vs one host look per iteration ----
 @pytest.mark.parametrize("case", ["lp_soc", "qp_mixed", "sdp", "long_cg"])
 def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):

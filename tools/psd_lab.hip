@@ -1,12 +1,14 @@
 // psd_lab.hip — phase breakdown of the batched PSD projection kernel (K9) with PSD_PROFILE timers.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPSD_PROFILE=1 -o devtools/psd_lab tools/psd_lab.hip
-//   ./devtools/psd_lab [order] [count] [calls] [perturbation]
+//   ./devtools/psd_lab [order] [count] [calls] [perturbation] [split: 0 one launch, 1 split mode, G >= 2 split mode with the sweeps
+//                       of each matrix over G workgroups (k_psd_sweep_mc)] [compare: 1 = rerun in split mode 1 and compare the bits]
 // First call is cold (V = I); later calls are warm-started on a matrix perturbed by `perturbation` (relative),
 // which is what consecutive ADMM iterations look like.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -17,16 +19,24 @@ using namespace scship;
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 200, cnt = argc > 2 ? atoi(argv[2]) : 50, calls = argc > 3 ? atoi(argv[3]) : 6;
   const double pert = argc > 4 ? atof(argv[4]) : 1e-3;
-  const bool split = argc > 5 && atoi(argv[5]) != 0;
+  const int split_arg = argc > 5 ? atoi(argv[5]) : 0;
+  const bool compare = argc > 6 && atoi(argv[6]) != 0;
+  int *d_err;
+  HIP_CHECK(hipMalloc(&d_err, 4));
+  HIP_CHECK(hipMemset(d_err, 0, 4));
+  std::vector<std::vector<double>> outs[2];
+  for (int pass = 0; pass < (compare ? 2 : 1); ++pass) {
+  const int mc = pass == 0 ? split_arg : 1;
+  const bool split = mc != 0;
   const long vlen = (long)n * (n + 1) / 2;
-  std::vector<int> off(cnt), ord(cnt, n);
-  std::vector<long> woff(cnt);
-  long wtot = 0;
-  for (int c = 0; c < cnt; ++c) { off[c] = (int)(c * vlen); woff[c] = wtot; wtot += psd_scratch_doubles(n); }
   std::mt19937_64 g(1);
   std::normal_distribution<double> nd;
   std::vector<double> x0(cnt * vlen), x(cnt * vlen);
   for (auto &v : x0) v = nd(g);
+  std::vector<int> off(cnt), ord(cnt, n);
+  std::vector<long> woff(cnt);
+  long wtot = 0;
+  for (int c = 0; c < cnt; ++c) { off[c] = (int)(c * vlen); woff[c] = wtot; wtot += psd_scratch_doubles(n); }
   int *d_off, *d_ord; long *d_woff; double *d_x, *d_scr;
   HIP_CHECK(hipMalloc(&d_off, cnt * 4)); HIP_CHECK(hipMalloc(&d_ord, cnt * 4)); HIP_CHECK(hipMalloc(&d_woff, cnt * 8));
   HIP_CHECK(hipMalloc(&d_x, x.size() * 8)); HIP_CHECK(hipMalloc(&d_scr, wtot * 8));
@@ -54,6 +64,16 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       for (int round = 0; round < 3; ++round) {
+        if (mc >= 2) {
+          int G = mc, rnd = round;
+          const int *st = nullptr;
+          void *args[] = {&B, &d_scr, &rnd, &G, &d_err, &st};
+          if (getenv("PSD_LAB_PLAIN"))  // ordinary launch (e.g. under rocprofv3)
+            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdLdsBytes, 0, B, d_scr, rnd, G, d_err, st);
+          else
+          HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads),
+                                               args, (unsigned)kPsdLdsBytes, 0));
+        } else
         hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
         hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
@@ -64,10 +84,15 @@ int main(int argc, char **argv) {
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     double st[8];
     HIP_CHECK(hipMemcpy(st, d_scr + st_off, sizeof st, hipMemcpyDeviceToHost));
+    outs[pass].emplace_back(x.size());
+    HIP_CHECK(hipMemcpy(outs[pass].back().data(), d_x, x.size() * 8, hipMemcpyDeviceToHost));
     const double steps = n <= kPsdSmallMax ? st[7] * (((n + 1) & ~1) - 1) : st[7] * (np / 8 - 1);  // rounds of the one-wave kernel / outer steps
     std::printf("%3d  %9.1f | %6.1f  %8.1f  %7.1f  %7.1f  %11.1f  %11.1f | %6.0f  %5.0f  %13.2f  %14.2f\n", call, ms * 1e3, st[1] / 100, st[2] / 100,
                 st[3] / 100, st[4] / 100, st[5] / 100, st[6] / 100, st[7], steps, steps ? st[3] / 100 / steps : 0., steps ? st[4] / 100 / steps : 0.);
   }
+  int herr = 0;
+  HIP_CHECK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
+  if (herr) std::printf("BARRIER TIMEOUT flagged\n");
   {  // orthogonality of the warm-start basis of matrix 0 after all calls
     const bool small = n <= kPsdSmallMax;
     const long N = small ? ((n + 1) & ~1) : np;
@@ -81,6 +106,16 @@ int main(int argc, char **argv) {
         worst = std::max(worst, std::fabs(acc - (i == j ? 1. : 0.)));
       }
     std::printf("max |V'V - I| after %d calls: %.3e\n", calls, worst);
+  }
+  g.seed(1);
+  nd.reset();
+  for (auto &v : x0) v = nd(g);  // same inputs in the second pass
+  }  // pass
+  if (compare) {
+    long diff = 0;
+    for (size_t c = 0; c < outs[0].size(); ++c)
+      for (size_t i = 0; i < outs[0][c].size(); ++i) diff += std::memcmp(&outs[0][c][i], &outs[1][c][i], 8) != 0;
+    std::printf("bitwise differences between the two passes over %zu calls: %ld\n", outs[0].size(), diff);
   }
   return 0;
 }

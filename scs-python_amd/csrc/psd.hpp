@@ -80,6 +80,9 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
   if (nb < 2) nb = 2;
   return nb * kPsdB;
 }
+// Rotation log entry: W row-major (ld 16), so that the MFMA operand fetch W[4 kk + lk][li] of a wavefront is 64 consecutive
+// doubles (4 lines per instruction; the column-major stride-17 LDS layout read from global memory costs 17)
+__host__ __device__ inline int psd_log_at(int row, int col) { return col + 16 * row; }
 constexpr int kPsdLogSweeps = 4;  // split mode: sweeps whose pivot rotations fit in the log of one round
 __host__ __device__ inline long psd_log_doubles(long n) {  // rotation log: sweeps x steps x pivots x 16x17
   const long np = psd_np(n), nb = np / kPsdB;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
         if (!w_in_lds)
           for (int e = lane; e < kPsdWsz; e += 64) Wg[(size_t)k * kPsdWsz + e] = Ww[e];
         if (MODE == 1)
-          for (int e = lane; e < kPsdWsz; e += 64) Wlog[((size_t)nlog * H + k) * kPsdWsz + e] = Ww[e];
+          for (int e = lane; e < 256; e += 64) Wlog[((size_t)nlog * H + k) * kPsdWsz + e] = Ww[(e >> 4) + kPsdWLd * (e & 15)];
       }
       __syncthreads();
       PSD_TICK(t_s2);
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
         wave_sync();
         wave_jacobi16(Sw, Ww, lane);
         double *Wk = Wlog + ((size_t)nlog * H + k) * kPsdWsz;
-        for (int e = lane; e < kPsdWsz; e += 64) st_shared(&Wk[e], Ww[e]);
+        for (int e = lane; e < 256; e += 64) st_shared(&Wk[e], Ww[(e >> 4) + kPsdWLd * (e & 15)]);
       }
       __syncthreads();
       PSD_TICK(t_p1);
@@ -862,8 +865,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
               av[u][kk] = ld_agent(&A[trow[u] + (size_t)ld * pq_index(4 * kk + lk, tp2[u], tq2[u])]);
-              w2[u][kk] = ld_agent(&W2[(4 * kk + lk) + kPsdWLd * li]);
-              w1[u][kk] = ld_agent(&W1[(4 * kk + lk) + kPsdWLd * li]);
+              w2[u][kk] = ld_agent(&W2[psd_log_at(4 * kk + lk, li)]);
+              w1[u][kk] = ld_agent(&W1[psd_log_at(4 * kk + lk, li)]);
             }
           }
         }
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, do
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         av[kk] = strip[li + 16 * pq_index(4 * kk + lk, p, q)];
-        w[kk] = W1[(4 * kk + lk) + kPsdWLd * li];
+        w[kk] = W1[psd_log_at(4 * kk + lk, li)];
       }
       f64x4 T = {0., 0., 0., 0.};
 #pragma unroll

@@ -729,13 +729,22 @@ __device__ __forceinline__ unsigned psd_xcc_id() {
 }
 __host__ __device__ inline int psd_mc_grid(int count, int G) { return 8 * G * ((count + 7) / 8); }
 
-__global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int *err, const int *stall) {
+constexpr size_t kPsdMcLdsBytes = kPsdLdsBytes + 4 * kPsdMaxH * sizeof(int);  // + next step's schedule, block -> (pair, position) map
+// look_ahead (and H <= 8 G): ONE barrier per step.  While the other wavefronts run the A tasks of step t (reading A_t, writing
+// A_{t+1} into the second buffer — Tm is free during the sweeps), the wavefront that owns pivot k' of step t+1 computes the
+// three tasks that produce its 16x16 block — (a,a), (b,b), (a,b) for the pairs a, b that hold its two 8-blocks in step t —
+// itself, keeps the results in registers, assembles the block in LDS, solves it and logs W_{t+1}: the 8 us pivot solve
+// disappears behind the 6 us of A tasks.  Same MFMA sequences on the same inputs: the same bits.
+__global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int look_ahead, int *err,
+                                                              const int *stall) {
   SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *lds = reinterpret_cast<double *>(smem_raw);
   double *red = lds + kPsdWaves * kPsdWaveLds;
   double *bc = red + 16;
-  int *osch = reinterpret_cast<int *>(bc + 2);
+  int *osch = reinterpret_cast<int *>(bc + 2);  // block pairs (p < q) of the current step
+  int *osch_n = osch + 2 * kPsdMaxH;            // ... of the next step
+  int *where = osch_n + 2 * kPsdMaxH;           // block -> 2 * pair + position (0: p, 1: q) in the current step
   // workgroup id -> (matrix, member): ids are dealt round-robin to the 8 XCDs
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int cidx = (slot / G) * 8 + xcd, g = slot % G;
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   const int nblk = H * (H + 1) / 2;
   unsigned bar_target = 0;
   auto gbar = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are acknowledged
     __syncthreads();
     if (G > 1) {
       bar_target += (unsigned)G;
@@ -791,17 +800,138 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
     if (wt) st_agent(p, v);
     else *p = v;
   };
-  int nlog = 0;
 #if PSD_PROFILE
-  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};  // [1] norms [2] pivot load+solve+store [3] barrier 1 [4] A tasks [5] barrier 2
+  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};  // [1] norms [2] pivots from memory [3] barrier [4] tasks (+ pivots ahead) [5] barrier [6] feeder tasks [7] solve
 #endif
+  const bool la = look_ahead && G > 1 && H <= 8 * G && H >= 2;
+  double *Acur = A, *Anxt = la ? A + 2 * (size_t)NP * NP : A;  // without look-ahead the update is in place
+  // look-ahead roles: pivot k' of the next step on member k' % G, wave k' / G (< 8); the other wavefronts are task workers
+  const int npw = g < H ? (H - g + G - 1) / G : 0;
+  const bool pivot_wave = wave < npw;
+  int wid = wave - npw;
+  for (int g2 = 0; g2 < g; ++g2) wid += kPsdWaves - (g2 < H ? (H - g2 + G - 1) / G : 0);
+  const int nworkers = G * kPsdWaves - H;
+
+  // operands of task (k, k2 >= k) of the current step: the block rows{p,q} x cols{p2,q2} of Acur and the two logged rotations
+  auto task_pairs = [&](int task, int &k, int &k2) {
+    int kk = 0, rem = task;
+    while (rem >= H - kk) { rem -= H - kk; ++kk; }
+    k = kk;
+    k2 = kk + rem;
+  };
+  auto load_task = [&](int k, int k2, int step, double (&av)[4], double (&w1)[4], double (&w2)[4]) {
+    const int p = osch[2 * k], q = osch[2 * k + 1], p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
+    const double *W1 = Wlog + ((size_t)step * H + k) * kPsdWsz, *W2 = Wlog + ((size_t)step * H + k2) * kPsdWsz;
+    const int row = pq_index(li, p, q);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      av[kk] = ld_agent(&Acur[row + (size_t)ld * pq_index(4 * kk + lk, p2, q2)]);
+      w2[kk] = ld_agent(&W2[psd_log_at(4 * kk + lk, li)]);
+      w1[kk] = ld_agent(&W1[psd_log_at(4 * kk + lk, li)]);
+    }
+  };
+  auto mma_task = [&](const double (&av)[4], const double (&w1)[4], const double (&w2)[4]) {
+    f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], w2[kk], T, 0, 0, 0);
+    f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T: lane holds R[lk + 4t][li], rows <-> pair k, columns <-> pair k2
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[t], T[t], Rr, 0, 0, 0);
+    return Rr;
+  };
+  // Two tasks per trip: the loads of both are in flight together.
+  auto run_tasks = [&](int first, int stride, int step) {
+    for (int task0 = first; task0 < nblk; task0 += 2 * stride) {
+      int tk[2], tk2[2];
+      bool live[2];
+      double av[2][4], w1[2][4], w2[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int task = task0 + u * stride;
+        live[u] = task < nblk;
+        task_pairs(live[u] ? task : 0, tk[u], tk2[u]);
+        if (live[u]) load_task(tk[u], tk2[u], step, av[u], w1[u], w2[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!live[u]) break;
+        const f64x4 Rr = mma_task(av[u], w1[u], w2[u]);
+        const int p = osch[2 * tk[u]], q = osch[2 * tk[u] + 1], p2 = osch[2 * tk2[u]], q2 = osch[2 * tk2[u] + 1];
+        const int gi = pq_index(li, p2, q2), row = pq_index(li, p, q);
+        if (tk[u] != tk2[u]) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) st_shared(&Anxt[gi + (size_t)ld * pq_index(lk + 4 * t, p, q)], Rr[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st_shared(&Anxt[row + (size_t)ld * pq_index(lk + 4 * t, p2, q2)], Sw[li + 17 * (lk + 4 * t)]);
+        wave_sync();
+      }
+    }
+  };
+  auto log_w = [&](int step, int k) {
+    double *Wk = Wlog + ((size_t)step * H + k) * kPsdWsz;
+    for (int e = lane; e < 256; e += 64) st_shared(&Wk[e], Ww[(e >> 4) + kPsdWLd * (e & 15)]);
+  };
+  // pivot kn of the NEXT step from the three tasks of this step that produce its block
+  auto pivot_ahead = [&](int kn, int step) {
+    const int pn = osch_n[2 * kn], qn = osch_n[2 * kn + 1];
+    const int a = where[pn] >> 1, pa = where[pn] & 1, b = where[qn] >> 1, pb = where[qn] & 1;
+    PSD_TICK(t_f0);
+    // the three tasks share two rotations: W_a, W_b (20 loads in flight, not 36)
+    double av[3][4], wa[4], wb[4];
+    {
+      const int pa_ = osch[2 * a], qa_ = osch[2 * a + 1], pb_ = osch[2 * b], qb_ = osch[2 * b + 1];
+      const int pl = a < b ? pa_ : pb_, ql = a < b ? qa_ : qb_, ph = a < b ? pb_ : pa_, qh = a < b ? qb_ : qa_;
+      const double *Wa = Wlog + ((size_t)step * H + a) * kPsdWsz, *Wb = Wlog + ((size_t)step * H + b) * kPsdWsz;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        av[0][kk] = ld_agent(&Acur[pq_index(li, pa_, qa_) + (size_t)ld * pq_index(4 * kk + lk, pa_, qa_)]);
+        av[1][kk] = ld_agent(&Acur[pq_index(li, pb_, qb_) + (size_t)ld * pq_index(4 * kk + lk, pb_, qb_)]);
+        av[2][kk] = ld_agent(&Acur[pq_index(li, pl, ql) + (size_t)ld * pq_index(4 * kk + lk, ph, qh)]);
+        wa[kk] = ld_agent(&Wa[psd_log_at(4 * kk + lk, li)]);
+        wb[kk] = ld_agent(&Wb[psd_log_at(4 * kk + lk, li)]);
+      }
+    }
+    const f64x4 Ra = mma_task(av[0], wa, wa), Rb = mma_task(av[1], wb, wb);
+    const f64x4 Rc = a < b ? mma_task(av[2], wa, wb) : mma_task(av[2], wb, wa);
+    // S = [[A(pn,pn), A(pn,qn)], [A(qn,pn), A(qn,qn)]] after this step; R[x][y] = A[pair k index x][pair k2 index y]
+    // Branch-free: every lane writes all four candidates, the ones that do not belong to the pivot go to the lane's own
+    // slot of the (not yet initialised) W scratch.  row = lk + 4t, col = li: row >> 3 = t >> 1.
+    const int pr = a < b ? pa : pb, pc = a < b ? pb : pa;  // position of the cross block's row / column 8-block in Rc
+    const int c7 = li & 7, ch = li >> 3, trash = kPsdWsz + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rh = t >> 1, r7 = lk + 4 * (t & 1);
+      const int ia = (rh == pa && ch == pa) ? r7 + kPsdLd * c7 : trash;
+      const int ib = (rh == pb && ch == pb) ? 8 + r7 + kPsdLd * (8 + c7) : trash;
+      const bool inc = rh == pr && ch == pc;
+      const int ic1 = !inc ? trash : (a < b ? r7 + kPsdLd * (8 + c7) : 8 + r7 + kPsdLd * c7);
+      const int ic2 = !inc ? trash : (a < b ? 8 + c7 + kPsdLd * r7 : c7 + kPsdLd * (8 + r7));
+      Sw[ia] = Ra[t];
+      Sw[ib] = Rb[t];
+      Sw[ic1] = Rc[t];
+      Sw[ic2] = Rc[t];
+    }
+    wave_sync();
+    PSD_TICK(t_f1);
+    wave_jacobi16(Sw, Ww, lane);
+    PSD_TICK(t_f2);
+    log_w(step + 1, kn);
+    PSD_ACC(6, t_f0, t_f1);
+    PSD_ACC(7, t_f1, t_f2);
+  };
+
+  int nlog = 0;
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_n0);
     // every member evaluates the stopping test on the same data in the same order: the same decision everywhere
     double off = 0., tot = 0.;
     for (int e = tid; e < n * n; e += kPsdThreads) {
       const int i = e % n, j = e / n;
-      const double a = ld_agent(&A[i + (size_t)ld * j]);
+      const double a = ld_agent(&Acur[i + (size_t)ld * j]);
       tot += a * a;
       if (i != j) off += a * a;
     }
@@ -820,94 +950,73 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
     if (sweep >= kPsdLogSweeps) break;  // log full: the next round continues
 
     for (int r = 0; r < NB - 1; ++r) {
+      const bool ahead = la && r + 1 < NB - 1;
       for (int k = tid; k < H; k += kPsdThreads) {
         int p, q;
         rr_pair(r, k, NB, p, q);
-        if (k < kPsdMaxH) { osch[2 * k] = p; osch[2 * k + 1] = q; }
+        osch[2 * k] = p;
+        osch[2 * k + 1] = q;
+        if (la) { where[p] = 2 * k; where[q] = 2 * k + 1; }
+        if (ahead) {
+          rr_pair(r + 1, k, NB, p, q);
+          osch_n[2 * k] = p;
+          osch_n[2 * k + 1] = q;
+        }
       }
       __syncthreads();
       PSD_TICK(t_p0);
-      // ---------------- phase 1: pivot k on workgroup k % G, wave k / G ----------------
-      for (int k = g + G * wave; k < H; k += G * kPsdWaves) {
-        const int p = osch[2 * k], q = osch[2 * k + 1];
-        for (int e = lane; e < 256; e += 64) {
-          const int i = e & 15, j = e >> 4;
-          Sw[i + kPsdLd * j] = ld_agent(&A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)]);
-        }
-        wave_sync();
-        wave_jacobi16(Sw, Ww, lane);
-        double *Wk = Wlog + ((size_t)nlog * H + k) * kPsdWsz;
-        for (int e = lane; e < 256; e += 64) st_shared(&Wk[e], Ww[(e >> 4) + kPsdWLd * (e & 15)]);
-      }
-      __syncthreads();
-      PSD_TICK(t_p1);
-      gbar();
-      PSD_TICK(t_p2);
-      // ---------------- phase 2: A <- W' A W over block pairs k <= k2, 16 G wavefronts ----------------
-      // Two tasks per trip: the (L2-bypassing) loads of both are in flight together — the phase is one load latency
-      // deep instead of two at order 200 (91 tasks on 64 wavefronts).
-      for (int task0 = g + G * wave; task0 < nblk; task0 += 2 * G * kPsdWaves) {
-        int tk[2], tk2[2], trow[2], tp[2], tq[2], tp2[2], tq2[2];
-        bool live[2];
-        double av[2][4], w1[2][4], w2[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int task = task0 + u * G * kPsdWaves;
-          live[u] = task < nblk;
-          int k = 0, rem = live[u] ? task : 0;
-          while (rem >= H - k) { rem -= H - k; ++k; }
-          tk[u] = k;
-          tk2[u] = k + rem;
-          tp[u] = osch[2 * k]; tq[u] = osch[2 * k + 1]; tp2[u] = osch[2 * tk2[u]]; tq2[u] = osch[2 * tk2[u] + 1];
-          trow[u] = pq_index(li, tp[u], tq[u]);
-          if (live[u]) {
-            const double *W1 = Wlog + ((size_t)nlog * H + k) * kPsdWsz, *W2 = Wlog + ((size_t)nlog * H + tk2[u]) * kPsdWsz;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              av[u][kk] = ld_agent(&A[trow[u] + (size_t)ld * pq_index(4 * kk + lk, tp2[u], tq2[u])]);
-              w2[u][kk] = ld_agent(&W2[psd_log_at(4 * kk + lk, li)]);
-              w1[u][kk] = ld_agent(&W1[psd_log_at(4 * kk + lk, li)]);
-            }
+      if (!la || r == 0) {
+        // ---------------- pivots of this step from memory: pivot k on workgroup k % G, wave k / G ----------------
+        for (int k = g + G * wave; k < H; k += G * kPsdWaves) {
+          const int p = osch[2 * k], q = osch[2 * k + 1];
+          for (int e = lane; e < 256; e += 64) {
+            const int i = e & 15, j = e >> 4;
+            Sw[i + kPsdLd * j] = ld_agent(&Acur[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)]);
           }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (!live[u]) break;
-          f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][kk], w2[u][kk], T, 0, 0, 0);
-          f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[u][t], T[t], Rr, 0, 0, 0);
-          const int gi = pq_index(li, tp2[u], tq2[u]);
-          if (tk[u] != tk2[u]) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) st_shared(&A[gi + (size_t)ld * pq_index(lk + 4 * t, tp[u], tq[u])], Rr[t]);
-          }
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = Rr[t];
           wave_sync();
-#pragma unroll
-          for (int t = 0; t < 4; ++t) st_shared(&A[trow[u] + (size_t)ld * pq_index(lk + 4 * t, tp2[u], tq2[u])], Sw[li + 17 * (lk + 4 * t)]);
-          wave_sync();
+          wave_jacobi16(Sw, Ww, lane);
+          log_w(nlog, k);
         }
+#if PSD_PROFILE
+        __syncthreads();
+#endif
+        PSD_TICK(t_p1);
+        gbar();
+        PSD_TICK(t_p2);
+        PSD_ACC(2, t_p0, t_p1);
+        PSD_ACC(3, t_p1, t_p2);
       }
-      __syncthreads();
       PSD_TICK(t_p3);
-      gbar();
+      // ---------------- A_{t+1} = W' A_t W over block pairs k <= k2 (and, ahead, the next step's pivots) ----------------
+      if (ahead && pivot_wave) {
+        // the pivot chain is the critical path of the step: its instructions go first on the SIMD it shares with three workers
+        __builtin_amdgcn_s_setprio(3);
+        pivot_ahead(g + G * wave, nlog);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        run_tasks(ahead ? wid : g + G * wave, ahead ? nworkers : G * kPsdWaves, nlog);
+      }
+#if PSD_PROFILE
+      __syncthreads();
+#endif
       PSD_TICK(t_p4);
-      PSD_ACC(2, t_p0, t_p1);
-      PSD_ACC(3, t_p1, t_p2);
-      PSD_ACC(4, t_p2, t_p3);
-      PSD_ACC(5, t_p3, t_p4);
+      gbar();
+      PSD_TICK(t_p5);
+      PSD_ACC(4, t_p3, t_p4);
+      PSD_ACC(5, t_p4, t_p5);
+      if (la) { double *t = Acur; Acur = Anxt; Anxt = t; }
       ++nlog;
     }
+  }
+  if (Acur != A) {  // an odd number of steps: the matrix goes home (the later kernels read A)
+    for (size_t e = (size_t)g * kPsdThreads + tid; e < (size_t)NP * NP; e += (size_t)G * kPsdThreads) A[e] = ld_agent(&Acur[e]);
   }
   if (g == 0 && tid == 0) state[2] = (double)nlog;
 #if PSD_PROFILE
   if (cidx == 0 && tid == 0 && nlog > 0)
-    printf("  mc member %d round %d: %d steps; per step (us): norms %.2f  pivots %.2f  barrier %.2f  A tasks %.2f  barrier %.2f\n", g, round, nlog,
-           prof[1] / 100 / nlog, prof[2] / 100 / nlog, prof[3] / 100 / nlog, prof[4] / 100 / nlog, prof[5] / 100 / nlog);
+    printf("  mc member %d round %d: %d steps; per step (us): norms %.2f  pivots(mem) %.2f  barrier %.2f  tasks %.2f  barrier %.2f\n", g, round,
+           nlog, prof[1] / 100 / nlog, prof[2] / 100 / nlog, prof[3] / 100 / nlog, prof[4] / 100 / nlog, prof[5] / 100 / nlog),
+    printf("      pivot ahead (wave 0): feeder tasks %.2f  solve %.2f us per step\n", prof[6] / 100 / nlog, prof[7] / 100 / nlog);
 #endif
 }
 

@@ -526,13 +526,14 @@ struct ScsHipWork {
             int G = mc, rnd = round;
             int *err = fl.p + F_PERSIST_ERR;
             const int *st = stall;
-            void *args[] = {&B, &scr, &rnd, &G, &err, &st};
+            int la = psd_mc_look_ahead;
+            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st};
             if (psd_mc_coop)
               HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
-                                                   dim3(kPsdThreads), args, (unsigned)kPsdLdsBytes, stream));
+                                                   dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream));
             else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
-              hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdLdsBytes, stream, B, scr, rnd, G,
-                                 err, st);
+              hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
+                                 la, err, st);
           } else
           hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
@@ -552,6 +553,7 @@ struct ScsHipWork {
   // Members (CUs) per matrix for the split-mode sweeps: as many as fit when every matrix gets the same number and a
   // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
   // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
+  int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
   bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return !(e && e[0] == '0'); }();
   int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
   int psd_mc_members(int big) {
@@ -559,7 +561,7 @@ struct ScsHipWork {
       int coop = 0, per_cu = 0, cus = 0;
       (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_psd_sweep_mc), kPsdThreads, kPsdLdsBytes) != hipSuccess)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_psd_sweep_mc), kPsdThreads, kPsdMcLdsBytes) != hipSuccess)
         per_cu = 0;
       psd_mc_cap = coop ? std::min(per_cu, 1) * cus : 0;  // one member per CU: the pivot solves want a SIMD each
     }

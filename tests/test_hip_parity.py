@@ -513,13 +513,14 @@ def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
 
 
 # ---- K9 split mode, sweeps of one matrix spread over G CUs (k_psd_sweep_mc) vs the one-workgroup sweep kernel ----
-@pytest.mark.parametrize("coop", ["1", "0"])
-def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coop):
+@pytest.mark.parametrize("coop,look_ahead", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coop, look_ahead):
     """Same rotations, same MFMA sequences, spinning barriers between the members of a matrix's group: every bit of the
     projection — and of a whole solve with warm starts, re-orthogonalisation and several [sweep, apply] rounds — must
     be the one the single-workgroup sweeps give.  G = 3 leaves members without a pivot at order 40; G = 8 is the cap."""
     monkeypatch.setenv("SCS_HIP_PSD_SPLIT", "1")
     monkeypatch.setenv("SCS_HIP_PSD_COOP", coop)  # 0: ordinary launch (profilers)
+    monkeypatch.setenv("SCS_HIP_PSD_LA", look_ahead)  # 1: one barrier per step, the next pivots solved beside the A tasks (A double-buffered)
     rng = np.random.RandomState(12)
     K = {"l": 5, "s": [200, 130, 40, 96, 64, 33, 177, 50, 150], "cs": [60, 20]}
     z = rng.randn(pg.cone_dims(K))

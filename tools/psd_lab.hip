@@ -67,12 +67,13 @@ int main(int argc, char **argv) {
         if (mc >= 2) {
           int G = mc, rnd = round;
           const int *st = nullptr;
-          void *args[] = {&B, &d_scr, &rnd, &G, &d_err, &st};
+          int la = getenv("PSD_LAB_LA0") ? 0 : 1;  // look-ahead (one barrier per step)
+          void *args[] = {&B, &d_scr, &rnd, &G, &la, &d_err, &st};
           if (getenv("PSD_LAB_PLAIN"))  // ordinary launch (e.g. under rocprofv3)
-            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdLdsBytes, 0, B, d_scr, rnd, G, d_err, st);
+            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdMcLdsBytes, 0, B, d_scr, rnd, G, la, d_err, st);
           else
           HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads),
-                                               args, (unsigned)kPsdLdsBytes, 0));
+                                               args, (unsigned)kPsdMcLdsBytes, 0));
         } else
         hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
         hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);

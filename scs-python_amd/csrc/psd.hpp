@@ -130,23 +130,30 @@ __device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, d
   s = t * y;
 }
 
-// One wavefront improves the symmetric 16x16 pivot S (LDS, column-major) by up to kPsdInnerSweeps
-// cyclic Jacobi sweeps, W <- accumulated rotations (LDS).
+// One wavefront works on the symmetric 16x16 pivot S = [[App, Apq], [Aqp, Aqq]] (LDS, column-major), W <- accumulated
+// rotations (LDS).  Which pairs: the 64 CROSS pairs (i in block p, j in block q) in 8 rounds of 8 disjoint rotations
+// (i, 8 + (i + r) mod 8) — and, in the first outer step of a sweep (`intra`), the 2 x 28 pairs INSIDE the two diagonal
+// blocks first (7 rounds: a round-robin on 8 indices in each block).  Every block sits in exactly one pivot of outer step
+// 0, so one outer sweep rotates every index pair of the matrix exactly once: a cyclic Jacobi method in block order.
+// (Round 1 ran a full cyclic sweep of the 16x16 pivot — 15 rounds, the intra-block pairs of every block rotated again in
+// each of its NB - 1 pivots.  Same number of outer sweeps to 1e-8 in tools/dbg/block_jacobi_model.py — cold 7 = 7,
+// warm 3 = 3 and 2 = 2 — at 8 instead of 15 rounds per pivot: the pivot solve is the critical path of K9.)
 // Lane (k = lane&7, k2 = lane>>3) owns the 2x2 block rows{p,q} x cols{p2,q2} of the round's pairs k and k2; the
-// round-robin schedule is computed arithmetically (no table look-up in front of the dependent LDS reads).
+// schedule is computed arithmetically (no table look-up in front of the dependent LDS reads).
 // A round is ONE LDS round trip: every lane reads the three entries that define the rotations of both its
 // pairs (the 8 lanes sharing a pair compute the same (c,s) redundantly — no exchange, no second barrier),
 // its 2x2 block of S and its two rows of W, rotates, writes back.
 constexpr int kPsdInnerSweeps = PSD_INNER;
-__device__ __forceinline__ void rr16(int r, int k, int &p, int &q) {  // rr_pair(r, k, 16) without divisions
-  int a = r + k, b = r - k + 15;
-  a = a >= 15 ? a - 15 : a;
-  b = b >= 15 ? b - 15 : b;
-  if (k == 0) { a = 15; b = r; }
-  p = min(a, b);
-  q = max(a, b);
+__device__ __forceinline__ void intra8(int r, int k, int &p, int &q) {  // round r < 7 of the round-robin inside both 8-blocks
+  const int kb = k & 3, base = (k >> 2) * 8;
+  int a = r + kb, b = r - kb + 7;
+  a = a >= 7 ? a - 7 : a;
+  b = b >= 7 ? b - 7 : b;
+  if (kb == 0) { a = 7; b = r; }
+  p = base + min(a, b);
+  q = base + max(a, b);
 }
-__device__ inline void wave_jacobi16(double *S, double *W, int lane) {
+__device__ inline void wave_jacobi16(double *S, double *W, int lane, bool intra) {
   for (int e = lane; e < 256; e += 64) W[(e & 15) + kPsdWLd * (e >> 4)] = ((e & 15) == (e >> 4)) ? 1. : 0.;
   wave_sync();
   const int i0 = lane >> 3, i1 = i0 + 8;  // the two rows of W this lane rotates (columns p,q of its pair k)
@@ -162,10 +169,17 @@ __device__ inline void wave_jacobi16(double *S, double *W, int lane) {
     off = __shfl(off, 0, 64);
     tot = __shfl(tot, 0, 64);
     if (off <= 1e-26 * tot || off == 0.) break;  // (16 eps)^2 ~ 1e-29 is the rounding floor
-    for (int r = 0; r < 15; ++r) {
+    for (int rr = intra ? 0 : 7; rr < 15; ++rr) {
       int p, q, p2, q2;
-      rr16(r, lane & 7, p, q);
-      rr16(r, lane >> 3, p2, q2);
+      if (rr < 7) {  // inside the diagonal blocks
+        intra8(rr, lane & 7, p, q);
+        intra8(rr, lane >> 3, p2, q2);
+      } else {       // block p against block q
+        p = lane & 7;
+        q = 8 + ((p + rr - 7) & 7);
+        p2 = lane >> 3;
+        q2 = 8 + ((p2 + rr - 7) & 7);
+      }
       const double dpp = S[p + kPsdLd * p], dqq = S[q + kPsdLd * q], dpq = S[p + kPsdLd * q];
       const double app = S[p + kPsdLd * p2], apq = S[p + kPsdLd * q2], aqp = S[q + kPsdLd * p2], aqq = S[q + kPsdLd * q2];
       const double wp0 = W[i0 + kPsdWLd * p], wq0 = W[i0 + kPsdWLd * q], wp1 = W[i1 + kPsdWLd * p], wq1 = W[i1 + kPsdWLd * q];
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
           Sw[i + kPsdLd * j] = A[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)];
         }
         wave_sync();
-        wave_jacobi16(Sw, Ww, lane);
+        wave_jacobi16(Sw, Ww, lane, r == 0);
         if (!w_in_lds)
           for (int e = lane; e < kPsdWsz; e += 64) Wg[(size_t)k * kPsdWsz + e] = Ww[e];
         if (MODE == 1)
@@ -917,7 +931,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
     }
     wave_sync();
     PSD_TICK(t_f1);
-    wave_jacobi16(Sw, Ww, lane);
+    wave_jacobi16(Sw, Ww, lane, false);  // step + 1 is never the first step of a sweep
     PSD_TICK(t_f2);
     log_w(step + 1, kn);
     PSD_ACC(6, t_f0, t_f1);
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
             Sw[i + kPsdLd * j] = ld_agent(&Acur[pq_index(i, p, q) + (size_t)ld * pq_index(j, p, q)]);
           }
           wave_sync();
-          wave_jacobi16(Sw, Ww, lane);
+          wave_jacobi16(Sw, Ww, lane, r == 0);
           log_w(nlog, k);
         }
 #if PSD_PROFILE

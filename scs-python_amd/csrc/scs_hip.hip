@@ -519,7 +519,7 @@ struct ScsHipWork {
         hipLaunchKernelGGL(k_proj_psd<2>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-        const int mc = in_capture ? 1 : psd_mc_members(big);
+        int mc = in_capture ? 1 : psd_mc_members(big);
         for (int round = 0; round < kPsdSplitRounds; ++round) {
           if (mc > 1) {  // sweeps of one matrix over `mc` CUs (k_psd_sweep_mc): cooperative launch, spinning barriers
             double *scr = psd_scratch.p;
@@ -528,13 +528,20 @@ struct ScsHipWork {
             const int *st = stall;
             int la = psd_mc_look_ahead;
             void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st};
-            if (psd_mc_coop)
-              HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
-                                                   dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream));
-            else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
+            if (psd_mc_coop) {
+              const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
+                                                             dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream);
+              if (e != hipSuccess) {  // the runtime cannot co-schedule the grid (it only refuses the FIRST round: nothing ran yet)
+                (void)hipGetLastError();
+                if (round > 0) HIP_CHECK(e);
+                psd_mc_cap = 0;  // from now on: one workgroup per matrix
+                mc = 1;
+              }
+            } else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
               hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
                                  la, err, st);
-          } else
+          }
+          if (mc <= 1)
           hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
@@ -572,7 +579,7 @@ struct ScsHipWork {
     int G = std::min(std::min(psd_mc_cap / groups, kPsdMcMaxG), pivots / 3);
     if (const char *env = getenv("SCS_HIP_PSD_MC")) {
       G = atoi(env);
-      if (G > kPsdMcMaxG || (long)G * groups > (long)psd_mc_cap) G = 1;
+      if (G > kPsdMcMaxG || ((long)G * groups > (long)psd_mc_cap && !getenv("SCS_HIP_PSD_MC_NOCHECK"))) G = 1;  // (NOCHECK: tests of the refused launch)
     }
     return std::max(G, 1);
   }

@@ -550,6 +550,20 @@ def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coo
         np.testing.assert_array_equal(sols["1"][key], sols["4"][key], err_msg=key)
 
 
+def test_psd_refused_cooperative_launch_falls_back(hip, monkeypatch):
+    """A grid the runtime cannot co-schedule (320 workgroups of 1024 lanes on 256 CUs): hipLaunchCooperativeKernel refuses it,
+    nothing has run, and the projection is done by the one-workgroup sweeps — same bits, no error."""
+    monkeypatch.setenv("SCS_HIP_PSD_SPLIT", "1")
+    rng = np.random.RandomState(3)
+    K = {"l": 2, "s": [40] * 40}
+    z = rng.randn(pg.cone_dims(K))
+    monkeypatch.setenv("SCS_HIP_PSD_MC", "1")
+    ref = hip.proj_cone(z, K)
+    monkeypatch.setenv("SCS_HIP_PSD_MC", "8")
+    monkeypatch.setenv("SCS_HIP_PSD_MC_NOCHECK", "1")
+    np.testing.assert_array_equal(hip.proj_cone(z, K), ref)
+
+
 # ---- run-ahead ADMM loop (whole iterations enqueued ahead of the host) vs one host look per iteration ----
 @pytest.mark.parametrize("case", ["lp_soc", "qp_mixed", "sdp", "long_cg"])
 def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):

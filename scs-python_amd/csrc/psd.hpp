@@ -1037,10 +1037,13 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
 #endif
 }
 
-// Split mode, V <- V W_1 W_2 ... : one 256-lane workgroup per (matrix, 16-row strip of V).  The strip lives in LDS
+// Split mode, V <- V W_1 W_2 ... : one 512-lane workgroup per (matrix, 16-row strip of V).  The strip lives in LDS
 // (16 x NP doubles); step t rotates, for every pivot (p,q) of that step, the strip's 16 columns {block p, block q}
 // by the logged 16x16 W — 4 MFMAs per pivot, the same instruction sequence as the in-kernel V tasks of MODE 0.
-constexpr int kPsdApplyThreads = 256;
+#ifndef PSD_APPLY_THREADS
+#define PSD_APPLY_THREADS 512  // 8 wavefronts share the 13 pivots of a step (tools/dbg/psd_apply_threads.sh: 257 us per round at 256 lanes, 212 at 512, 217 at 1024)
+#endif
+constexpr int kPsdApplyThreads = PSD_APPLY_THREADS;
 __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, double *scratch, const int *stall) {
   SCS_STALL_GUARD(stall);
   extern __shared__ __attribute__((aligned(16))) double strip[];  // [row + 16 * col]

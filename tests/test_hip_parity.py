@@ -403,6 +403,48 @@ def test_psd_large_orders_warm_path_in_solve(hip, monkeypatch, orders, split):
         o += d
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_psd_projection_special_spectra(hip, monkeypatch, split):
+    """The block Jacobi (cross-pair pivots, intra-block pairs once per sweep) on spectra that stress a Jacobi method: multiple and
+    clustered eigenvalues, low rank, already diagonal, zero, identity multiples, tiny and huge scales, one order per kernel family
+    (one wavefront <= 32 < block kernel; 200 = config 4).  Checked against numpy's eigensolver."""
+    monkeypatch.setenv("SCS_HIP_PSD_SPLIT", split)
+    rng = np.random.RandomState(5)
+
+    def sym_with(eigs):
+        k = len(eigs)
+        Q, _ = np.linalg.qr(rng.randn(k, k))
+        return (Q * np.asarray(eigs)) @ Q.T
+
+    mats = []
+    for k in (7, 32, 33, 48, 100, 200):
+        mats += [
+            sym_with(np.r_[np.ones(k // 2), -np.ones(k - k // 2)]),                      # two eigenvalues, both highly multiple
+            sym_with(np.r_[rng.rand(3) + 1, np.zeros(k - 3)]),                           # rank 3, PSD already
+            sym_with(np.r_[-(rng.rand(3) + 1), np.zeros(k - 3)]),                        # rank 3, NSD: projection is 0
+            sym_with(1.0 + 1e-9 * rng.randn(k)),                                          # cluster at 1
+            sym_with(1e-7 * rng.randn(k)),                                                # cluster around 0, both signs
+            np.diag(rng.randn(k)),                                                        # diagonal
+            np.zeros((k, k)),
+            -3.0 * np.eye(k),
+            1e-12 * sym_with(rng.randn(k)),                                               # tiny scale
+            1e9 * sym_with(rng.randn(k)),                                                 # huge scale
+            sym_with(np.sign(rng.randn(k)) * 10.0 ** rng.uniform(-6, 2, k)),              # eight decades
+        ]
+    K = {"s": [M.shape[0] for M in mats]}
+    z = np.concatenate([helpers.sym_to_svec(M) for M in mats])
+    got = hip.proj_cone(z, K)
+    o = 0
+    for M in mats:
+        k = M.shape[0]
+        d = k * (k + 1) // 2
+        w, V = np.linalg.eigh(M)
+        want = helpers.sym_to_svec((V * np.maximum(w, 0)) @ V.T)
+        scale = max(np.abs(M).max(), 1e-300)
+        np.testing.assert_allclose(got[o:o + d], want, rtol=0, atol=2e-11 * k * scale, err_msg="order %d" % k)
+        o += d
+
+
 # ---- complex PSD cone `cs` (SURVEY §8 f3) ---------------------------------------------------------------------
 @pytest.mark.parametrize("orders", [[1], [2], [3], [5, 4], [8, 1, 0, 13], [40], [100]])
 def test_cs_projection_vs_oracle_and_complex_eigh(hip, oracle, orders):

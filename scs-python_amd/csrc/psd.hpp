@@ -435,9 +435,11 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int li = lane & 15, lk = lane >> 4;
   const int nblk = H * (H + 1) / 2, ntile = NP / 16;
+  if (MODE == 3 && !reorth) return;  // k_psd_front did the unpacking and V': only the periodic re-orthogonalisation is left here
 
   if (!resumed) {
   // ---- unpack (lower tri, col-major, off-diag / sqrt2), zero padding; V = I when cold; inner schedule ----
+  if (MODE != 3) {
   for (int e = tid; e < NP * NP; e += kPsdThreads) {
     const int i = e % NP, j = e / NP;
     A[e] = 0.;
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
     A[j + (size_t)ld * i] = v;
   }
   __syncthreads();
+  }  // MODE != 3
 
   PSD_TICK(t_unpacked);
   PSD_ACC(1, t_begin, t_unpacked);
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       for (int e = tid; e < NP * NP; e += kPsdThreads) Vt[e] = Tm[e];
       __syncthreads();
     }
-    if (MODE != 2) {
+    if (MODE != 2 && MODE != 3) {
       for (int task = wave; task < ntile * ngrp; task += kPsdWaves) psd_task_g1(task, NP, A, Vt, Tm, Sw, li, lk);
       __syncthreads();
       for (int task = wave; task < ntile * ngrp; task += kPsdWaves) psd_task_g2(task, NP, A, Vt, Tm, Sw, li, lk);
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
   }  // !resumed
+  if (MODE == 3) return;
   if (MODE == 2) {
     if (tid == 0) state[3] = state[4] = state[5] = state[6] = 0.;  // barrier counters of k_psd_sweep_mc, one per round
     return;
@@ -717,6 +721,56 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   if (tid == 0)
     for (int i = 1; i < 8; ++i) state[i] = prof[i];
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Split mode, front on many CUs: unpack the packed vector into A (one pass: every entry of the padded square is computed
+// from the packed lower triangle, the same value for both triangles), V = I on a cold start, V' for the warm-start GEMMs,
+// the barrier counters of k_psd_sweep_mc.  One workgroup per matrix (MODE 2) needed 65 us at 50 x order 200 on 50 CUs.
+// The periodic re-orthogonalisation of V stays with the one-workgroup kernel (MODE 3, which returns at once otherwise):
+// on those calls V' is formed there, after V has changed.
+// ---------------------------------------------------------------------------
+constexpr int kPsdFrontThreads = 256;
+__global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+  SCS_STALL_GUARD(stall);
+  __shared__ double Sws[kPsdFrontThreads / 64][16 * 17];
+  const int cidx = blockIdx.y;
+  const int n = B.order[cidx];
+  if (n < 2) return;  // orders 0 and 1: the MODE 3 launch behind this one
+  const double *X = x + B.off[cidx];
+  const int NP = (int)psd_np(n), H = NP / kPsdB / 2, ld = NP, ntile = NP / 16;
+  double *A = scratch + B.woff[cidx];
+  double *V = A + (size_t)NP * NP;
+  double *Vt = V + 2 * (size_t)NP * NP;
+  double *state = Vt + (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n) + NP;
+  const bool warm = allow_warm && state[0] >= 1.;
+  const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const double isq2 = 0.70710678118654752440;
+  for (long e = (long)blockIdx.x * kPsdFrontThreads + tid; e < (long)NP * NP; e += (long)gridDim.x * kPsdFrontThreads) {
+    const int i = (int)(e % NP), j = (int)(e / NP);
+    double v = 0.;
+    if (i < n && j < n) {
+      const int lo = min(i, j), hi = max(i, j);  // packed column lo, row hi
+      v = X[(long)lo * n - (long)lo * (lo - 1) / 2 + (hi - lo)];
+      if (i != j) v *= isq2;
+    }
+    A[e] = v;
+    if (!warm) V[e] = (i == j) ? 1. : 0.;
+  }
+  if (warm && !reorth) {
+    double *Sw = Sws[wave];
+    for (int tile = blockIdx.x * (kPsdFrontThreads / 64) + wave; tile < ntile * ntile; tile += gridDim.x * (kPsdFrontThreads / 64)) {
+      const int ti = tile % ntile, tj = tile / ntile;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Sw[li + 17 * (lk + 4 * t)] = V[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)];
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Vt[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = Sw[(lk + 4 * t) + 17 * li];
+      wave_sync();
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) state[3] = state[4] = state[5] = state[6] = 0.;  // barrier counters of k_psd_sweep_mc
 }
 
 // ---------------------------------------------------------------------------

@@ -516,7 +516,10 @@ struct ScsHipWork {
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
         const dim3 gg((unsigned)((psd_max_tiles * ((psd_max_tiles + kPsdNJ - 1) / kPsdNJ) + 3) / 4), (unsigned)big), gb(kPsdGemmThreads);
-        hipLaunchKernelGGL(k_proj_psd<2>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
+        // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
+        hipLaunchKernelGGL(k_psd_front, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(kPsdFrontThreads), 0, stream,
+                           (const double *)base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         int mc = in_capture ? 1 : psd_mc_members(big);

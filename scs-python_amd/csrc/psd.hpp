@@ -308,12 +308,15 @@ __device__ __forceinline__ void psd_task_g2(int task, int NP, double *A, const d
   }
 }
 // R1: T = V F  (F symmetric, formed on the fly from the diagonalised A and lam = its diagonal)
+// (FMAP = false: `A` is F itself, formed once by k_psd_fmap — the split pipeline; the divided differences cost a division each and
+// every element of F is an operand of NP / 16 row tiles)
+template <bool FMAP = true>
 __device__ __forceinline__ void psd_task_r1(int task, int NP, const double *A, const double *V, double *Tm, const double *lam,
                                             double *Sw, int li, int lk) {
   const int ld = NP, ntile = NP / 16;
   const int ti = task % ntile, tj0 = (task / ntile) * kPsdNJ;
   f64x4 acc[kPsdNJ];
-  mma_row<true>(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc, lam);
+  mma_row<FMAP>(V, A, ld, NP, ti, tj0, ntile - 1, li, lk, acc, lam);
 #pragma unroll
   for (int j = 0; j < kPsdNJ; ++j) {
     const int tj = tj0 + j;
@@ -1138,6 +1141,22 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, do
   for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)] = strip[e];
 }
 
+// Split mode: F = Pi_+(D + E) of the nearly diagonal A (psd_fmap, see the reconstruction) once, element by element, into the
+// buffer of V' (free after the warm-start GEMMs) — the B operand of the R1 GEMM.
+__global__ __launch_bounds__(256) void k_psd_fmap(PsdBatch B, double *scratch, const int *stall) {
+  SCS_STALL_GUARD(stall);
+  const int n = B.order[blockIdx.y];
+  if (n < 2) return;
+  const int NP = (int)psd_np(n), ld = NP;
+  const double *A = scratch + B.woff[blockIdx.y];
+  double *F = scratch + B.woff[blockIdx.y] + 3 * (size_t)NP * NP;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)NP * NP; e += (long)gridDim.x * 256) {
+    const int r = (int)(e % NP), k = (int)(e / NP);
+    const double dj = r < n ? A[r + (size_t)ld * r] : 0., dk = k < n ? A[k + (size_t)ld * k] : 0.;
+    F[e] = psd_fmap(A[e], dj, dk, r == k);
+  }
+}
+
 // Split mode: the four GEMM phases as multi-workgroup launches — grid (workgroups per matrix, matrices), 4 wavefronts per
 // workgroup, wave-level tasks of psd_task_* (one row tile x up to 4 column tiles each).
 enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2 };
@@ -1160,14 +1179,10 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
   if ((KIND == PSD_G1 || KIND == PSD_G2) && !warm) return;  // cold start: A0 = A
   const int ntask = ntile * ((ntile + kPsdNJ - 1) / kPsdNJ);
   double *Sw = Sws[wave];
-  if (KIND == PSD_R1) {  // eigenvalue estimates: every workgroup of the matrix writes the same values
-    for (int j = tid; j < NP; j += kPsdGemmThreads) lam[j] = (j < n) ? A[j + (size_t)ld * j] : 0.;
-    __syncthreads();
-  }
   for (int task = blockIdx.x * (kPsdGemmThreads / 64) + wave; task < ntask; task += gridDim.x * (kPsdGemmThreads / 64)) {
     if (KIND == PSD_G1) psd_task_g1(task, NP, A, Vt, Tm, Sw, li, lk);
     else if (KIND == PSD_G2) psd_task_g2(task, NP, A, Vt, Tm, Sw, li, lk);
-    else if (KIND == PSD_R1) psd_task_r1(task, NP, A, V, Tm, lam, Sw, li, lk);
+    else if (KIND == PSD_R1) psd_task_r1<false>(task, NP, Vt, V, Tm, lam, Sw, li, lk);  // Vt holds F (k_psd_fmap)
     else psd_task_r2(task, n, NP, Tm, V, x + B.off[blockIdx.y], li, lk);
   }
   if (KIND == PSD_R2 && blockIdx.x == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;

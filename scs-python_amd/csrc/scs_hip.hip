@@ -549,6 +549,7 @@ struct ScsHipWork {
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
         }
+        hipLaunchKernelGGL(k_psd_fmap, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(256), 0, stream, B, psd_scratch.p, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
       } else {

@@ -79,6 +79,7 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
         hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
+      hipLaunchKernelGGL(k_psd_fmap, dim3(ntile, cnt), dim3(256), 0, 0, B, d_scr, (const int *)nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
     } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);

@@ -1158,9 +1158,22 @@ __global__ __launch_bounds__(256) void k_psd_fmap(PsdBatch B, double *scratch, c
 }
 
 // Split mode: the four GEMM phases as multi-workgroup launches — grid (workgroups per matrix, matrices), 4 wavefronts per
-// workgroup, wave-level tasks of psd_task_* (one row tile x up to 4 column tiles each).
+// workgroup.  A wavefront's task is a block of kPsdRT row tiles x kPsdNJ column tiles: the operand fetches, not the matrix
+// cores, bound these launches (every k-step of one row tile x 4 column tiles issues 5 loads for 4 MFMAs and the texture
+// addresser takes ~35 clocks per load instruction against 16 clocks per MFMA and CU), so two row tiles share the four
+// B operands — 6 loads for 8 MFMAs — and the k-steps are software-pipelined (four in flight).  Measured at 50 x order 200
+// (tools/dbg/psd_gemm_threads.sh): 44 us per launch with 1 x 4 tiles and no pipeline, 53 us with 2 x 4 tiles alone (fewer
+// wavefronts, every k-step one L2 round trip), 38 us with both; the workgroup size (64 / 128 / 256 lanes) does not matter.
+// Every output tile still accumulates its k-steps in order: the bits of psd_task_*.
 enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2 };
-constexpr int kPsdGemmThreads = 256;
+#ifndef PSD_GEMM_THREADS
+#define PSD_GEMM_THREADS 128
+#endif
+constexpr int kPsdGemmThreads = PSD_GEMM_THREADS;
+constexpr int kPsdRT = 2;
+constexpr int kPsdPf = 4;  // k-steps in flight
+__host__ __device__ inline int psd_gemm_tasks(int ntile) { return ((ntile + kPsdRT - 1) / kPsdRT) * ((ntile + kPsdNJ - 1) / kPsdNJ); }
+__host__ inline unsigned psd_gemm_wgs(int max_tiles) { return (unsigned)((psd_gemm_tasks(max_tiles) + kPsdGemmThreads / 64 - 1) / (kPsdGemmThreads / 64)); }
 template <int KIND>
 __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
   SCS_STALL_GUARD(stall);
@@ -1171,19 +1184,105 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
   double *A = scratch + B.woff[blockIdx.y];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;
-  double *Vt = Tm + (size_t)NP * NP;
-  double *lam = Vt + (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n);
-  double *state = lam + NP;
+  double *Vt = Tm + (size_t)NP * NP;  // V' for G1 / G2; F = Pi_+(D + E) (k_psd_fmap) for R1
+  double *state = Vt + (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n) + NP;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const bool warm = allow_warm && state[0] >= 1.;
   if ((KIND == PSD_G1 || KIND == PSD_G2) && !warm) return;  // cold start: A0 = A
-  const int ntask = ntile * ((ntile + kPsdNJ - 1) / kPsdNJ);
+  constexpr bool lower = KIND == PSD_G2 || KIND == PSD_R2;   // symmetric results: tiles on and below the diagonal only
+  // C[i][j] = sum_k Aop[i][k] Bop[j][k]:  G1 Tt = Vt A (A symmetric)   G2 A0 = Vt Tt'   R1 T = V F   R2 X+ = T V'
+  const double *Aop = KIND == PSD_G1 || KIND == PSD_G2 ? Vt : KIND == PSD_R1 ? V : Tm;
+  const double *Bop = KIND == PSD_G1 ? A : KIND == PSD_G2 ? Tm : KIND == PSD_R1 ? Vt : V;
+  double *X = x + B.off[blockIdx.y];
+  const double sq2 = 1.41421356237309504880;
+  const int ntr = (ntile + kPsdRT - 1) / kPsdRT, ntask = psd_gemm_tasks(ntile);
   double *Sw = Sws[wave];
   for (int task = blockIdx.x * (kPsdGemmThreads / 64) + wave; task < ntask; task += gridDim.x * (kPsdGemmThreads / 64)) {
-    if (KIND == PSD_G1) psd_task_g1(task, NP, A, Vt, Tm, Sw, li, lk);
-    else if (KIND == PSD_G2) psd_task_g2(task, NP, A, Vt, Tm, Sw, li, lk);
-    else if (KIND == PSD_R1) psd_task_r1<false>(task, NP, Vt, V, Tm, lam, Sw, li, lk);  // Vt holds F (k_psd_fmap)
-    else psd_task_r2(task, n, NP, Tm, V, x + B.off[blockIdx.y], li, lk);
+    const int ti0 = (task % ntr) * kPsdRT, tj0 = (task / ntr) * kPsdNJ;
+    const int tilast = min(ti0 + kPsdRT - 1, ntile - 1);
+    if (lower && tj0 > tilast) continue;
+    const int tjmax = lower ? tilast : ntile - 1;  // tiles beyond it are computed on a clamped tile and ignored
+    const double *pa[kPsdRT], *pb[kPsdNJ];
+    f64x4 acc[kPsdRT][kPsdNJ];
+#pragma unroll
+    for (int r = 0; r < kPsdRT; ++r) pa[r] = Aop + (min(ti0 + r, ntile - 1) * 16 + li) + (size_t)ld * lk;
+#pragma unroll
+    for (int j = 0; j < kPsdNJ; ++j) {
+      pb[j] = Bop + (min(tj0 + j, tjmax) * 16 + li) + (size_t)ld * lk;
+#pragma unroll
+      for (int r = 0; r < kPsdRT; ++r) acc[r][j] = f64x4{0., 0., 0., 0.};
+    }
+    // Software pipeline over the k-steps: the operands of kPsdPf steps are in flight while the MFMAs of the oldest run.  Every
+    // load is unconditional (the last stages re-fetch the final step: a conditional load in this loop makes hipcc fall back to
+    // s_waitcnt vmcnt(0) and the steps serialise on the L2 latency — 52 round trips per task at order 200).
+    double as[kPsdPf][kPsdRT], bs[kPsdPf][kPsdNJ];
+    auto fetch = [&](int st, int k0) {
+#pragma unroll
+      for (int r = 0; r < kPsdRT; ++r) as[st][r] = pa[r][(size_t)ld * k0];
+#pragma unroll
+      for (int j = 0; j < kPsdNJ; ++j) bs[st][j] = pb[j][(size_t)ld * k0];
+    };
+#pragma unroll
+    for (int st = 0; st < kPsdPf; ++st) fetch(st, 4 * st);  // NP >= 16 and NP / 4 is a multiple of kPsdPf = 4
+    for (int k0 = 0; k0 < NP; k0 += 4 * kPsdPf) {
+#pragma unroll
+      for (int st = 0; st < kPsdPf; ++st) {
+        double a[kPsdRT], b[kPsdNJ];
+#pragma unroll
+        for (int r = 0; r < kPsdRT; ++r) a[r] = as[st][r];
+#pragma unroll
+        for (int j = 0; j < kPsdNJ; ++j) b[j] = bs[st][j];
+        fetch(st, min(k0 + 4 * st + 4 * kPsdPf, NP - 4));
+#pragma unroll
+        for (int r = 0; r < kPsdRT; ++r)
+#pragma unroll
+          for (int j = 0; j < kPsdNJ; ++j) acc[r][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[j], acc[r][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kPsdRT; ++r) {
+      const int ti = ti0 + r;
+      if (ti >= ntile) break;
+#pragma unroll
+      for (int j = 0; j < kPsdNJ; ++j) {
+        const int tj = tj0 + j;
+        if (tj >= ntile || (lower && tj > ti)) break;
+        const f64x4 c = acc[r][j];  // lane holds C[row = lk + 4t][col = li] of tile (ti, tj)
+        if (KIND == PSD_G1 || KIND == PSD_R1) {  // stored through the 16x17 transpose: li runs down the columns of the result
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
+          wave_sync();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+          wave_sync();
+        } else if (KIND == PSD_G2) {  // mirrored; diagonal tiles symmetrised (average of the two triangles): A0 exactly symmetric
+          if (ti != tj) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
+          wave_sync();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int rr = li, cc = lk + 4 * t;
+            double v = Sw[rr + 17 * cc];
+            if (ti == tj && rr != cc) v = 0.5 * ((rr > cc ? v : Sw[cc + 17 * rr]) + (rr > cc ? Sw[cc + 17 * rr] : v));
+            A[(ti * 16 + rr) + (size_t)ld * (tj * 16 + cc)] = v;
+          }
+          wave_sync();
+        } else {  // R2: lower-triangular tiles straight into the packed vector
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
+            if (i < n && jc <= i) {
+              const long base = (long)jc * n - (long)jc * (jc - 1) / 2;
+              X[base + (i - jc)] = (i == jc) ? c[t] : c[t] * sq2;
+            }
+          }
+        }
+      }
+    }
   }
   if (KIND == PSD_R2 && blockIdx.x == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;
 }

@@ -515,7 +515,7 @@ struct ScsHipWork {
       PsdBatch B{off, order, woff, big};
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
-        const dim3 gg((unsigned)((psd_max_tiles * ((psd_max_tiles + kPsdNJ - 1) / kPsdNJ) + 3) / 4), (unsigned)big), gb(kPsdGemmThreads);
+        const dim3 gg(psd_gemm_wgs(psd_max_tiles), (unsigned)big), gb(kPsdGemmThreads);
         // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
         hipLaunchKernelGGL(k_psd_front, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(kPsdFrontThreads), 0, stream,
                            (const double *)base, B, psd_scratch.p, psd_warm, stall);

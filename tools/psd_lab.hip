@@ -59,7 +59,7 @@ int main(int argc, char **argv) {
     if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, nullptr);
     else if (split) {
       const int ntile = (int)np / 16;
-      const dim3 gg((unsigned)((ntile * ((ntile + kPsdNJ - 1) / kPsdNJ) + 3) / 4), (unsigned)cnt), gb(kPsdGemmThreads);
+      const dim3 gg(psd_gemm_wgs(ntile), (unsigned)cnt), gb(kPsdGemmThreads);
       hipLaunchKernelGGL(k_psd_front, dim3(ntile, cnt), dim3(kPsdFrontThreads), 0, 0, (const double *)d_x, B, d_scr, 1, (const int *)nullptr);
       hipLaunchKernelGGL(k_proj_psd<3>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);

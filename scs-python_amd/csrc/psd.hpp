@@ -22,6 +22,8 @@
 // chain straight from registers.  A and V live in an L2-resident scratch; finally
 // X+ = (V sqrt(L+)) (V sqrt(L+))' over lower-triangular 16x16 tiles, again on MFMA.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 #ifndef PSD_INNER
@@ -56,10 +58,6 @@ constexpr int kPsdWLd = PSD_WLD;      // leading dimension of W
 constexpr int kPsdWsz = 16 * 17;  // 272 doubles reserved per S / W
 constexpr int kPsdWaveLds = 2 * kPsdWsz;  // per wave: S (also the 16x17 transpose scratch), W
 constexpr int kPsdWarmPeriod = 32;  // calls between two re-orthogonalisations of the warm-start basis V
-#ifndef PSD_DEPTH
-#define PSD_DEPTH 1
-#endif
-constexpr int kPsdDepth = PSD_DEPTH;  // phase 2: prefetch distance (tasks) of each wave's software pipeline
 constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
 #ifndef PSD_OFFTOL2
 #define PSD_OFFTOL2 1e-16
@@ -94,6 +92,7 @@ __host__ __device__ inline long psd_scratch_doubles(long n) {
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) double lds_f64;  // explicit LDS address space for pointers hipcc would treat as generic
 
 __device__ __forceinline__ void rr_pair(int r, int k, int N, int &p, int &q) {
   // round-robin tournament on N (even) players, round r in [0, N-1)
@@ -611,7 +610,10 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
       // Software-pipelined: the four global loads of the wave's NEXT task are in flight while the current one
       // runs its MFMAs and stores (all waves reach the same phase at the same time, so without this the
       // matrix cores idle during the loads and the memory path idles during the MFMAs).
-      {
+      // (instantiated twice — rotations in LDS / in global memory — so that each instruction stream has ONE kind of operand
+      //  fetch and exact wait counts)
+      auto phase2 = [&](auto w_lds_tag) {
+        constexpr bool kWLds = decltype(w_lds_tag)::value;
         const int ntask = MODE == 1 ? nblk : nblk + H * ntile;  // split mode: the V tasks run in k_psd_apply_v
         auto decode = [&](int task, int &k, int &k2) {  // A task: (k, k2 >= k); V task: (k, row tile) with k2 = -1 - tile
           if (task < nblk) {
@@ -640,18 +642,33 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
         };
         auto run = [&](int k, int k2, const double (&av)[4]) {
           const int p = osch[2 * k], q = osch[2 * k + 1];
-          const double *W1 = w_in_lds ? lds + k * kPsdWaveLds + kPsdWsz : Wg + (size_t)k * kPsdWsz;
+          // W operands into registers through two typed paths (LDS / global): a pointer that may be either compiles to FLAT
+          // loads, and a flat load makes every later wait a full s_waitcnt vmcnt(0) lgkmcnt(0) — no prefetch survives that
+          auto ld_w = [&](int kp, double (&w)[4]) {
+            if (kWLds) {
+              const lds_f64 *pw = (const lds_f64 *)(lds + kp * kPsdWaveLds + kPsdWsz);  // ds_read, not flat_load
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) w[kk] = pw[(4 * kk + lk) + kPsdWLd * li];
+            } else {
+              const double *pw = Wg + (size_t)kp * kPsdWsz;
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) w[kk] = pw[(4 * kk + lk) + kPsdWLd * li];
+            }
+          };
+          double w1[4];
+          ld_w(k, w1);
           if (k2 >= 0) {
             const int p2 = osch[2 * k2], q2 = osch[2 * k2 + 1];
-            const double *W2 = w_in_lds ? lds + k2 * kPsdWaveLds + kPsdWsz : Wg + (size_t)k2 * kPsdWsz;
+            double w2[4];
+            ld_w(k2, w2);
             f64x4 T = {0., 0., 0., 0.};  // T = Bm * W2
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-              T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], W2[(4 * kk + lk) + kPsdWLd * li], T, 0, 0, 0);
+              T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], w2[kk], T, 0, 0, 0);
             f64x4 Rr = {0., 0., 0., 0.};  // R = W1' * T  (B operand of k-step t is T[t])
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * t + lk) + kPsdWLd * li], T[t], Rr, 0, 0, 0);
+              Rr = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[t], T[t], Rr, 0, 0, 0);
             // Stores.  Lane holds R[row = lk + 4t][col = li].  The mirror block (k2,k) = R' is written straight
             // from this layout (li runs down a column: full 128-byte lines).  The direct block goes through a
             // 16x17 LDS transpose in the wave's private scratch so that li runs down its columns as well.
@@ -672,37 +689,39 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
             f64x4 T = {0., 0., 0., 0.};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-              T = __builtin_amdgcn_mfma_f64_16x16x4f64(W1[(4 * kk + lk) + kPsdWLd * li], av[kk], T, 0, 0, 0);  // (V_blk W)'
+              T = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[kk], av[kk], T, 0, 0, 0);  // (V_blk W)'
             // lane holds (V_blk W)[row = li][col = lk + 4t]: li runs down a column -> full-line stores
 #pragma unroll
             for (int t = 0; t < 4; ++t) V[(rt * 16 + li) + (size_t)ld * pq_index(lk + 4 * t, p, q)] = T[t];
           }
         };
-        constexpr int D = kPsdDepth;  // prefetch distance in tasks; D + 1 register buffers
-        double buf[D + 1][4];
-        int bk[D + 1], bk2[D + 1];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const int t = wave + j * kPsdWaves;
-          bk[j] = bk2[j] = 0;
-          if (t < ntask) { decode(t, bk[j], bk2[j]); load(bk[j], bk2[j], buf[j]); }
-        }
-        bk[D] = bk2[D] = 0;
-        for (int base = wave; base < ntask; base += (D + 1) * kPsdWaves) {
-#pragma unroll
-          for (int j = 0; j <= D; ++j) {  // static buffer indices
-            const int tcur = base + j * kPsdWaves;
-            if (tcur < ntask) {
-              const int tpre = tcur + D * kPsdWaves;
-              constexpr int dummy = 0;
-              (void)dummy;
-              const int sp = (j + D) % (D + 1);
-              if (tpre < ntask) { decode(tpre, bk[sp], bk2[sp]); load(bk[sp], bk2[sp], buf[sp]); }
-              run(bk[j], bk2[j], buf[j]);
+        // Two register buffers, the next task's loads issued before the current task runs.  The loads sit in straight-line code
+        // between uniform branches (never inside a per-task condition): with `if (next exists) load` hipcc waits for ALL
+        // outstanding loads (s_waitcnt vmcnt(0)) before the current task's first MFMA and the prefetch hides nothing.
+        {
+          double bufa[4], bufb[4];
+          int ka = 0, k2a = 0, kb = 0, k2b = 0;
+          int t = wave;
+          if (t < ntask) {
+            decode(t, ka, k2a);
+            load(ka, k2a, bufa);
+            while (true) {
+              if (t + kPsdWaves >= ntask) { run(ka, k2a, bufa); break; }
+              decode(t + kPsdWaves, kb, k2b);
+              load(kb, k2b, bufb);
+              run(ka, k2a, bufa);
+              t += kPsdWaves;
+              if (t + kPsdWaves >= ntask) { run(kb, k2b, bufb); break; }
+              decode(t + kPsdWaves, ka, k2a);
+              load(ka, k2a, bufa);
+              run(kb, k2b, bufb);
+              t += kPsdWaves;
             }
           }
         }
-      }
+      };
+      if (w_in_lds) phase2(std::true_type{});
+      else phase2(std::false_type{});
       __syncthreads();
       PSD_TICK(t_s3);
       PSD_ACC(4, t_s2, t_s3);

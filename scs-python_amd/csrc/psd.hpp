@@ -374,13 +374,14 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
 // MODE 0: the whole projection in one launch (one workgroup = one CU per matrix; right when the batch fills the GPU).
 // Split mode for small batches of large matrices (config 4: 50 matrices on 256 CUs), everything that parallelises
 // beyond one CU per matrix in its own multi-workgroup launch:
-//   MODE 2  front: unpack, V' (and the periodic re-orthogonalisation of V)           1 workgroup / matrix
-//   k_psd_gemm<G1>, <G2>: warm start A0 = V'AV                                        13 workgroups / matrix at order 200
+//   k_psd_front: unpack, V = I / V', counters (many workgroups per matrix); MODE 3: the periodic re-orthogonalisation of V
+//           (one workgroup per matrix; returns at once on the other calls).  MODE 2 = both in one workgroup (kept for A/B)
+//   k_psd_gemm<G1>, <G2>: warm start A0 = V'AV                                        7 workgroups / matrix at order 200
 //   MODE 1  sweeps: diagonalise A (pivots + A updates), LOG every pivot's 16x16 rotation; a round logs at most
 //           kPsdLogSweeps sweeps, the host enqueues [sweep, apply] rounds back to back and later rounds return at
 //           once when the matrix has already converged (state[1])                     1 workgroup / matrix
 //   k_psd_apply_v: V <- V W_1 W_2 ... per 16-row strip (the V update is 2/3 of the update work)   13 / matrix
-//   k_psd_gemm<R1>, <R2>: X+ = V F V'                                                 13 / matrix
+//   k_psd_fmap: F = Pi_+(D + E) element by element; k_psd_gemm<R1>, <R2>: X+ = V F V'   7 / matrix (2 x 4 tiles per wavefront)
 // Same rotations, same MFMA sequences: bit-identical to MODE 0.
 template <int MODE>
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall) {

@@ -108,6 +108,17 @@ void scs_hip_kernel_times(const ScsWork *w, double *out);
  * host copies scs_solve returned (NaN where the status leaves a vector undefined).  scs/batch.py gathers from these. */
 int scs_hip_solution_to_device(ScsWork *w, scs_float *x_dev, scs_float *y_dev, scs_float *s_dev);
 
+/* Grouped solve of `count` independent, already initialised workspaces (BASELINE.json configs[4]: a batch of small cone
+ * programs; the reference's notion is "independent instances run concurrently", R:test/test_thread_safety.py:78-93 —
+ * one scs_solve per thread).  Members of equal shape (n, m, cone structure, Anderson schedule) whose matrices use the
+ * CSR-stream layout advance through the ADMM loop in lock step and SHARE every kernel launch (blockIdx.y = problem,
+ * arguments from a per-problem record in HBM; csrc/batch.hpp); whatever cannot be grouped is solved by scs_solve's own
+ * loop, one after the other.  sol[i] / info[i] are filled exactly as scs_solve(w[i], sol[i], info[i], warm_start) fills
+ * them — the grouped kernels run the same device code over the same block decomposition, so iterates, iteration and
+ * CG-step counts are bit-identical to separate solves (timing fields are those of the group).  Returns 0, -1 on error
+ * (scs_hip_last_error).  The workspaces must live on one device and must not be used by other threads meanwhile. */
+scs_int scs_hip_solve_batch(ScsWork **w, ScsSolution **sol, ScsInfo **info, scs_int count, scs_int warm_start);
+
 /* bench.py: a timestamp inside the next scs_solve calls.  When ADMM iteration `iter` is about to start, the stream is
  * drained and out[4] = {ms since the start of the solve, CG steps so far, Anderson calls so far, accepted so far} is
  * recorded (out[0] < 0: the solve ended before that iteration); iter < 0 switches it off. */

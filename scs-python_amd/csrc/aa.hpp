@@ -36,8 +36,8 @@ enum : int { AA_R_OK = 0, AA_R_RANK, AA_R_CODE, AA_R_NORM, AA_R_REG, AA_R_NORMG,
 enum : int { AA_CODE_OK = 0, AA_CODE_RANK0, AA_CODE_LAPACK, AA_CODE_NONFINITE, AA_CODE_WEIGHT };
 
 // first call after a reset: x_prev = x, f_prev = f, g_prev = x - f
-__global__ __launch_bounds__(kVecThreads) void k_aa_seed(const double *__restrict__ x, const double *__restrict__ f, double *ax,
-                                                         double *af, double *gprev, long dim) {
+__device__ __forceinline__ void d_aa_seed(const double *__restrict__ x, const double *__restrict__ f,
+                                          double *ax, double *af, double *gprev, long dim) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < dim; i += (long)gridDim.x * kVecThreads) {
     const double xi = x[i], fi = f[i];
     ax[i] = xi;
@@ -45,12 +45,17 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_seed(const double *__restric
     gprev[i] = xi - fi;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_aa_seed(const double *__restrict__ x,
+                                                         const double *__restrict__ f, double *ax, double *af,
+                                                         double *gprev, long dim) {
+  d_aa_seed(x, f, ax, af, gprev, dim);
+}
 
 // g = x - f; s = x - x_prev; d = f - f_prev; y = g - g_prev; store column idx of S,D,Y;
 // roll x_prev,f_prev,g_prev; partial ||g||^2
-__global__ __launch_bounds__(kVecThreads) void k_aa_update(const double *__restrict__ x, const double *__restrict__ f, double *ax,
-                                                           double *af, double *gprev, double *S, double *Y, double *D, long dim,
-                                                           int idx, double *part) {
+__device__ __forceinline__ void d_aa_update(const double *__restrict__ x, const double *__restrict__ f,
+                                            double *ax, double *af, double *gprev, double *S, double *Y,
+                                            double *D, long dim, int idx, double *part) {
   __shared__ double sm[kVecThreads / 64];
   double acc = 0.;
   double *Sc = S + (size_t)dim * idx, *Yc = Y + (size_t)dim * idx, *Dc = D + (size_t)dim * idx;
@@ -67,6 +72,12 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_update(const double *__restr
   }
   acc = block_sum<kVecThreads>(acc, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(kVecThreads) void k_aa_update(const double *__restrict__ x,
+                                                           const double *__restrict__ f, double *ax,
+                                                           double *af, double *gprev, double *S, double *Y,
+                                                           double *D, long dim, int idx, double *part) {
+  d_aa_update(x, f, ax, af, gprev, S, Y, D, dim, idx, part);
 }
 
 // ------------------------------------------------------------------------------------------------ Gram path
@@ -184,7 +195,7 @@ inline size_t aa_tsqr_lds(int c, int npiv, int rho) { return ((size_t)c * 64 * r
 // npiv x c triangle E (rows of [R_LL | Q'(other columns)]), which it stores as rows [w * npiv, (w+1) * npiv) of the
 // column-major output (leading dimension out_ld).  Householder step k on the stacked [E row k; tile]: only E row k and
 // the tile carry column k below the diagonal (E is upper trapezoidal), v = [alpha - beta; tile column k].
-__global__ __launch_bounds__(64) void k_aa_tsqr(AaTall W, int rho, long tiles_per_wave, double *out, long out_ld) {
+__device__ __forceinline__ void d_aa_tsqr(AaTall W, int rho, long tiles_per_wave, double *out, long out_ld) {
   extern __shared__ double aa_lds[];
   const int lane = threadIdx.x, c = W.c, npiv = W.npiv, TR = 64 * rho;
   double *T = aa_lds;                      // T[j * TR + r]: tile, column-major (lane-consecutive rows: conflict-free)
@@ -251,13 +262,18 @@ __global__ __launch_bounds__(64) void k_aa_tsqr(AaTall W, int rho, long tiles_pe
     out[(size_t)j * out_ld + (size_t)blockIdx.x * npiv + i] = E[t];
   }
 }
+__global__ __launch_bounds__(64) void k_aa_tsqr(AaTall W, int rho, long tiles_per_wave, double *out,
+                                                long out_ld) {
+  d_aa_tsqr(W, rho, tiles_per_wave, out, out_ld);
+}
 
 // One wavefront: the regularised len x len system from the final triangle R (column-major npiv x c, npiv = len),
 //   type-I : M = R_LL' R_LY (columns len .. 2 len - 1), w = R_LL' R_Lg;   type-II: M = R_YY' R_YY, w = R_YY' R_Yg,
 // LU with partial pivoting (row swaps, then eliminations, the order DeviceAa::dense_solve uses), then the rank / finite /
 // weight-cap tests of aa.c's solve.  Leaves the verdict and gamma in res.
-__global__ __launch_bounds__(64) void k_aa_solve(const double *__restrict__ R, int len, int c, int type1, double regularization,
-                                                 double max_weight_norm, const double *npart, int nnp, double *res) {
+__device__ __forceinline__ void d_aa_solve(const double *__restrict__ R, int len, int c, int type1,
+                                           double regularization, double max_weight_norm, const double *npart,
+                                           int nnp, double *res) {
   __shared__ double M[kAaMaxMem * kAaMaxMem], w[kAaMaxMem];
   const int lane = threadIdx.x;
   {
@@ -331,12 +347,18 @@ __global__ __launch_bounds__(64) void k_aa_solve(const double *__restrict__ R, i
     for (int j = 0; j < len; ++j) res[AA_R_GAMMA + j] = code == AA_CODE_OK ? w[j] : 0.0;
   }
 }
+__global__ __launch_bounds__(64) void k_aa_solve(const double *__restrict__ R, int len, int c, int type1,
+                                                 double regularization, double max_weight_norm,
+                                                 const double *npart, int nnp, double *res) {
+  d_aa_solve(R, len, c, type1, regularization, max_weight_norm, npart, nnp, res);
+}
 
 // f -= D gamma;  optional relaxation: f = beta f + (1-beta) (x - S gamma).  ok != nullptr: the device-side verdict
 // of k_aa_solve (gamma sits right behind it); a rejected step leaves f untouched.
-__global__ __launch_bounds__(kVecThreads) void k_aa_apply(double *f, const double *__restrict__ D, const double *__restrict__ S,
-                                                          const double *__restrict__ xcur, const double *__restrict__ gamma,
-                                                          long dim, int len, double relaxation, const double *ok) {
+__device__ __forceinline__ void d_aa_apply(double *f, const double *__restrict__ D,
+                                           const double *__restrict__ S, const double *__restrict__ xcur,
+                                           const double *__restrict__ gamma, long dim, int len,
+                                           double relaxation, const double *ok) {
   if (ok && !(*ok != 0.)) return;
   double gm[kAaMaxMem];
 #pragma unroll
@@ -355,10 +377,17 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_apply(double *f, const doubl
     f[i] = fi;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_aa_apply(double *f, const double *__restrict__ D,
+                                                          const double *__restrict__ S,
+                                                          const double *__restrict__ xcur,
+                                                          const double *__restrict__ gamma, long dim, int len,
+                                                          double relaxation, const double *ok) {
+  d_aa_apply(f, D, S, xcur, gamma, dim, len, relaxation, ok);
+}
 
 // safeguard: partial ||x_new - f_new||^2
-__global__ __launch_bounds__(kVecThreads) void k_aa_diffsq(const double *__restrict__ a, const double *__restrict__ b, long dim,
-                                                           double *part) {
+__device__ __forceinline__ void d_aa_diffsq(const double *__restrict__ a, const double *__restrict__ b,
+                                            long dim, double *part) {
   __shared__ double sm[kVecThreads / 64];
   double acc = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < dim; i += (long)gridDim.x * kVecThreads) {
@@ -368,7 +397,13 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_diffsq(const double *__restr
   acc = block_sum<kVecThreads>(acc, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(kVecThreads) void k_fin_safeguard(const double *part, int np, double factor, double *res, int *bad) {
+__global__ __launch_bounds__(kVecThreads) void k_aa_diffsq(const double *__restrict__ a,
+                                                           const double *__restrict__ b, long dim,
+                                                           double *part) {
+  d_aa_diffsq(a, b, dim, part);
+}
+__device__ __forceinline__ void d_fin_safeguard(const double *part, int np, double factor, double *res,
+                                                int *bad) {
   __shared__ double sm[kVecThreads / 64];
   const double s = part_sum(part, np, sm);
   if (threadIdx.x == 0) {
@@ -378,14 +413,24 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_safeguard(const double *par
     *bad = (nd <= factor * res[AA_R_NORMG]) ? 0 : 1;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_fin_safeguard(const double *part, int np, double factor,
+                                                               double *res, int *bad) {
+  d_fin_safeguard(part, np, factor, res, bad);
+}
 // roll back to the pre-AA iterate when the safeguard fired
-__global__ __launch_bounds__(kVecThreads) void k_aa_restore(double *f_new, double *x_new, const double *__restrict__ af,
-                                                            const double *__restrict__ ax, long dim, const int *bad) {
+__device__ __forceinline__ void d_aa_restore(double *f_new, double *x_new, const double *__restrict__ af,
+                                             const double *__restrict__ ax, long dim, const int *bad) {
   if (!*bad) return;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < dim; i += (long)gridDim.x * kVecThreads) {
     f_new[i] = af[i];
     x_new[i] = ax[i];
   }
+}
+__global__ __launch_bounds__(kVecThreads) void k_aa_restore(double *f_new, double *x_new,
+                                                            const double *__restrict__ af,
+                                                            const double *__restrict__ ax, long dim,
+                                                            const int *bad) {
+  d_aa_restore(f_new, x_new, af, ax, dim, bad);
 }
 
 // ================================================================================================ host object
@@ -447,8 +492,18 @@ struct DeviceAa {
 
   static constexpr int kTsqrWaves1 = 1024, kTsqrWaves2 = 16;
 
-  // [L | Y | g] -> final npiv x c triangle (column-major, ld = npiv); returns the device pointer holding it
-  const double *tsqr_factor(int len) {
+  // One launch of the TSQR reduction: the tall matrix it reads, its geometry and where its stacked triangles go
+  struct TsqrLevel {
+    AaTall W;
+    int rho;
+    long tiles_per_wave, nw, out_ld;
+    double *out;
+    size_t lds;
+  };
+  // [L | Y | g] -> final npiv x c triangle (column-major, ld = npiv): the launches of the fixed reduction tree, in
+  // order; the last level's `out` holds the triangle.  (Also read by the grouped solve, batch.hpp.)
+  std::vector<TsqrLevel> tsqr_levels(int len) const {
+    std::vector<TsqrLevel> lv;
     AaTall W{};
     W.L = type1 ? S.p : Y.p; W.Y = type1 ? Y.p : nullptr; W.g = gprev.p;
     W.ld = dim; W.rows = dim; W.nL = len; W.nY = type1 ? len : 0; W.c = W.nL + W.nY + 1; W.npiv = len;
@@ -463,32 +518,58 @@ struct DeviceAa {
       nw = (ntiles + tpw - 1) / tpw;
       double *o = rbuf[dst].p;
       const long out_ld = nw * len;
-      hipLaunchKernelGGL(k_aa_tsqr, dim3((unsigned)nw), dim3(64), lds, stream, W, rho, tpw, o, out_ld);
-      if (nw == 1) return o;
+      lv.push_back(TsqrLevel{W, rho, tpw, nw, out_ld, o, lds});
+      if (nw == 1) return lv;
       W.L = o; W.Y = nullptr; W.g = nullptr; W.ld = out_ld; W.rows = out_ld; W.nL = c; W.nY = 0;
       dst ^= 1;
       ++level;
     }
+  }
+  const double *tsqr_factor(int len) {
+    const std::vector<TsqrLevel> lv = tsqr_levels(len);
+    for (const TsqrLevel &L : lv)
+      hipLaunchKernelGGL(k_aa_tsqr, dim3((unsigned)L.nw), dim3(64), L.lds, stream, L.W, L.rho, L.tiles_per_wave, L.out, L.out_ld);
+    return lv.back().out;
+  }
+
+  // What one call has to do, from the control state alone (aa.c's apply): 0 nothing (no memory), 1 seed the history,
+  // 2 extend it (still filling), 3 extend + solve + extrapolate.  len / idx: columns in use / column written.
+  // The caller runs the kernels, hands the solve's record to complete() (mode 3) and then advances `iter`.
+  int plan(int &len, int &idx) {
+    success = 0;
+    len = idx = 0;
+    if (mem <= 0) return 0;
+    st.iter++;
+    if (iter == 0) return 1;
+    len = std::min(iter, mem);
+    idx = (iter - 1) % mem;
+    return iter >= mem ? 3 : 2;
+  }
+  // res = the AA_R_* record k_aa_solve left (read back by the caller); returns aa_norm
+  double complete(const double *res, int len) {
+    const double aa_norm = verdict((int)res[AA_R_RANK], (int)res[AA_R_CODE], res[AA_R_NORM], res[AA_R_REG]);
+    last_gamma.assign(res + AA_R_GAMMA, res + AA_R_GAMMA + len);
+    last_norm_g = res[AA_R_NORMG];
+    return aa_norm;
   }
 
   // f = current map output F(x) (device, may be overwritten with the extrapolated iterate), x = map input.
   // Returns aa_norm with aa.c's sign convention (0: nothing done, < 0: rejected).
   double apply(double *fdev, const double *xdev) {
     double aa_norm = 0;
-    success = 0;
-    if (mem <= 0) return aa_norm;
-    st.iter++;
+    int len, idx;
+    const int mode = plan(len, idx);
+    if (mode == 0) return aa_norm;
     const int nb = nbl();
-    if (iter == 0) {
+    if (mode == 1) {
       hipLaunchKernelGGL(k_aa_seed, dim3(nb), dim3(kVecThreads), 0, stream, xdev, fdev, x.p, f.p, gprev.p, dim);
       iter++;
       return aa_norm;
     }
-    const int len = std::min(iter, mem), idx = (iter - 1) % mem;
     hipLaunchKernelGGL(k_aa_update, dim3(nb), dim3(kVecThreads), 0, stream, xdev, fdev, x.p, f.p, gprev.p, S.p, Y.p, D.p, dim,
                        idx, npart.p);
     if (tsqr) {
-      if (iter >= mem) {
+      if (mode == 3) {
         const double *R = tsqr_factor(len);
         hipLaunchKernelGGL(k_aa_solve, dim3(1), dim3(64), 0, stream, R, len, ncols(), type1, regularization, max_weight_norm,
                            (const double *)npart.p, nb, res.p);
@@ -496,9 +577,7 @@ struct DeviceAa {
                            relaxation, (const double *)res.p + AA_R_OK);
         HIP_CHECK(hipMemcpyAsync(h_pin, res.p, sizeof(double) * AA_R_COUNT, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        aa_norm = verdict((int)h_pin[AA_R_RANK], (int)h_pin[AA_R_CODE], h_pin[AA_R_NORM], h_pin[AA_R_REG]);
-        last_gamma.assign(h_pin + AA_R_GAMMA, h_pin + AA_R_GAMMA + len);
-        last_norm_g = h_pin[AA_R_NORMG];
+        aa_norm = complete(h_pin, len);
       }
     } else {
       const double *L = type1 ? S.p : Y.p;

@@ -28,8 +28,8 @@ constexpr int kSocBig = 4096;
 
 // ------------------------------------------------------------------ SOC
 // in-place Pi_SOC on slices x[off[c] .. off[c]+dim[c]); one wave per cone
-__global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const int *__restrict__ off,
-                                                                const int *__restrict__ dim, int ncones, const int *stall) {
+__device__ __forceinline__ void d_proj_soc_wave(double *x, const int *__restrict__ off,
+                                                const int *__restrict__ dim, int ncones, const int *stall) {
   SCS_STALL_GUARD(stall);
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kConeThreads / 64) + (threadIdx.x >> 6);
@@ -54,6 +54,11 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const
   const double alpha = 0.5 * (s + t), f = alpha / s;
   for (int i = 1 + lane; i < q; i += 64) v[i] *= f;
   if (lane == 0) v[0] = alpha;
+}
+__global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const int *__restrict__ off,
+                                                                const int *__restrict__ dim, int ncones,
+                                                                const int *stall) {
+  d_proj_soc_wave(x, off, dim, ncones, stall);
 }
 
 // one workgroup per big cone
@@ -114,7 +119,8 @@ __device__ inline void proj_power_cone(double *v, double a) {
 }
 
 // lane-per-cone: u = Pi_{K*}(w).  a >= 0: K = pow(a): u = w + Pi_K(-w);  a < 0: K* = pow(|a|): u = Pi_{pow(|a|)}(w)
-__global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const double *__restrict__ a, int ncones, const int *stall) {
+__device__ __forceinline__ void d_proj_pow_dual(double *x, const double *__restrict__ a, int ncones,
+                                                const int *stall) {
   SCS_STALL_GUARD(stall);
   const int c = blockIdx.x * kConeThreads + threadIdx.x;
   if (c >= ncones) return;
@@ -129,6 +135,10 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const
     proj_power_cone(t, -ac);
     w[0] = t[0]; w[1] = t[1]; w[2] = t[2];
   }
+}
+__global__ __launch_bounds__(kConeThreads) void k_proj_pow_dual(double *x, const double *__restrict__ a,
+                                                                int ncones, const int *stall) {
+  d_proj_pow_dual(x, a, ncones, stall);
 }
 // primal-cone variant (test entry point): a >= 0: Pi_{pow(a)}(w);  a < 0: w + Pi_{pow(|a|)}(-w)
 __global__ __launch_bounds__(kConeThreads) void k_proj_pow_primal(double *x, const double *__restrict__ a, int ncones, const int *stall) {
@@ -321,7 +331,7 @@ __device__ inline void proj(double *v0, int primal) {
 
 // lane-per-cone.  mode 0: u = Pi_{K*}(w) for the ep block (K = K_exp): dual projection;
 //                 mode 1: ed block (K = K_exp^*): K* = K_exp: primal projection.
-__global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones, int primal, const int *stall) {
+__device__ __forceinline__ void d_proj_exp(double *x, int ncones, int primal, const int *stall) {
   SCS_STALL_GUARD(stall);
   const int c = blockIdx.x * kConeThreads + threadIdx.x;
   if (c >= ncones) return;
@@ -330,13 +340,17 @@ __global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones
   expc::proj(t, primal);
   w[0] = t[0]; w[1] = t[1]; w[2] = t[2];
 }
+__global__ __launch_bounds__(kConeThreads) void k_proj_exp(double *x, int ncones, int primal, const int *stall) {
+  d_proj_exp(x, ncones, primal, stall);
+}
 
 // -------------------------------------------------------------- box cone
 // K = {(t,s): t bl <= s <= t bu, t >= 0}.  In place: x <- x + Pi_K(-x) (dual=1) or Pi_K(x) (dual=0).
 // One workgroup; Newton on t of a piecewise quadratic, warm-started from sc_t (device scalar).
 constexpr int kBoxThreads = 1024;
-__global__ __launch_bounds__(kBoxThreads) void k_proj_box(double *x, const double *__restrict__ bl, const double *__restrict__ bu,
-                                                          int bsize, double *t_warm, int dual, const int *stall) {
+__device__ __forceinline__ void d_proj_box(double *x, const double *__restrict__ bl,
+                                           const double *__restrict__ bu, int bsize, double *t_warm, int dual,
+                                           const int *stall) {
   SCS_STALL_GUARD(stall);
   __shared__ double sm[kBoxThreads / 64];
   __shared__ double bc[2];
@@ -383,6 +397,11 @@ __global__ __launch_bounds__(kBoxThreads) void k_proj_box(double *x, const doubl
     x[0] = dual ? x[0] + t : t;
     *t_warm = t;
   }
+}
+__global__ __launch_bounds__(kBoxThreads) void k_proj_box(double *x, const double *__restrict__ bl,
+                                                          const double *__restrict__ bu, int bsize,
+                                                          double *t_warm, int dual, const int *stall) {
+  d_proj_box(x, bl, bu, bsize, t_warm, dual, stall);
 }
 
 // Large box cones (bsize > kBoxMultiMin): the same Newton iteration on t, one launch per round over many workgroups.

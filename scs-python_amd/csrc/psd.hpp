@@ -1320,7 +1320,8 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
 constexpr int kPsdSmallMax = 32;
 constexpr int kPsdSLd = 33;
 
-__global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+__device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm,
+                                                 const int *stall) {
   SCS_STALL_GUARD(stall);
   __shared__ double S[32 * kPsdSLd], V[32 * kPsdSLd], T[32 * kPsdSLd];
   __shared__ double csc[16], css[16];
@@ -1546,6 +1547,10 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
   if (lane == 0)
     for (int i = 1; i < 8; ++i) state[i] = prof[i];
 #endif
+}
+__global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm,
+                                                       const int *stall) {
+  d_proj_psd_small(x, B, scratch, allow_warm, stall);
 }
 
 // ---------------------------------------------------------------------------

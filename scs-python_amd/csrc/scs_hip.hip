@@ -1098,10 +1098,15 @@ struct ScsHipWork {
     HIP_CHECK(hipMemcpyAsync(h_pin + 32, u.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipMemcpyAsync(h_pin + 33, rsk.p + (l - 1), sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    consume_residuals(h_pin);
+  }
+  // host half of populate_residuals: res = the 32 reduced scalars of the two residual products, then u_tau, rsk_tau
+  // (the grouped solve, batch.hpp, reads the records of all its problems with one copy and hands each one over here)
+  void consume_residuals(const double *res) {
     const double pd = normalized ? scal.sigma * scal.sigma : 1.0;
-    const double *hp = h_pin, *hd = h_pin + 16;
-    r.tau = std::fabs(h_pin[32]);
-    r.kap_n = std::fabs(h_pin[33]);
+    const double *hp = res, *hd = res + 16;
+    r.tau = std::fabs(res[32]);
+    r.kap_n = std::fabs(res[33]);
     r.kap = r.kap_n / pd;
     r.bty_tau_n = hp[RES_P_BTY];
     r.bty_tau = r.bty_tau_n / pd;
@@ -1156,28 +1161,36 @@ struct ScsHipWork {
     return 0;
   }
 
-  void update_scale(int iter) {
+  // the adaptive-scale rule on the residuals in `r` (host state only).  true: `scale` changed — the caller rebuilds
+  // R, the preconditioner and g, resets the acceleration and re-expresses v (apply_scale_update; batch.hpp does the
+  // same for a sub-list of its group)
+  bool decide_scale_update(int iter) {
     const int since = iter - last_scale_update_iter;
     const double rel_pri = safediv_pos(r.nm_ax_s_btau, std::max(std::max(r.nm_ax, r.nm_s), nm_b_orig * r.tau));
     const double rel_dual = safediv_pos(r.nm_px_aty_ctau, std::max(std::max(r.nm_px, r.nm_aty), nm_c_orig * r.tau));
     sum_log_scale_factor += std::log(rel_pri) - std::log(rel_dual);
     n_log_scale_factor++;
     const double factor = std::sqrt(std::exp(sum_log_scale_factor / (double)n_log_scale_factor));
-    if (since < 100) return;
+    if (since < 100) return false;
     const double new_scale = std::min(std::max(scale * factor, 1e-4), 1e6);
-    if (new_scale == scale) return;
+    if (new_scale == scale) return false;
     if (factor > std::sqrt(10.) || factor < 1. / std::sqrt(10.)) {
       scale_updates++;
       sum_log_scale_factor = 0;
       n_log_scale_factor = 0;
       last_scale_update_iter = iter;
       scale = new_scale;
-      set_diag_r();
-      update_work_cache();
-      aa.reset();  // reset acceleration
-      hipLaunchKernelGGL(k_v_rescale, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, rsk.p, u.p, ut.p, diag_r.p, l);
-      v_norm_fresh = false;
+      return true;
     }
+    return false;
+  }
+  void update_scale(int iter) {
+    if (!decide_scale_update(iter)) return;
+    set_diag_r();
+    update_work_cache();
+    aa.reset();  // reset acceleration
+    hipLaunchKernelGGL(k_v_rescale, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, rsk.p, u.p, ut.p, diag_r.p, l);
+    v_norm_fresh = false;
   }
 
   // --------------------------------------------------------------------- AA
@@ -1237,6 +1250,143 @@ struct ScsHipWork {
     HIP_CHECK(hipMemcpyAsync(h_pin + 40, out.p + 40, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     write_csv_row(f, iter, r, scale, h_pin + 40, aa_norm, elapsed_ms / 1e3);
+  }
+
+  // ---- the two ends of a solve, shared by scs_solve and the grouped solve (batch.hpp) ----
+  // per-solve state, info header and the initial iterate (cold: v = [0; 0; 1]; warm: from sol)
+  void begin_solve(ScsSolution *sol, ScsInfo *info, int warm_start) {
+    std::memset(info, 0, sizeof(*info));
+    info->setup_time = setup_time;
+    if (persist_wgs > 0)
+      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (PCG, persistent %dx%d-wave kernel)",
+                    persist_wgs, 4 * persist_ng);
+    else
+      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV, PCG)",
+                    At.cs.ok ? "column-sorted pass" : At.has_slab ? "L2-blocked slab" : "CSR-stream");
+    // per-solve state
+    sum_log_scale_factor = 0; n_log_scale_factor = 0; last_scale_update_iter = 0; scale_updates = 0;
+    rejected_accel = 0; accepted_accel = 0; aa_norm = 0;
+    aa.reset(); aa.success = 0; aa.pending_safeguard = false; aa.st = ScsAaStats{};
+    r = Residuals{};
+    cg_res_min = 0;
+    tot_cg_iters = 0;
+    prof_ms[0] = prof_ms[1] = 0;
+    prof_n[0] = prof_n[1] = 0;
+    prof_cone_ms = 0; prof_cone_n = 0;
+
+    // ---- initial iterate ----
+    {
+      const double one = 1.0;
+      if (warm_start) {
+        // v = [x_hat; y_hat + s_hat / r_y; 1] with the normalised warm start (boundary work, O(l) on the host)
+        std::vector<double> v0(l, 0.0);
+        const double sg = normalized ? scal.sigma : 1.0;
+        for (int i = 0; i < n; ++i) v0[i] = normalized ? sol->x[i] / (scal.E[i] / sg) : sol->x[i];
+        for (int i = 0; i < m; ++i) {
+          const double ry = (i < cone.z) ? 1.0 / (1000. * scale) : 1.0 / scale;
+          const double yh = normalized ? sol->y[i] / (scal.D[i] / sg) : sol->y[i];
+          const double sh = normalized ? sol->s[i] * (scal.D[i] * sg) : sol->s[i];
+          v0[n + i] = yh + sh / ry;
+        }
+        for (long i = 0; i < l; ++i)
+          if (!std::isfinite(v0[i])) v0[i] = 0.;
+        v0[l - 1] = 1.0;
+        HIP_CHECK(hipMemcpyAsync(v.p, v0.data(), sizeof(double) * l, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));  // v0 is a local
+      } else {  // cold start: v = [0; 0; 1], nothing crosses PCIe
+        HIP_CHECK(hipMemsetAsync(v.p, 0, sizeof(double) * l, stream));
+        HIP_CHECK(hipMemcpyAsync(v.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, stream));
+      }
+      v_norm_fresh = false;
+      HIP_CHECK(hipMemsetAsync(u.p, 0, sizeof(double) * l, stream));
+      HIP_CHECK(hipMemcpyAsync(u.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    info->status_val = SCS_UNFINISHED;
+  }
+  // status, un-normalised (x, y, s) on the device and on the host, info; i = iterations done.  info->status_val holds
+  // the verdict of the last convergence check (SCS_UNFINISHED: none fired).
+  void finish_solve(ScsSolution *sol, ScsInfo *info, int i, double t_start, double t_lin, double t_cone, double t_acc,
+                    bool grouped = false) {
+    // ---- finalize ----
+    const int max_iters = stgs.max_iters;
+    if (!grouped) {  // (the grouped solve has read this problem's flags and residuals already)
+      read_flags();
+      populate_residuals(i == max_iters ? max_iters - 1 : i);  // loop ran out: rsk of the last iteration was computed
+    }
+    const double sg = normalized ? scal.sigma : 1.0;
+    hipLaunchKernelGGL(k_unnormalize, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, u.p, rsk.p,
+                       normalized ? D.p : (const double *)nullptr, normalized ? E.p : (const double *)nullptr, sg, 1.0,
+                       1.0, 1.0, n, m, solx.p, soly.p, sols.p);
+    // complementary slackness s'y of the un-rescaled pair (fixed-order two-stage sum), then status and its scaling
+    const int nbm = vb(m);
+    hipLaunchKernelGGL(k_dot_part, dim3(nbm), dim3(kVecThreads), 0, stream, (const double *)sols.p, (const double *)soly.p, (long)m, part.p);
+    std::vector<double> cs_part((size_t)nbm);
+    HIP_CHECK(hipMemcpyAsync(cs_part.data(), part.p, sizeof(double) * nbm, hipMemcpyDeviceToHost, stream));
+    info->iter = i;
+    info->res_infeas = r.res_infeas;
+    info->res_unbdd_a = r.res_unbdd_a;
+    info->res_unbdd_p = r.res_unbdd_p;
+    info->scale = scale;
+    info->scale_updates = scale_updates;
+    info->rejected_accel_steps = rejected_accel;
+    info->accepted_accel_steps = accepted_accel;
+    if (info->status_val == SCS_UNFINISHED) {
+      if (r.tau > r.kap) info->status_val = SCS_SOLVED_INACCURATE;
+      else if (r.bty_tau < r.ctx_tau) info->status_val = SCS_INFEASIBLE_INACCURATE;
+      else info->status_val = SCS_UNBOUNDED_INACCURATE;
+    }
+    // final scaling on the device (a NaN factor marks a vector the status leaves undefined); the host copies are plain
+    // downloads of the finished vectors, and the device copies stay behind for scs_hip_solution_to_device (scs/batch.py:
+    // the RCCL gather starts from where the solutions live)
+    double fx = 1., fy = 1., fs = 1.;
+    switch (info->status_val) {
+      case SCS_SOLVED:
+      case SCS_SOLVED_INACCURATE:
+        fx = fy = fs = safediv_pos(1.0, r.tau);
+        info->gap = r.gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual;
+        info->pobj = r.xt_p_x / 2. + r.ctx;
+        info->dobj = -r.xt_p_x / 2. - r.bty;
+        std::snprintf(info->status, sizeof(info->status), "%s",
+                      info->status_val == SCS_SOLVED ? "solved" : "solved (inaccurate - reached max_iters)");
+        break;
+      case SCS_INFEASIBLE:
+      case SCS_INFEASIBLE_INACCURATE:
+        fy = -1. / r.bty_tau;
+        fx = fs = NAN;
+        info->gap = info->res_pri = info->res_dual = NAN;
+        info->pobj = INFINITY; info->dobj = INFINITY;
+        std::snprintf(info->status, sizeof(info->status), "%s",
+                      info->status_val == SCS_INFEASIBLE ? "infeasible" : "infeasible (inaccurate - reached max_iters)");
+        break;
+      default:
+        fx = fs = -1. / r.ctx_tau;
+        fy = NAN;
+        info->gap = info->res_pri = info->res_dual = NAN;
+        info->pobj = -INFINITY; info->dobj = -INFINITY;
+        std::snprintf(info->status, sizeof(info->status), "%s",
+                      info->status_val == SCS_UNBOUNDED ? "unbounded" : "unbounded (inaccurate - reached max_iters)");
+        break;
+    }
+    hipLaunchKernelGGL(k_scale3, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, solx.p, soly.p, sols.p, n, m, fx, fy, fs);
+    solx.download(sol->x, n, stream);
+    soly.download(sol->y, m, stream);
+    sols.download(sol->s, m, stream);
+    // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
+    // un-synchronised kernel was measured to take 25 ms on this runtime)
+    HIP_CHECK(hipStreamSynchronize(stream));
+    sol_on_device = true;
+    {
+      double cs = 0.;
+      for (double v : cs_part) cs += v;
+      info->comp_slack = std::fabs(cs);
+    }
+    info->lin_sys_time = t_lin;
+    info->cone_time = t_cone;
+    info->accel_time = t_acc;
+    info->cg_iters = (scs_int)tot_cg_iters;
+    info->aa_stats = aa.st;
+    info->solve_time = now_ms() - t_start;
   }
 };
 
@@ -1632,55 +1782,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   const int n = w->n, m = w->m;
   const long l = w->l;
   hipStream_t s = w->stream;
-  std::memset(info, 0, sizeof(*info));
-  info->setup_time = w->setup_time;
-  if (w->persist_wgs > 0)
-    std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (PCG, persistent %dx%d-wave kernel)",
-                  w->persist_wgs, 4 * w->persist_ng);
-  else
-    std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV, PCG)",
-                  w->At.cs.ok ? "column-sorted pass" : w->At.has_slab ? "L2-blocked slab" : "CSR-stream");
-  // per-solve state
-  w->sum_log_scale_factor = 0; w->n_log_scale_factor = 0; w->last_scale_update_iter = 0; w->scale_updates = 0;
-  w->rejected_accel = 0; w->accepted_accel = 0; w->aa_norm = 0;
-  w->aa.reset(); w->aa.success = 0; w->aa.pending_safeguard = false; w->aa.st = ScsAaStats{};
-  w->r = Residuals{};
-  w->cg_res_min = 0;
-  w->tot_cg_iters = 0;
-  w->prof_ms[0] = w->prof_ms[1] = 0;
-  w->prof_n[0] = w->prof_n[1] = 0;
-  w->prof_cone_ms = 0; w->prof_cone_n = 0;
+  w->begin_solve(sol, info, warm_start);
   double t_lin = 0, t_cone = 0, t_acc = 0;
-
-  // ---- initial iterate ----
-  {
-    const double one = 1.0;
-    if (warm_start) {
-      // v = [x_hat; y_hat + s_hat / r_y; 1] with the normalised warm start (boundary work, O(l) on the host)
-      std::vector<double> v0(l, 0.0);
-      const double sg = w->normalized ? w->scal.sigma : 1.0;
-      for (int i = 0; i < n; ++i) v0[i] = w->normalized ? sol->x[i] / (w->scal.E[i] / sg) : sol->x[i];
-      for (int i = 0; i < m; ++i) {
-        const double ry = (i < w->cone.z) ? 1.0 / (1000. * w->scale) : 1.0 / w->scale;
-        const double yh = w->normalized ? sol->y[i] / (w->scal.D[i] / sg) : sol->y[i];
-        const double sh = w->normalized ? sol->s[i] * (w->scal.D[i] * sg) : sol->s[i];
-        v0[n + i] = yh + sh / ry;
-      }
-      for (long i = 0; i < l; ++i)
-        if (!std::isfinite(v0[i])) v0[i] = 0.;
-      v0[l - 1] = 1.0;
-      HIP_CHECK(hipMemcpyAsync(w->v.p, v0.data(), sizeof(double) * l, hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipStreamSynchronize(s));  // v0 is a local
-    } else {  // cold start: v = [0; 0; 1], nothing crosses PCIe
-      HIP_CHECK(hipMemsetAsync(w->v.p, 0, sizeof(double) * l, s));
-      HIP_CHECK(hipMemcpyAsync(w->v.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    w->v_norm_fresh = false;
-    HIP_CHECK(hipMemsetAsync(w->u.p, 0, sizeof(double) * l, s));
-    HIP_CHECK(hipMemcpyAsync(w->u.p + (l - 1), &one, sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-  }
-  info->status_val = SCS_UNFINISHED;
   FILE *csv = nullptr;
   if (!w->log_csv_filename.empty()) {
     csv = std::fopen(w->log_csv_filename.c_str(), "w");
@@ -1804,84 +1907,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     for (int v : w->cg_hist) std::fprintf(stderr, " %d", v);
     std::fprintf(stderr, "\n");
   }
-  // ---- finalize ----
-  if (i == max_iters) i = max_iters;  // loop ran out: rsk of the last iteration was computed
-  w->read_flags();
-  w->populate_residuals(i == max_iters ? max_iters - 1 : i);
-  const Residuals &r = w->r;
-  const double sg = w->normalized ? w->scal.sigma : 1.0;
-  hipLaunchKernelGGL(k_unnormalize, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->u.p, w->rsk.p,
-                     w->normalized ? w->D.p : (const double *)nullptr, w->normalized ? w->E.p : (const double *)nullptr, sg, 1.0,
-                     1.0, 1.0, n, m, w->solx.p, w->soly.p, w->sols.p);
-  // complementary slackness s'y of the un-rescaled pair (fixed-order two-stage sum), then status and its scaling
-  const int nbm = w->vb(m);
-  hipLaunchKernelGGL(k_dot_part, dim3(nbm), dim3(kVecThreads), 0, s, (const double *)w->sols.p, (const double *)w->soly.p, (long)m, w->part.p);
-  std::vector<double> cs_part((size_t)nbm);
-  HIP_CHECK(hipMemcpyAsync(cs_part.data(), w->part.p, sizeof(double) * nbm, hipMemcpyDeviceToHost, s));
-  info->iter = i;
-  info->res_infeas = r.res_infeas;
-  info->res_unbdd_a = r.res_unbdd_a;
-  info->res_unbdd_p = r.res_unbdd_p;
-  info->scale = w->scale;
-  info->scale_updates = w->scale_updates;
-  info->rejected_accel_steps = w->rejected_accel;
-  info->accepted_accel_steps = w->accepted_accel;
-  if (info->status_val == SCS_UNFINISHED) {
-    if (r.tau > r.kap) info->status_val = SCS_SOLVED_INACCURATE;
-    else if (r.bty_tau < r.ctx_tau) info->status_val = SCS_INFEASIBLE_INACCURATE;
-    else info->status_val = SCS_UNBOUNDED_INACCURATE;
-  }
-  // final scaling on the device (a NaN factor marks a vector the status leaves undefined); the host copies are plain
-  // downloads of the finished vectors, and the device copies stay behind for scs_hip_solution_to_device (scs/batch.py:
-  // the RCCL gather starts from where the solutions live)
-  double fx = 1., fy = 1., fs = 1.;
-  switch (info->status_val) {
-    case SCS_SOLVED:
-    case SCS_SOLVED_INACCURATE:
-      fx = fy = fs = safediv_pos(1.0, r.tau);
-      info->gap = r.gap; info->res_pri = r.res_pri; info->res_dual = r.res_dual;
-      info->pobj = r.xt_p_x / 2. + r.ctx;
-      info->dobj = -r.xt_p_x / 2. - r.bty;
-      std::snprintf(info->status, sizeof(info->status), "%s",
-                    info->status_val == SCS_SOLVED ? "solved" : "solved (inaccurate - reached max_iters)");
-      break;
-    case SCS_INFEASIBLE:
-    case SCS_INFEASIBLE_INACCURATE:
-      fy = -1. / r.bty_tau;
-      fx = fs = NAN;
-      info->gap = info->res_pri = info->res_dual = NAN;
-      info->pobj = INFINITY; info->dobj = INFINITY;
-      std::snprintf(info->status, sizeof(info->status), "%s",
-                    info->status_val == SCS_INFEASIBLE ? "infeasible" : "infeasible (inaccurate - reached max_iters)");
-      break;
-    default:
-      fx = fs = -1. / r.ctx_tau;
-      fy = NAN;
-      info->gap = info->res_pri = info->res_dual = NAN;
-      info->pobj = -INFINITY; info->dobj = -INFINITY;
-      std::snprintf(info->status, sizeof(info->status), "%s",
-                    info->status_val == SCS_UNBOUNDED ? "unbounded" : "unbounded (inaccurate - reached max_iters)");
-      break;
-  }
-  hipLaunchKernelGGL(k_scale3, dim3(w->vb((long)n + m)), dim3(kVecThreads), 0, s, w->solx.p, w->soly.p, w->sols.p, n, m, fx, fy, fs);
-  w->solx.download(sol->x, n, s);
-  w->soly.download(sol->y, m, s);
-  w->sols.download(sol->s, m, s);
-  // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
-  // un-synchronised kernel was measured to take 25 ms on this runtime)
-  HIP_CHECK(hipStreamSynchronize(s));
-  w->sol_on_device = true;
-  {
-    double cs = 0.;
-    for (double v : cs_part) cs += v;
-    info->comp_slack = std::fabs(cs);
-  }
-  info->lin_sys_time = t_lin;
-  info->cone_time = t_cone;
-  info->accel_time = t_acc;
-  info->cg_iters = (scs_int)w->tot_cg_iters;
-  info->aa_stats = w->aa.st;
-  info->solve_time = now_ms() - t_start;
+  w->finish_solve(sol, info, i, t_start, t_lin, t_cone, t_acc);
   if (verbose) {
     std::printf("------------------------------------------------------------------\n");
     std::printf("status:  %s\ntimings: total: %.2es = setup: %.2es + solve: %.2es\n\t lin-sys: %.2es, cones: %.2es, accel: %.2es\n",
@@ -1918,6 +1944,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   return info->status_val;
 }
 
+#include "batch.hpp"
+
 // ================================================================ C ABI
 extern "C" {
 
@@ -1945,6 +1973,71 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
     fill_nan(sol->s, w->m);
     return SCS_FAILED;
   }
+}
+
+// Grouped solve of `count` workspaces (include/scs_hip.h): members that can share launches — same shape, CSR-stream
+// layouts, one-launch cone kernels (GroupSolve::member_ok / same_shape) — advance in lock step through the grouped
+// kernels of batch.hpp; the others are solved one after the other by scs_solve's own loop.  Every info[i] / sol[i] is
+// filled exactly as scs_solve(w[i], sol[i], info[i], warm_start) would (iterates are bit-identical).
+scs_int scs_hip_solve_batch(ScsWork **works, ScsSolution **sols, ScsInfo **infos, scs_int count, scs_int warm_start) {
+  if (!works || !sols || !infos || count < 0) return -1;
+  set_last_error("");
+  for (int i = 0; i < count; ++i) {
+    if (!works[i] || !sols[i] || !infos[i]) { set_last_error("scs_hip_solve_batch: null entry"); return -1; }
+    for (int j = 0; j < i; ++j)
+      if (works[j] == works[i]) { set_last_error("scs_hip_solve_batch: a workspace appears twice"); return -1; }
+  }
+  static const int group_max = [] { const char *e = getenv("SCS_HIP_GROUP_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  std::vector<char> taken((size_t)count, 0);
+  scs_int rc = 0;
+  for (int i = 0; i < count; ++i) {
+    if (taken[(size_t)i]) continue;
+    taken[(size_t)i] = 1;
+    std::vector<int> idx{i};
+    if (group_max > 1 && GroupSolve::member_ok(works[i]))
+      for (int j = i + 1; j < count && (int)idx.size() < group_max; ++j)
+        if (!taken[(size_t)j] && GroupSolve::member_ok(works[j]) && GroupSolve::same_shape(works[i], works[j])) {
+          taken[(size_t)j] = 1;
+          idx.push_back(j);
+        }
+    if (idx.size() == 1) {
+      if (scs_solve(works[i], sols[i], infos[i], warm_start) == SCS_FAILED) rc = -1;
+      continue;
+    }
+    std::vector<std::unique_lock<std::mutex>> locks;
+    std::vector<hipStream_t> saved;
+    GroupSolve gs;
+    try {
+      for (int j : idx) locks.emplace_back(works[j]->mtx);
+      HIP_CHECK(hipSetDevice(works[i]->device));
+      gs.s = works[i]->stream;
+      for (int j : idx) {
+        gs.W.push_back(works[j]); gs.sols.push_back(sols[j]); gs.infos.push_back(infos[j]);
+        saved.push_back(works[j]->stream);
+        works[j]->stream = gs.s;  // every member's kernels go to the group's stream for the duration of the solve
+        works[j]->aa.stream = gs.s;
+      }
+      gs.build();
+      gs.run(warm_start);
+    } catch (const std::exception &e) {
+      set_last_error(e.what());
+      rc = -1;
+      (void)hipStreamSynchronize(gs.s);
+      for (int j : idx)
+        if (infos[j]->status_val == SCS_UNFINISHED || infos[j]->status[0] == 0) {
+          infos[j]->status_val = SCS_FAILED;
+          std::snprintf(infos[j]->status, sizeof(infos[j]->status), "failure");
+          fill_nan(sols[j]->x, works[j]->n);
+          fill_nan(sols[j]->y, works[j]->m);
+          fill_nan(sols[j]->s, works[j]->m);
+        }
+    }
+    for (size_t k = 0; k < saved.size(); ++k) {
+      works[idx[k]]->stream = saved[k];
+      works[idx[k]]->aa.stream = saved[k];
+    }
+  }
+  return rc;
 }
 
 scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {

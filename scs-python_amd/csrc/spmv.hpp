@@ -294,9 +294,10 @@ __device__ __forceinline__ void spmv_stream_block(const CsrView &A, const double
 }
 
 template <class Epi>
-__global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi,
-                                                               const int *done_flag, int *step_counter) {
+__device__ __forceinline__ void d_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi, const int *done_flag,
+                                              int *step_counter) {
   if (done_flag && *done_flag) return;
+  if ((int)blockIdx.x >= A.nblk) return;  // (grouped launches, batch.hpp: the grid is sized for the problem with the most row blocks)
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;  // one CG step begins
   __shared__ double prod[kNnzPerWg];
   __shared__ double red[kSpmvThreads / 64];
@@ -304,6 +305,11 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const d
   CsrView B = A;
   B.blk = A.blk - A.pbase;
   spmv_stream_block(B, x, epi, A.pbase + (int)blockIdx.x, A.pstride > 0 ? A.pstride : (int)gridDim.x, prod, red, (int)threadIdx.x, BlockSync{});
+}
+template <class Epi>
+__global__ __launch_bounds__(kSpmvThreads) void k_spmv_stream(CsrView A, const double *__restrict__ x, Epi epi,
+                                                               const int *done_flag, int *step_counter) {
+  d_spmv_stream(A, x, epi, done_flag, step_counter);
 }
 
 // ---------------------------------------------------------------------------

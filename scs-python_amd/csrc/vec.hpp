@@ -67,12 +67,15 @@ __device__ __forceinline__ double part_max(const double *part, int np, double *s
 }
 
 // ||v||_2 partials
-__global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict__ v, long n, double *part) {
+__device__ __forceinline__ void d_sumsq(const double *__restrict__ v, long n, double *part) {
   __shared__ double sm[kVecThreads / 64];
   double s = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += v[i] * v[i];
   s = block_sum<kVecThreads>(s, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict__ v, long n, double *part) {
+  d_sumsq(v, n, part);
 }
 
 // Start of project_lin_sys: normalise v, snapshot v_prev and form the CG warm start
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(kVecThreads) void k_sumsq(const double *__restrict_
 // The iterate normalisation factor sqrt(l) / ||v|| is formed in the prologue from the
 // sum-of-squares partials `vpart` (written by k_v_update of the previous iteration, or by k_sumsq after
 // anything else touched v): every workgroup reduces them in the same fixed order, no finalize launch.
-__global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *ws,
-                                                      const double *__restrict__ u, const double *__restrict__ g,
-                                                      const double *__restrict__ diag_r, int n, int m, const double *params,
-                                                      const double *vpart, int nvp, double *sc, double *part,
-                                                      const int *stall) {
+__device__ __forceinline__ void d_prep(double *v, double *v_prev, double *ut, double *ws,
+                                       const double *__restrict__ u, const double *__restrict__ g,
+                                       const double *__restrict__ diag_r, int n, int m, const double *params,
+                                       const double *vpart, int nvp, double *sc, double *part,
+                                       const int *stall) {
   SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc;
@@ -125,12 +128,20 @@ __global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev,
     part[gridDim.x + blockIdx.x] = mr;  // ||rhs||_inf of the KKT system
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_prep(double *v, double *v_prev, double *ut, double *ws,
+                                                      const double *__restrict__ u,
+                                                      const double *__restrict__ g,
+                                                      const double *__restrict__ diag_r, int n, int m,
+                                                      const double *params, const double *vpart, int nvp,
+                                                      double *sc, double *part, const int *stall) {
+  d_prep(v, v_prev, ut, ws, u, g, diag_r, n, m, params, vpart, nvp, sc, part, stall);
+}
 
 // CG tolerance: tol = max(1e-12, 0.2 * min(res_min, ||ws||_inf / (k+1)^1.5))
 // A right-hand side with ||rhs||_inf <= 1e-12 short-circuits to the zero solution (F_ZERO_RHS).
-__global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int np, double res_min, double ipow,
-                                                         double fixed_tol, int have_rhs_norm, const double *params,
-                                                         double *sc, int *fl) {
+__device__ __forceinline__ void d_fin_tol(const double *part, int np, double res_min, double ipow,
+                                          double fixed_tol, int have_rhs_norm, const double *params,
+                                          double *sc, int *fl) {
   __shared__ double sm[kVecThreads / 64];
   if (params) {
     res_min = params[P_RES_MIN];
@@ -151,13 +162,18 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int
     fl[F_DONE] = zero;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_fin_tol(const double *part, int np, double res_min,
+                                                         double ipow, double fixed_tol, int have_rhs_norm,
+                                                         const double *params, double *sc, int *fl) {
+  d_fin_tol(part, np, res_min, ipow, fixed_tol, have_rhs_norm, params, sc, fl);
+}
 
 // r = b - G ws; x = ws; p = M r; partial [max|r| , sum r M r]
 // Gws2 != nullptr: G ws = Gws + Gws2 (split layout of A', see EpiGp::split)
-__global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restrict__ b, const double *__restrict__ Gws,
-                                                         const double *__restrict__ ws, const double *__restrict__ M,
-                                                         double *x, double *r, double *p, int n, int have_ws, const int *fl,
-                                                         double *part, const double *__restrict__ Gws2 = nullptr) {
+__device__ __forceinline__ void d_cg_init(const double *__restrict__ b, const double *__restrict__ Gws,
+                                          const double *__restrict__ ws, const double *__restrict__ M,
+                                          double *x, double *r, double *p, int n, int have_ws, const int *fl,
+                                          double *part, const double *__restrict__ Gws2) {
   __shared__ double sm[kVecThreads / 64];
   double mx = 0., s = 0.;
   if (fl[F_ZERO_RHS]) {  // zero right-hand side: the solution is zero, no iterations
@@ -184,9 +200,18 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restric
     part[gridDim.x + blockIdx.x] = s;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_cg_init(const double *__restrict__ b,
+                                                         const double *__restrict__ Gws,
+                                                         const double *__restrict__ ws,
+                                                         const double *__restrict__ M, double *x, double *r,
+                                                         double *p, int n, int have_ws, const int *fl,
+                                                         double *part,
+                                                         const double *__restrict__ Gws2 = nullptr) {
+  d_cg_init(b, Gws, ws, M, x, r, p, n, have_ws, fl, part, Gws2);
+}
 
 // sum_first: partial layout [sum | max] (SpMV epilogue) instead of [max | sum] (k_cg_init)
-__global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part, int np, int sum_first, double *sc, int *fl) {
+__device__ __forceinline__ void d_fin_cg_init(const double *part, int np, int sum_first, double *sc, int *fl) {
   __shared__ double sm[kVecThreads / 64];
   const double rn = part_max(sum_first ? part + np : part, np, sm);
   const double ztr = part_sum(sum_first ? part : part + np, np, sm);
@@ -196,13 +221,17 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part,
     if (rn < fmax(sc[S_TOL], 1e-12)) fl[F_DONE] = 1;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_fin_cg_init(const double *part, int np, int sum_first,
+                                                             double *sc, int *fl) {
+  d_fin_cg_init(part, np, sum_first, sc, fl);
+}
 
 // ADMM path: k_fin_tol + k_fin_cg_init + the CG step counter reset + the zero-rhs short circuit in ONE
 // single-workgroup launch after the fused CG start (the two SpMVs of the start do not depend on the tolerance).
 //   prep_part = k_prep's [max |ws| (np_p) | max |rhs| (np_p)],  r0_part = EpiR0's [sum r0'M r0 (np_r) | max |r0| (np_r)]
-__global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_part, int np_p, const double *r0_part, int np_r,
-                                                          const double *params, double *sc, int *fl, double *ut, long nm,
-                                                          const int *stall) {
+__device__ __forceinline__ void d_fin_head(const double *prep_part, int np_p, const double *r0_part, int np_r,
+                                           const double *params, double *sc, int *fl, double *ut, long nm,
+                                           const int *stall) {
   SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   __shared__ int zero_rhs;
@@ -225,6 +254,12 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_par
   __syncthreads();
   if (zero_rhs)  // zero right-hand side => zero solution (happens at most at the first iteration of a cold start)
     for (long i = threadIdx.x; i < nm; i += kVecThreads) ut[i] = 0.;
+}
+__global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_part, int np_p,
+                                                          const double *r0_part, int np_r,
+                                                          const double *params, double *sc, int *fl,
+                                                          double *ut, long nm, const int *stall) {
+  d_fin_head(prep_part, np_p, r0_part, np_r, params, sc, fl, ut, nm, stall);
 }
 
 // x += alpha p; r -= alpha Gp; partial [max|r|, sum r M r].
@@ -259,11 +294,11 @@ __device__ __forceinline__ void cg_update_block(double *x, double *r, const doub
     part[nb + b] = s;
   }
 }
-__global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
-                                                           const double *__restrict__ Gp, const double *__restrict__ M,
-                                                           int n, double *yacc, const double *__restrict__ z, int m,
-                                                           const double *pgp_part, int pgp_np, double *sc, const int *fl,
-                                                           double *part, const double *__restrict__ Gp2 = nullptr) {
+__device__ __forceinline__ void d_cg_update(double *x, double *r, const double *__restrict__ p,
+                                            const double *__restrict__ Gp, const double *__restrict__ M, int n,
+                                            double *yacc, const double *__restrict__ z, int m,
+                                            const double *pgp_part, int pgp_np, double *sc, const int *fl,
+                                            double *part, const double *__restrict__ Gp2) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc;
@@ -277,13 +312,22 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r,
   }
   cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
 }
+__global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
+                                                           const double *__restrict__ Gp,
+                                                           const double *__restrict__ M, int n, double *yacc,
+                                                           const double *__restrict__ z, int m,
+                                                           const double *pgp_part, int pgp_np, double *sc,
+                                                           const int *fl, double *part,
+                                                           const double *__restrict__ Gp2 = nullptr) {
+  d_cg_update(x, r, p, Gp, M, n, yacc, z, m, pgp_part, pgp_np, sc, fl, part, Gp2);
+}
 
 // p = M r + beta p.  beta = z'r(new) / z'r(old) and the convergence test are formed in the prologue from the
 // partials of k_cg_update (every workgroup reduces them in the same fixed order); workgroup 0 then does the
 // bookkeeping for the step: new z'r into the OTHER slot (nobody reads that one during this launch),
 // ||r||_inf, the CG step counter and the done flag (p is dead once the flag is set).
-__global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r, const double *__restrict__ M,
-                                                        int n, const double *upd_part, int upd_np, double *sc, int *fl) {
+__device__ __forceinline__ void d_cg_dir(double *p, const double *__restrict__ r, const double *__restrict__ M,
+                                         int n, const double *upd_part, int upd_np, double *sc, int *fl) {
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc[2];
@@ -308,11 +352,17 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double 
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
     p[i] = M[i] * r[i] + beta * p[i];
 }
+__global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r,
+                                                        const double *__restrict__ M, int n,
+                                                        const double *upd_part, int upd_np, double *sc,
+                                                        int *fl) {
+  d_cg_dir(p, r, M, n, upd_part, upd_np, sc, fl);
+}
 
 // R-weighted dots for the tau quadratic (root_plus): [p'Rg, p'Rp, p'Rmu, mu'Rg] over the first l-1 entries
-__global__ __launch_bounds__(kVecThreads) void k_tau_dots(const double *__restrict__ p, const double *__restrict__ mu,
-                                                          const double *__restrict__ g, const double *__restrict__ diag_r,
-                                                          long n, double *part, int *stall_fl) {
+__device__ __forceinline__ void d_tau_dots(const double *__restrict__ p, const double *__restrict__ mu,
+                                           const double *__restrict__ g, const double *__restrict__ diag_r,
+                                           long n, double *part, int *stall_fl) {
   // first kernel behind a CG chunk: in run-ahead mode (stall_fl = the flag array) an unconverged solve stalls the queue
   if (stall_fl) {
     if (stall_fl[F_STALL]) return;
@@ -342,10 +392,17 @@ __global__ __launch_bounds__(kVecThreads) void k_tau_dots(const double *__restri
     part[3 * gridDim.x + blockIdx.x] = d;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_tau_dots(const double *__restrict__ p,
+                                                          const double *__restrict__ mu,
+                                                          const double *__restrict__ g,
+                                                          const double *__restrict__ diag_r, long n,
+                                                          double *part, int *stall_fl) {
+  d_tau_dots(p, mu, g, diag_r, n, part, stall_fl);
+}
 
 // g'Rg (cached per scale)
-__global__ __launch_bounds__(kVecThreads) void k_gg(const double *__restrict__ g, const double *__restrict__ diag_r, long n,
-                                                    double *part) {
+__device__ __forceinline__ void d_gg(const double *__restrict__ g, const double *__restrict__ diag_r, long n,
+                                     double *part) {
   __shared__ double sm[kVecThreads / 64];
   double a = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
@@ -353,10 +410,18 @@ __global__ __launch_bounds__(kVecThreads) void k_gg(const double *__restrict__ g
   a = block_sum<kVecThreads>(a, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
-__global__ __launch_bounds__(kVecThreads) void k_fin_store_sum(const double *part, int np, double *sc, int slot) {
+__global__ __launch_bounds__(kVecThreads) void k_gg(const double *__restrict__ g,
+                                                    const double *__restrict__ diag_r, long n, double *part) {
+  d_gg(g, diag_r, n, part);
+}
+__device__ __forceinline__ void d_fin_store_sum(const double *part, int np, double *sc, int slot) {
   __shared__ double sm[kVecThreads / 64];
   const double s = part_sum(part, np, sm);
   if (threadIdx.x == 0) sc[slot] = s;
+}
+__global__ __launch_bounds__(kVecThreads) void k_fin_store_sum(const double *part, int np, double *sc,
+                                                               int slot) {
+  d_fin_store_sum(part, np, sc, slot);
 }
 
 // tau_tilde = positive root of the scalar quadratic from the partials of k_tau_dots
@@ -373,10 +438,10 @@ __device__ __forceinline__ double tau_root(double pg, double pp, double pmu, dou
 //   x rows: identity.  zero-cone rows: dual cone is free -> identity.  l rows: max(.,0).
 // tau_t is formed in the prologue: every workgroup reduces the four k_tau_dots partial arrays in the same
 // fixed order (no single-workgroup finalize launch in between); workgroup 0 publishes it in sc[S_TAUT].
-__global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
-                                                          const double *__restrict__ g, int n, int m, int nz, int nl,
-                                                          const double *params, double *sc, const double *tau_part, int np,
-                                                          const double *__restrict__ diag_r, int *stall_fl) {
+__device__ __forceinline__ void d_cone_pre(double *ut, double *u, const double *__restrict__ v,
+                                           const double *__restrict__ g, int n, int m, int nz, int nl,
+                                           const double *params, double *sc, const double *tau_part, int np,
+                                           const double *__restrict__ diag_r, int *stall_fl) {
   if (stall_fl && stall_fl[F_STALL]) {  // queue stalled by k_tau_dots: also park the CG-step kernels queued behind
     if (blockIdx.x == 0 && threadIdx.x == 0) stall_fl[F_DONE] = 1;
     return;
@@ -410,18 +475,32 @@ __global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u,
     }
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_cone_pre(double *ut, double *u, const double *__restrict__ v,
+                                                          const double *__restrict__ g, int n, int m, int nz,
+                                                          int nl, const double *params, double *sc,
+                                                          const double *tau_part, int np,
+                                                          const double *__restrict__ diag_r, int *stall_fl) {
+  d_cone_pre(ut, u, v, g, n, m, nz, nl, params, sc, tau_part, np, diag_r, stall_fl);
+}
 
 // rsk = R (v + u - 2 u_t)
-__global__ __launch_bounds__(kVecThreads) void k_rsk(double *rsk, const double *__restrict__ v, const double *__restrict__ u,
-                                                     const double *__restrict__ ut, const double *__restrict__ diag_r, long l) {
+__device__ __forceinline__ void d_rsk(double *rsk, const double *__restrict__ v, const double *__restrict__ u,
+                                      const double *__restrict__ ut, const double *__restrict__ diag_r, long l) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
     rsk[i] = (v[i] + u[i] - 2 * ut[i]) * diag_r[i];
+}
+__global__ __launch_bounds__(kVecThreads) void k_rsk(double *rsk, const double *__restrict__ v,
+                                                     const double *__restrict__ u,
+                                                     const double *__restrict__ ut,
+                                                     const double *__restrict__ diag_r, long l) {
+  d_rsk(rsk, v, u, ut, diag_r, l);
 }
 
 // v += alpha (u - u_t); vpart[block] = partial ||v_new||^2 — same partition and order as k_sumsq, so the next
 // iteration's k_prep normalises with the same bits as if k_sumsq had run
-__global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const double *__restrict__ u, const double *__restrict__ ut,
-                                                          double alpha, long l, double *vpart, const int *stall) {
+__device__ __forceinline__ void d_v_update(double *v, const double *__restrict__ u,
+                                           const double *__restrict__ ut, double alpha, long l, double *vpart,
+                                           const int *stall) {
   SCS_STALL_GUARD(stall);
   __shared__ double sm[kVecThreads / 64];
   double s = 0.;
@@ -433,16 +512,28 @@ __global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const doubl
   s = block_sum<kVecThreads>(s, sm);
   if (threadIdx.x == 0) vpart[blockIdx.x] = s;
 }
+__global__ __launch_bounds__(kVecThreads) void k_v_update(double *v, const double *__restrict__ u,
+                                                          const double *__restrict__ ut, double alpha, long l,
+                                                          double *vpart, const int *stall) {
+  d_v_update(v, u, ut, alpha, l, vpart, stall);
+}
 
 // after a scale update: v = rsk / R+ + 2 u_t - u
-__global__ __launch_bounds__(kVecThreads) void k_v_rescale(double *v, const double *__restrict__ rsk, const double *__restrict__ u,
-                                                           const double *__restrict__ ut, const double *__restrict__ diag_r, long l) {
+__device__ __forceinline__ void d_v_rescale(double *v, const double *__restrict__ rsk,
+                                            const double *__restrict__ u, const double *__restrict__ ut,
+                                            const double *__restrict__ diag_r, long l) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads)
     v[i] = rsk[i] / diag_r[i] + 2 * ut[i] - u[i];
 }
+__global__ __launch_bounds__(kVecThreads) void k_v_rescale(double *v, const double *__restrict__ rsk,
+                                                           const double *__restrict__ u,
+                                                           const double *__restrict__ ut,
+                                                           const double *__restrict__ diag_r, long l) {
+  d_v_rescale(v, rsk, u, ut, diag_r, l);
+}
 
 // diag_r = [rho_x (n) | 1/(1000 scale) (z rows) | 1/scale (other rows) | 10]
-__global__ __launch_bounds__(kVecThreads) void k_set_diag_r(double *diag_r, int n, int m, int nz, double rho_x, double scale) {
+__device__ __forceinline__ void d_set_diag_r(double *diag_r, int n, int m, int nz, double rho_x, double scale) {
   const long l = (long)n + m + 1;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < l; i += (long)gridDim.x * kVecThreads) {
     double r;
@@ -453,42 +544,65 @@ __global__ __launch_bounds__(kVecThreads) void k_set_diag_r(double *diag_r, int 
     diag_r[i] = r;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_set_diag_r(double *diag_r, int n, int m, int nz, double rho_x,
+                                                            double scale) {
+  d_set_diag_r(diag_r, n, m, nz, rho_x, scale);
+}
 
 // g rhs: g = [c ; -b]
-__global__ __launch_bounds__(kVecThreads) void k_g_rhs(double *g, const double *__restrict__ h, int n, int m) {
+__device__ __forceinline__ void d_g_rhs(double *g, const double *__restrict__ h, int n, int m) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads)
     g[i] = i < n ? h[i] : -h[i];
 }
+__global__ __launch_bounds__(kVecThreads) void k_g_rhs(double *g, const double *__restrict__ h, int n, int m) {
+  d_g_rhs(g, h, n, m);
+}
 
 // generic KKT rhs prep for a standalone solve: tmp = rhs_y / r_y, (rhs_x stays)
-__global__ __launch_bounds__(kVecThreads) void k_kkt_prep(const double *__restrict__ rhs, const double *__restrict__ diag_r,
-                                                          double *tmp, int n, int m) {
+__device__ __forceinline__ void d_kkt_prep(const double *__restrict__ rhs, const double *__restrict__ diag_r,
+                                           double *tmp, int n, int m) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
     tmp[i] = rhs[n + i] / diag_r[n + i];
 }
+__global__ __launch_bounds__(kVecThreads) void k_kkt_prep(const double *__restrict__ rhs,
+                                                          const double *__restrict__ diag_r, double *tmp,
+                                                          int n, int m) {
+  d_kkt_prep(rhs, diag_r, tmp, n, m);
+}
 // y = (A x - rhs_y) / r_y, with ax already in `ax`
-__global__ __launch_bounds__(kVecThreads) void k_kkt_y(double *rhs, const double *__restrict__ ax, const double *__restrict__ diag_r,
-                                                       int n, int m) {
+__device__ __forceinline__ void d_kkt_y(double *rhs, const double *__restrict__ ax,
+                                        const double *__restrict__ diag_r, int n, int m) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < m; i += (long)gridDim.x * kVecThreads)
     rhs[n + i] = (ax[i] - rhs[n + i]) / diag_r[n + i];
 }
+__global__ __launch_bounds__(kVecThreads) void k_kkt_y(double *rhs, const double *__restrict__ ax,
+                                                       const double *__restrict__ diag_r, int n, int m) {
+  d_kkt_y(rhs, ax, diag_r, n, m);
+}
 
 // Jacobi preconditioner: M_j = 1 / (R_x,j + P_jj + sum_i A_ij^2 / R_y,i)  over CSC(A) columns
-__global__ __launch_bounds__(kVecThreads) void k_precond(const int *__restrict__ colptr, const int *__restrict__ rowidx,
-                                                         const double *__restrict__ val, const double *__restrict__ diag_r,
-                                                         const double *__restrict__ Pdiag, double *M, int n) {
+__device__ __forceinline__ void d_precond(const int *__restrict__ colptr, const int *__restrict__ rowidx,
+                                          const double *__restrict__ val, const double *__restrict__ diag_r,
+                                          const double *__restrict__ Pdiag, double *M, int n) {
   for (long j = (long)blockIdx.x * kVecThreads + threadIdx.x; j < n; j += (long)gridDim.x * kVecThreads) {
     double d = diag_r[j] + (Pdiag ? Pdiag[j] : 0.0);
     for (int p = colptr[j]; p < colptr[j + 1]; ++p) d += val[p] * val[p] / diag_r[n + rowidx[p]];
     M[j] = 1.0 / d;
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_precond(const int *__restrict__ colptr,
+                                                         const int *__restrict__ rowidx,
+                                                         const double *__restrict__ val,
+                                                         const double *__restrict__ diag_r,
+                                                         const double *__restrict__ Pdiag, double *M, int n) {
+  d_precond(colptr, rowidx, val, diag_r, Pdiag, M, n);
+}
 
 // final solution in original units: x = E x_hat/(sigma tau) ...; mode selects solved / infeasible / unbounded scaling
-__global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__restrict__ u, const double *__restrict__ rsk,
-                                                             const double *__restrict__ D, const double *__restrict__ E,
-                                                             double sigma, double fx, double fy, double fs, int n, int m,
-                                                             double *x, double *y, double *s) {
+__device__ __forceinline__ void d_unnormalize(const double *__restrict__ u, const double *__restrict__ rsk,
+                                              const double *__restrict__ D, const double *__restrict__ E,
+                                              double sigma, double fx, double fy, double fs, int n, int m,
+                                              double *x, double *y, double *s) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads) {
     if (i < n) {
       x[i] = u[i] * (E ? E[i] / sigma : 1.0) * fx;
@@ -499,18 +613,32 @@ __global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__res
     }
   }
 }
+__global__ __launch_bounds__(kVecThreads) void k_unnormalize(const double *__restrict__ u,
+                                                             const double *__restrict__ rsk,
+                                                             const double *__restrict__ D,
+                                                             const double *__restrict__ E, double sigma,
+                                                             double fx, double fy, double fs, int n, int m,
+                                                             double *x, double *y, double *s) {
+  d_unnormalize(u, rsk, D, E, sigma, fx, fy, fs, n, m, x, y, s);
+}
 
 // partials of a'b (fixed-order two-stage sum: the consumer adds part[0 .. gridDim) in order)
-__global__ __launch_bounds__(kVecThreads) void k_dot_part(const double *__restrict__ a, const double *__restrict__ b, long n, double *part) {
+__device__ __forceinline__ void d_dot_part(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                           double *part) {
   __shared__ double sm[kVecThreads / 64];
   double s = 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) s += a[i] * b[i];
   s = block_sum<kVecThreads>(s, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
+__global__ __launch_bounds__(kVecThreads) void k_dot_part(const double *__restrict__ a,
+                                                          const double *__restrict__ b, long n, double *part) {
+  d_dot_part(a, b, n, part);
+}
 
 // in-place final scaling of the device copies of the solution (a NaN factor marks a vector the status leaves undefined)
-__global__ __launch_bounds__(kVecThreads) void k_scale3(double *x, double *y, double *s, int n, int m, double fx, double fy, double fs) {
+__device__ __forceinline__ void d_scale3(double *x, double *y, double *s, int n, int m, double fx, double fy,
+                                         double fs) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < (long)n + m; i += (long)gridDim.x * kVecThreads) {
     if (i < n) x[i] = (fx != fx) ? fx : x[i] * fx;
     else {
@@ -519,6 +647,10 @@ __global__ __launch_bounds__(kVecThreads) void k_scale3(double *x, double *y, do
       s[k] = (fs != fs) ? fs : s[k] * fs;
     }
   }
+}
+__global__ __launch_bounds__(kVecThreads) void k_scale3(double *x, double *y, double *s, int n, int m,
+                                                        double fx, double fy, double fs) {
+  d_scale3(x, y, s, n, m, fx, fy, fs);
 }
 
 // per-iteration CSV diagnostics: [||u-u_t||_2^2, ||v-v_prev||_2^2, ||u-u_t||_inf, ||v-v_prev||_inf]
@@ -547,13 +679,17 @@ __global__ __launch_bounds__(kVecThreads) void k_diff_norms(const double *__rest
 }
 
 // collapse k groups of np partials into out[0..k): sums for the first `nsum` groups, max for the rest
-__global__ __launch_bounds__(kVecThreads) void k_fin_multi(const double *part, int np, int nsum, int nmax, double *out) {
+__device__ __forceinline__ void d_fin_multi(const double *part, int np, int nsum, int nmax, double *out) {
   __shared__ double sm[kVecThreads / 64];
   for (int k = 0; k < nsum + nmax; ++k) {
     const double v = k < nsum ? part_sum(part + (size_t)k * np, np, sm) : part_max(part + (size_t)k * np, np, sm);
     if (threadIdx.x == 0) out[k] = v;
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(kVecThreads) void k_fin_multi(const double *part, int np, int nsum, int nmax,
+                                                           double *out) {
+  d_fin_multi(part, np, nsum, nmax, out);
 }
 
 }  // namespace scship

@@ -173,3 +173,15 @@ def solve(data, cone, **settings):
   """Legacy one-shot API; warm-start vectors may ride along in `data`."""
   solver = SCS(data, cone, **settings)
   return solver.solve(warm_start=True, x=data.get("x"), y=data.get("y"), s=data.get("s"))
+
+
+def solve_batch(solvers, warm_start=False):
+  """Solve several `SCS` objects of the HIP backend as one batch: equally shaped problems advance in lock step and
+  share every kernel launch (the MI355X answer to the reference's "independent instances run concurrently",
+  R:test/test_thread_safety.py:78-93).  Returns one result dict per solver, identical to what `.solve()` returns."""
+  raw = []
+  for sv in solvers:
+    if not isinstance(sv, SCS) or not isinstance(sv._solver, _scs_hip.SCS):
+      raise TypeError("solve_batch needs scs.SCS objects created with LinearSolver.HIP_INDIRECT")
+    raw.append(sv._solver)
+  return _scs_hip.solve_batch(raw, warm_start)

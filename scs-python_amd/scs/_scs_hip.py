@@ -127,6 +127,9 @@ def _load():
     lib.scs_init.argtypes = [C.POINTER(_ScsData), C.POINTER(_ScsCone), C.POINTER(_ScsSettings)]
     lib.scs_solve.restype = c_int
     lib.scs_solve.argtypes = [C.c_void_p, C.POINTER(_ScsSolution), C.POINTER(_ScsInfo), c_int]
+    lib.scs_hip_solve_batch.restype = c_int
+    lib.scs_hip_solve_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.POINTER(_ScsSolution)),
+                                        C.POINTER(C.POINTER(_ScsInfo)), c_int, c_int]
     lib.scs_update.restype = c_int
     lib.scs_update.argtypes = [C.c_void_p, _PD, _PD]
     lib.scs_finish.restype = None
@@ -358,6 +361,46 @@ def _cone_float_list(cone, key):
     return np.ascontiguousarray(arr)
 
 
+def _info_dict(info):
+    """ScsInfo -> the reference's info dict (R:scs/scsobject.h:1073-1111) + this backend's extras"""
+    aa = info.aa_stats
+    return {
+        "status_val": int(info.status_val),
+        "iter": int(info.iter),
+        "scale_updates": int(info.scale_updates),
+        "scale": float(info.scale),
+        "pobj": float(info.pobj),
+        "dobj": float(info.dobj),
+        "res_pri": float(info.res_pri),
+        "res_dual": float(info.res_dual),
+        "gap": float(info.gap),
+        "res_infeas": float(info.res_infeas),
+        "res_unbdd_a": float(info.res_unbdd_a),
+        "res_unbdd_p": float(info.res_unbdd_p),
+        "comp_slack": float(info.comp_slack),
+        "solve_time": float(info.solve_time),
+        "setup_time": float(info.setup_time),
+        "lin_sys_time": float(info.lin_sys_time),
+        "cone_time": float(info.cone_time),
+        "accel_time": float(info.accel_time),
+        "rejected_accel_steps": int(info.rejected_accel_steps),
+        "accepted_accel_steps": int(info.accepted_accel_steps),
+        "status": info.status.decode(),
+        "aa_stats": {
+            "iter": int(aa.iter), "n_accept": int(aa.n_accept),
+            "n_reject_lapack": int(aa.n_reject_lapack), "n_reject_rank0": int(aa.n_reject_rank0),
+            "n_reject_nonfinite": int(aa.n_reject_nonfinite),
+            "n_reject_weight_cap": int(aa.n_reject_weight_cap),
+            "n_safeguard_reject": int(aa.n_safeguard_reject), "last_rank": int(aa.last_rank),
+            "last_aa_norm": float(aa.last_aa_norm),
+            "last_regularization": float(aa.last_regularization),
+        },
+        # extras of this backend (the reference's dict is a subset)
+        "cg_iters": int(info.cg_iters),
+        "lin_sys_solver": info.lin_sys_solver.decode(),
+    }
+
+
 class SCS(object):
     """Raw backend type; `scs.SCS` (scs/__init__.py) is the user-facing wrapper."""
 
@@ -498,42 +541,7 @@ class SCS(object):
             _lib.scs_solve(self._work, C.byref(sol), C.byref(info), 1 if warm_start else 0)
             # fresh copies owning their data (R:scs/scsobject.h:993-1043), taken under the lock
             xo, yo, so = self._x.copy(), self._y.copy(), self._s.copy()
-        aa = info.aa_stats
-        info_dict = {
-            "status_val": int(info.status_val),
-            "iter": int(info.iter),
-            "scale_updates": int(info.scale_updates),
-            "scale": float(info.scale),
-            "pobj": float(info.pobj),
-            "dobj": float(info.dobj),
-            "res_pri": float(info.res_pri),
-            "res_dual": float(info.res_dual),
-            "gap": float(info.gap),
-            "res_infeas": float(info.res_infeas),
-            "res_unbdd_a": float(info.res_unbdd_a),
-            "res_unbdd_p": float(info.res_unbdd_p),
-            "comp_slack": float(info.comp_slack),
-            "solve_time": float(info.solve_time),
-            "setup_time": float(info.setup_time),
-            "lin_sys_time": float(info.lin_sys_time),
-            "cone_time": float(info.cone_time),
-            "accel_time": float(info.accel_time),
-            "rejected_accel_steps": int(info.rejected_accel_steps),
-            "accepted_accel_steps": int(info.accepted_accel_steps),
-            "status": info.status.decode(),
-            "aa_stats": {
-                "iter": int(aa.iter), "n_accept": int(aa.n_accept),
-                "n_reject_lapack": int(aa.n_reject_lapack), "n_reject_rank0": int(aa.n_reject_rank0),
-                "n_reject_nonfinite": int(aa.n_reject_nonfinite),
-                "n_reject_weight_cap": int(aa.n_reject_weight_cap),
-                "n_safeguard_reject": int(aa.n_safeguard_reject), "last_rank": int(aa.last_rank),
-                "last_aa_norm": float(aa.last_aa_norm),
-                "last_regularization": float(aa.last_regularization),
-            },
-            # extras of this backend (the reference's dict is a subset)
-            "cg_iters": int(info.cg_iters),
-            "lin_sys_solver": info.lin_sys_solver.decode(),
-        }
+        info_dict = _info_dict(info)
         return {"x": xo, "y": yo, "s": so, "info": info_dict}
 
     # ----------------------------------------------------------------- update
@@ -612,6 +620,45 @@ class SCS(object):
             with lock:
                 _lib.scs_finish(self._work)
                 self._work = None
+
+
+def solve_batch(solvers, warm_start=False):
+    """Grouped solve of several backend `SCS` objects (include/scs_hip.h: scs_hip_solve_batch): equally shaped
+    problems share every kernel launch of the ADMM loop.  Returns the list of result dicts `solve()` would have
+    returned for each (iterates bit-identical to separate solves).  warm_start uses each object's stored solution."""
+    if not isinstance(warm_start, (bool, np.bool_)):
+        raise TypeError("argument 2 must be bool, not %s" % type(warm_start).__name__)
+    solvers = list(solvers)
+    if not solvers:
+        return []
+    if len(set(id(sv) for sv in solvers)) != len(solvers):
+        raise ValueError("solve_batch: a solver appears twice")
+    for sv in solvers:
+        if not isinstance(sv, SCS):
+            raise TypeError("solve_batch expects scs._scs_hip.SCS objects")
+    ordered = sorted(solvers, key=id)  # one global lock order: two overlapping batches cannot deadlock
+    for sv in ordered:
+        sv._lock.acquire()
+    try:
+        for sv in solvers:
+            if not sv._work:
+                raise ValueError("Workspace not initialized!")
+        cnt = len(solvers)
+        sols = [_ScsSolution(_pd(sv._x), _pd(sv._y), _pd(sv._s)) for sv in solvers]
+        infos = [_ScsInfo() for _ in solvers]
+        works = (C.c_void_p * cnt)(*[sv._work for sv in solvers])
+        solp = (C.POINTER(_ScsSolution) * cnt)(*[C.pointer(so) for so in sols])
+        infp = (C.POINTER(_ScsInfo) * cnt)(*[C.pointer(io) for io in infos])
+        rc = _lib.scs_hip_solve_batch(works, solp, infp, cnt, 1 if warm_start else 0)  # GIL released by ctypes
+        err = last_error() if rc != 0 else ""
+        out = [{"x": sv._x.copy(), "y": sv._y.copy(), "s": sv._s.copy(), "info": _info_dict(io)}
+               for sv, io in zip(solvers, infos)]
+    finally:
+        for sv in ordered:
+            sv._lock.release()
+    if rc != 0:
+        raise RuntimeError("libscs_hip: " + err)
+    return out
 
 
 # ---------------------------------------------------------------- kernel-level entry points (tests, bench)

@@ -444,6 +444,7 @@ struct DeviceAa {
   DevBuf<double> x, f, gprev, S, Y, D, npart, spart, part, out, res, gamma, rbuf[2];
   DevBuf<int> bad;
   double *h_pin = nullptr;  // pinned: 1 + 3 * kAaMaxMem (Gram partial results) / AA_R_COUNT (TSQR verdict)
+  bool owns_pin = true;     // false: h_pin points into the owning workspace's pinned block
   std::vector<double> M;    // Gram path: raw mem x mem system matrix (col-major), maintained incrementally
   ScsAaStats st{};
   bool pending_safeguard = false;
@@ -453,7 +454,7 @@ struct DeviceAa {
   DeviceAa() = default;
   DeviceAa(const DeviceAa &) = delete;
   DeviceAa &operator=(const DeviceAa &) = delete;
-  ~DeviceAa() { if (h_pin) (void)hipHostFree(h_pin); }
+  ~DeviceAa() { if (h_pin && owns_pin) (void)hipHostFree(h_pin); }
 
   static bool tsqr_default() {  // SCS_HIP_AA=gram: incremental Gram update + host solve (A/B, tests)
     const char *e = getenv("SCS_HIP_AA");

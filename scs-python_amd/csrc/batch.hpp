@@ -222,6 +222,9 @@ struct GroupSolve {
   }
 
   int vb(long nelem) const { return vec_blocks(nelem); }
+  // For the duration of the grouped solve a member's flag block (vec.hpp F_*) is its slice of ONE array, so the host
+  // reads every member's CG flags with a single copy and no gather launch
+  int *fl_of(int g) const { return flags_d.p + (size_t)g * F_COUNT; }
 
   // ---- lists: a ring of device slots; a slot is not reused before the host has synchronised at least once
   const int *upload_list(const std::vector<int> &v) {
@@ -261,7 +264,7 @@ struct GroupSolve {
   void set_scale_records(int g) {
     ScsHipWork *w = W[(size_t)g];
     const CsrView Ar = csr_of(w->Ar);
-    int *fl = w->fl.p;
+    int *fl = fl_of(g);
     t_spmv_y.set(g, Ar, w->ws.p, EpiY{w->ut.p + n, w->rdy(), w->v.p + n}, nullptr, nullptr);
     t_spmv_a.set(g, Ar, w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, fl + F_DONE, fl + F_STEP);
     t_set_diag_r.set(g, w->diag_r.p, n, m, w->cone.z, w->stgs.rho_x, w->scale);
@@ -326,7 +329,7 @@ struct GroupSolve {
       const CsrView Pf = has_P ? csr_of(w->Pf) : CsrView{};
       gx_ar = std::max(gx_ar, Ar.nblk); gx_at = std::max(gx_at, At.nblk); gx_pf = std::max(gx_pf, Pf.nblk);
       double *par = params_d.p + (size_t)g * P_COUNT;
-      int *fl = w->fl.p;
+      int *fl = fl_of(g);
       double *uy = w->u.p + n;
       const int *nostall = nullptr;
       t_sumsq.set(g, w->v.p, l, w->part_v.p);
@@ -370,7 +373,7 @@ struct GroupSolve {
                      nullptr, nullptr);
       t_fin_multi_d.set(g, w->part.p, At.nblk, 4, 6, w->out.p + 16);
       t_gather_res.set(g, w->out.p, tau_ptr, w->rsk.p + (l - 1), res_d.p + (size_t)g * kResRec);
-      t_gather_fl.set(g, fl, flags_d.p + (size_t)g * F_COUNT, (int)F_COUNT);
+      t_gather_fl.set(g, w->fl.p, fl, (int)F_COUNT);  // (once, at the start: the member's own flag block -> the group's)
       // scale update
       t_precond.set(g, w->At.rowptr.p, w->At.col.p, w->At.val.p, w->diag_r.p, has_P ? w->Pdiag.p : nullptr, w->cg_M.p, n);
       t_g_rhs.set(g, w->g.p, w->h.p, n, m);
@@ -419,6 +422,11 @@ struct GroupSolve {
     t_pow.gx = ceil_div((long)c0.p.size(), kConeThreads);
     if (mem > 0) t_aa_seed.gx = t_aa_update.gx = t_aa_apply.gx = t_aa_diffsq.gx = t_aa_restore.gx = w0->aa.nbl();
     upload_all();
+    {  // seed the group's flag array from the members' own blocks (the step parity F_STEP carries over)
+      std::vector<int> all((size_t)G);
+      std::iota(all.begin(), all.end(), 0);
+      go(t_gather_fl, upload_list(all), G);
+    }
     sync();  // (records may be rewritten from here on)
   }
 
@@ -437,8 +445,7 @@ struct GroupSolve {
   }
 
   // ---- pieces of the iteration, each over a sub-list of the group ----
-  void read_flags(const int *list, int count) {  // enqueue: every listed member's flag block -> flags_h
-    go(t_gather_fl, list, count);
+  void read_flags(const int *, int) {  // enqueue: every member's flag block -> flags_h
     HIP_CHECK(hipMemcpyAsync(flags_h, flags_d.p, sizeof(int) * F_COUNT * G, hipMemcpyDeviceToHost, s));
   }
   const int *flags_of(int g) const { return flags_h + (size_t)g * F_COUNT; }
@@ -458,25 +465,41 @@ struct GroupSolve {
     go(t_cg_update[variant], list, count);
     go(t_cg_dir[variant], list, count);
   }
-  // run the CG of the listed members to the end (their start is already enqueued, `first_chunk` steps with it);
-  // returns with flags_h holding every listed member's final flags
-  void finish_cg(const std::vector<int> &members, const int *list_d, int first_chunk, int variant, const std::function<void()> &after_first_sync) {
+  // CG steps to enqueue for a set of members whose predicted remaining step counts are `need`: enough for three
+  // quarters of them.  A step enqueued for a member that is already done is a launch of early-exit workgroups — ~20 us
+  // for 512 members — while a second round for the slow quarter costs one host synchronisation (~40 us) and runs on a
+  // quarter of the grid.  (A single member gets exactly its prediction.)
+  static int chunk_for(std::vector<int> &need) {
+    if (need.empty()) return 2;
+    std::sort(need.begin(), need.end());
+    const int c = need[std::min(need.size() - 1, (need.size() * 3) / 4)];
+    return std::max(2, std::min(c, 64));
+  }
+  // run the CG of the listed members to the end (their start is already enqueued); returns with flags_h holding every
+  // listed member's final flags.  predict(g) = steps member g is expected to need in total.
+  void finish_cg(const std::vector<int> &members, const int *list_d, int variant, const std::function<int(int)> &predict,
+                 const std::function<void()> &after_first_sync) {
+    std::vector<int> need;
+    for (int g : members) need.push_back(predict(g));
+    const int first_chunk = chunk_for(need);
     for (int k = 0; k < first_chunk; ++k) cg_step(list_d, (int)members.size(), variant);
     read_flags(list_d, (int)members.size());
     sync();
     if (after_first_sync) after_first_sync();
-    std::vector<int> nd;
     auto collect = [&](const std::vector<int> &from) {
       std::vector<int> out;
       for (int g : from)
         if (!flags_of(g)[F_DONE] && flags_of(g)[F_ITERS] < 10 * n) out.push_back(g);
       return out;
     };
-    nd = collect(members);
+    std::vector<int> nd = collect(members);
     while (!nd.empty()) {
-      int done = 0;
-      for (int g : nd) done = std::max(done, flags_of(g)[F_ITERS]);
-      const int chunk = std::max(2, std::min(std::max(done / 2, 4), 64));
+      need.clear();
+      for (int g : nd) {
+        const int done = flags_of(g)[F_ITERS];
+        need.push_back(std::max(predict(g) - done, std::max(done / 2, 2)));  // (a wrong prediction: grow geometrically)
+      }
+      const int chunk = chunk_for(need);
       const int *ld = upload_list(nd);
       for (int k = 0; k < chunk; ++k) cg_step(ld, (int)nd.size(), variant);
       read_flags(ld, (int)nd.size());
@@ -511,9 +534,7 @@ struct GroupSolve {
     go(t_cg_init, ld, cnt);
     go(t_fin_cg_init, ld, cnt);
     go(t_zero_iters, ld, cnt);
-    int first = 1;
-    for (int g : su) first = std::max(first, std::min(W[(size_t)g]->last_cg_iters + 2, 64));
-    finish_cg(su, ld, first, 1, nullptr);
+    finish_cg(su, ld, 1, [&](int g) { return std::min(4 * W[(size_t)g]->last_cg_iters + 8, 64); }, nullptr);  // (cold, to 1e-12)
     for (int g : su) {
       ScsHipWork *w = W[(size_t)g];
       w->last_cg_iters = flags_of(g)[F_ITERS];
@@ -543,9 +564,12 @@ struct GroupSolve {
     std::iota(active.begin(), active.end(), 0);
     upload_active();
     std::vector<int> tmp_list;
+    const bool stats = getenv("SCS_HIP_GROUP_STATS") != nullptr;
     for (int i = 0; !active.empty(); ++i) {
       ++lockstep_iters;
       const int na = (int)active.size();
+      if (stats && (i % 200 == 0 || (i < 200 && i % 50 == 0)))
+        std::fprintf(stderr, "[scs-hip group] iteration %5d: %4d active, %8.1f ms, %ld launches, %d syncs\n", i, na, now_ms() - t_start, launches, syncs);
       const bool aa_now = mem > 0 && i > 0 && (i % interval == 0);
       double t = now_ms();
       std::vector<int> aa_solved;
@@ -605,10 +629,7 @@ struct GroupSolve {
       if (has_P) go(t_spmv_pws, active_d, na);
       go(t_spmv_r0, active_d, na);
       go(t_fin_head, active_d, na);
-      int chunk = 2;
-      for (int g : active) chunk = std::max(chunk, W[(size_t)g]->recent_cg_max() + 1);
-      chunk = std::min(chunk, 64);
-      finish_cg(active, active_d, chunk, 0, [&] {
+      finish_cg(active, active_d, 0, [&](int g) { return W[(size_t)g]->recent_cg_max() + 1; }, [&] {
         // first synchronisation of the iteration: everything the host deferred
         for (int g : aa_solved) {
           ScsHipWork *w = W[(size_t)g];

@@ -19,6 +19,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "aa.hpp"
 #include "common.hpp"
@@ -47,6 +48,75 @@ static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
+
+// ---------------------------------------------------------------- runtime-object pools
+// Measured on this runtime (tools/api_cost.hip): hipStreamCreate 2.55 ms, hipStreamDestroy 1.6 ms, hipHostFree 0.13 ms,
+// against 0.7 ms of kernels in the scs_init of a config-5 problem — a batch of 512 small problems spent more time
+// creating and destroying streams than solving.  So streams and pinned blocks are pooled per process:
+//  * a workspace takes the LEAST-USED stream of its device's pool; the pool grows (up to SCS_HIP_STREAMS, default 32)
+//    while every stream has a user, so up to that many live workspaces own a stream each — independent instances run
+//    concurrently as before (R:test/test_thread_safety.py:78-93; the device has a handful of hardware queues) — and
+//    beyond it streams are shared (stream order keeps every instance correct; the grouped solve puts its members on
+//    one stream anyway).  Streams are never destroyed.
+//  * one pinned, device-mapped block per workspace holds all its host-side scalars / flags; finished workspaces
+//    return their block to a free list.
+struct StreamPool {
+  struct Dev { std::vector<hipStream_t> streams; std::vector<int> users; };
+  std::mutex mtx;
+  std::vector<Dev> devs;
+  static int cap() {
+    static const int c = [] { const char *e = getenv("SCS_HIP_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
+    return c;
+  }
+  hipStream_t acquire(int device, bool *shared) {
+    std::lock_guard<std::mutex> g(mtx);
+    if ((int)devs.size() <= device) devs.resize((size_t)device + 1);
+    Dev &d = devs[(size_t)device];
+    int best = -1;
+    for (size_t i = 0; i < d.streams.size(); ++i)
+      if (best < 0 || d.users[i] < d.users[(size_t)best]) best = (int)i;
+    if ((best < 0 || d.users[(size_t)best] > 0) && (int)d.streams.size() < cap()) {
+      hipStream_t st = nullptr;
+      HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      d.streams.push_back(st);
+      d.users.push_back(0);
+      best = (int)d.streams.size() - 1;
+    }
+    *shared = d.users[(size_t)best] > 0;
+    d.users[(size_t)best]++;
+    return d.streams[(size_t)best];
+  }
+  void release(int device, hipStream_t st) {
+    std::lock_guard<std::mutex> g(mtx);
+    if ((int)devs.size() <= device) return;
+    Dev &d = devs[(size_t)device];
+    for (size_t i = 0; i < d.streams.size(); ++i)
+      if (d.streams[i] == st && d.users[i] > 0) { d.users[i]--; return; }
+  }
+};
+static StreamPool g_streams;
+
+constexpr size_t kPinnedBlockBytes = 8192;
+struct PinnedPool {
+  std::mutex mtx;
+  std::vector<void *> free_blocks;
+  void *acquire() {
+    {
+      std::lock_guard<std::mutex> g(mtx);
+      if (!free_blocks.empty()) { void *p = free_blocks.back(); free_blocks.pop_back(); return p; }
+    }
+    void *p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, kPinnedBlockBytes, hipHostMallocMapped));
+    return p;
+  }
+  void release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mtx);
+    if (free_blocks.size() < 4096) { free_blocks.push_back(p); return; }
+    (void)hipHostFree(p);
+  }
+};
+static PinnedPool g_pinned;
 
 // ---------------------------------------------------------------- device CSR
 struct DeviceCsr {
@@ -428,6 +498,7 @@ static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, c
 
 // ============================================================== workspace
 struct ScsHipWork {
+  std::unique_ptr<Arena> arena;  // small problems: all device buffers of the workspace come from here (FIRST member: destroyed last)
   int device = 0;  // the HIP device this workspace (stream, buffers, events) lives on
   int n = 0, m = 0;
   long l = 0;
@@ -442,7 +513,8 @@ struct ScsHipWork {
   std::string log_csv_filename, write_data_filename;
 
   hipStream_t stream = nullptr;
-  bool owns_stream = true;
+  bool owns_stream = true, pooled_stream = false, stream_shared = false;
+  void *pinned_block = nullptr;  // all pinned host scalars / flags of the workspace (g_pinned)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   double *h_pin = nullptr;  // pinned scalars
   int *h_flags = nullptr;   // pinned flags
@@ -621,15 +693,20 @@ struct ScsHipWork {
     for (auto &g : g_pre) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : g_cg) if (g) (void)hipGraphExecDestroy(g);
     if (g_post) (void)hipGraphExecDestroy(g_post);
-    if (h_pin) (void)hipHostFree(h_pin);
-    if (h_flags) (void)hipHostFree(h_flags);
-    if (h_params_base) (void)hipHostFree(h_params_base);
-    for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
+    if (pinned_block) {
+      g_pinned.release(pinned_block);
+    } else {  // (stack workspaces of the kernel-level entry points allocate what they need themselves)
+      if (h_pin) (void)hipHostFree(h_pin);
+      if (h_flags) (void)hipHostFree(h_flags);
+      if (h_params_base) (void)hipHostFree(h_params_base);
+      for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
+    }
     for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
     for (auto &es : ev_prof) for (auto &e : es) if (e) (void)hipEventDestroy(e);
     for (auto &es : ev_cone) for (auto &e : es) if (e) (void)hipEventDestroy(e);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-    if (stream && owns_stream) (void)hipStreamDestroy(stream);
+    if (stream && pooled_stream) g_streams.release(device, stream);
+    else if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
 
   // -------------------------------------------------------------- helpers
@@ -1592,19 +1669,6 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   for (double x : w->b_orig) w->nm_b_orig = std::max(w->nm_b_orig, std::fabs(x));
   for (double x : w->c_orig) w->nm_c_orig = std::max(w->nm_c_orig, std::fabs(x));
 
-  HIP_CHECK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
-  for (auto &e : w->ev) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipHostMalloc((void **)&w->h_pin, sizeof(double) * 256));
-  HIP_CHECK(hipHostMalloc((void **)&w->h_flags, sizeof(int) * F_COUNT));
-  HIP_CHECK(hipHostMalloc((void **)&w->h_params_base, sizeof(double) * 2 * P_COUNT, hipHostMallocMapped));
-  HIP_CHECK(hipHostGetDevicePointer((void **)&w->d_params_base, w->h_params_base, 0));
-  std::memset(w->h_params_base, 0, sizeof(double) * 2 * P_COUNT);
-  w->h_params = w->h_params_base;
-  w->d_params = w->d_params_base;
-  for (int i = 0; i < 2; ++i) {
-    HIP_CHECK(hipHostMalloc((void **)&w->h_flags_slot[i], sizeof(int) * F_COUNT));
-    HIP_CHECK(hipEventCreateWithFlags(&w->ev_iter[i], hipEventDisableTiming));
-  }
   {
     const char *env = getenv("SCS_HIP_GRAPH");  // "0" keeps every launch eager (A/B measurements)
     w->graphs_enabled = !(env && env[0] == '0');
@@ -1612,7 +1676,42 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     w->pipelined = !(envp && envp[0] == '0');
     if (const char *envc = getenv("SCS_HIP_PIPE_CHUNK")) w->pipe_chunk_override = std::max(0, atoi(envc));
   }
+  if (!w->pipelined && w->graphs_enabled) {  // hipGraph capture needs a stream nobody else enqueues on: a private one
+    HIP_CHECK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+  } else {
+    w->stream = g_streams.acquire(w->device, &w->stream_shared);
+    w->pooled_stream = true;
+  }
+  for (auto &e : w->ev) HIP_CHECK(hipEventCreate(&e));
+  {  // one pinned, device-mapped block: [h_pin 256 f64 | AA h_pin 256 f64 | params 2 x P_COUNT f64 | flags 3 x F_COUNT i32]
+    char *blk = (char *)g_pinned.acquire();
+    w->pinned_block = blk;
+    std::memset(blk, 0, kPinnedBlockBytes);
+    w->h_pin = (double *)blk;
+    w->aa.h_pin = (double *)blk + 256;
+    w->aa.owns_pin = false;
+    w->h_params_base = (double *)blk + 512;
+    w->h_flags = (int *)((double *)blk + 512 + 2 * P_COUNT);
+    w->h_flags_slot[0] = w->h_flags + F_COUNT;
+    w->h_flags_slot[1] = w->h_flags + 2 * F_COUNT;
+    static_assert((512 + 2 * P_COUNT) * sizeof(double) + 3 * F_COUNT * sizeof(int) <= kPinnedBlockBytes, "pinned block too small");
+    HIP_CHECK(hipHostGetDevicePointer((void **)&w->d_params_base, w->h_params_base, 0));
+  }
+  w->h_params = w->h_params_base;
+  w->d_params = w->d_params_base;
+  for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&w->ev_iter[i], hipEventDisableTiming));
   hipStream_t s = w->stream;
+  // small problems (config 5: a batch of them) take their device memory from one arena (common.hpp) instead of ~100
+  // separate allocations; SCS_HIP_ARENA=0 restores exact allocations (A/B)
+  {
+    const char *ea = getenv("SCS_HIP_ARENA");
+    const long annz = d->A->p[n];
+    if (!(ea && ea[0] == '0') && annz <= (1L << 18) && w->l <= (1L << 17)) {
+      w->arena.reset(new Arena());
+      w->arena->stream = s;
+    }
+  }
+  ArenaScope arena_scope(w->arena.get());
   const bool setup_timing = getenv("SCS_HIP_SETUP_TIMING") != nullptr;  // diagnostics: where does scs_init spend its time
   double t_mark = now_ms();
   auto mark = [&](const char *what) {
@@ -1977,8 +2076,57 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
 
 // Grouped solve of `count` workspaces (include/scs_hip.h): members that can share launches — same shape, CSR-stream
 // layouts, one-launch cone kernels (GroupSolve::member_ok / same_shape) — advance in lock step through the grouped
-// kernels of batch.hpp; the others are solved one after the other by scs_solve's own loop.  Every info[i] / sol[i] is
-// filled exactly as scs_solve(w[i], sol[i], info[i], warm_start) would (iterates are bit-identical).
+// kernels of batch.hpp; the others are solved by scs_solve's own loop.  Every info[i] / sol[i] is filled exactly as
+// scs_solve(w[i], sol[i], info[i], warm_start) would (iterates are bit-identical).
+// A shape class is one group (up to SCS_HIP_GROUP_MAX members, default 1024).  Cutting it into several groups that run
+// concurrently — one host thread and one stream each, SCS_HIP_GROUP_LANES > 1 — was built and measured (512 config-5
+// problems, solve phase): 1 x 512: 4.0 s, 4 x 128: 4.2 s, 8 x 64: 6.4 s, 8 lanes of 32: 10.7 s — launches and
+// synchronisations issued from several host threads contend inside the HIP runtime, as the one-stream-per-problem
+// mode showed before (profiles/r02_batch_queues.txt) => off by default.
+static scs_int solve_one_group(ScsWork **works, ScsSolution **sols, ScsInfo **infos, const std::vector<int> &idx, scs_int warm_start,
+                               std::string &err) {
+  if (idx.size() == 1) {
+    const int i = idx[0];
+    const scs_int st = scs_solve(works[i], sols[i], infos[i], warm_start);
+    if (st == SCS_FAILED) { err = scs_hip_last_error(); return -1; }
+    return 0;
+  }
+  scs_int rc = 0;
+  std::vector<std::unique_lock<std::mutex>> locks;
+  std::vector<hipStream_t> saved;
+  GroupSolve gs;
+  try {
+    for (int j : idx) locks.emplace_back(works[j]->mtx);
+    HIP_CHECK(hipSetDevice(works[idx[0]]->device));
+    gs.s = works[idx[0]]->stream;
+    for (int j : idx) {
+      gs.W.push_back(works[j]); gs.sols.push_back(sols[j]); gs.infos.push_back(infos[j]);
+      saved.push_back(works[j]->stream);
+      works[j]->stream = gs.s;  // every member's kernels go to the group's stream for the duration of the solve
+      works[j]->aa.stream = gs.s;
+    }
+    gs.build();
+    gs.run(warm_start);
+  } catch (const std::exception &e) {
+    err = e.what();
+    rc = -1;
+    (void)hipStreamSynchronize(gs.s);
+    for (int j : idx)
+      if (infos[j]->status_val == SCS_UNFINISHED || infos[j]->status[0] == 0) {
+        infos[j]->status_val = SCS_FAILED;
+        std::snprintf(infos[j]->status, sizeof(infos[j]->status), "failure");
+        fill_nan(sols[j]->x, works[j]->n);
+        fill_nan(sols[j]->y, works[j]->m);
+        fill_nan(sols[j]->s, works[j]->m);
+      }
+  }
+  for (size_t k = 0; k < saved.size(); ++k) {
+    works[idx[k]]->stream = saved[k];
+    works[idx[k]]->aa.stream = saved[k];
+  }
+  return rc;
+}
+
 scs_int scs_hip_solve_batch(ScsWork **works, ScsSolution **sols, ScsInfo **infos, scs_int count, scs_int warm_start) {
   if (!works || !sols || !infos || count < 0) return -1;
   set_last_error("");
@@ -1987,57 +2135,59 @@ scs_int scs_hip_solve_batch(ScsWork **works, ScsSolution **sols, ScsInfo **infos
     for (int j = 0; j < i; ++j)
       if (works[j] == works[i]) { set_last_error("scs_hip_solve_batch: a workspace appears twice"); return -1; }
   }
-  static const int group_max = [] { const char *e = getenv("SCS_HIP_GROUP_MAX"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
+  const int group_max = env_int("SCS_HIP_GROUP_MAX", 1024), lanes = env_int("SCS_HIP_GROUP_LANES", 1),
+            group_min = env_int("SCS_HIP_GROUP_MIN", 16);
+  // shape classes, then groups
+  std::vector<std::vector<int>> jobs;
   std::vector<char> taken((size_t)count, 0);
-  scs_int rc = 0;
   for (int i = 0; i < count; ++i) {
     if (taken[(size_t)i]) continue;
     taken[(size_t)i] = 1;
-    std::vector<int> idx{i};
+    std::vector<int> cls{i};
     if (group_max > 1 && GroupSolve::member_ok(works[i]))
-      for (int j = i + 1; j < count && (int)idx.size() < group_max; ++j)
+      for (int j = i + 1; j < count; ++j)
         if (!taken[(size_t)j] && GroupSolve::member_ok(works[j]) && GroupSolve::same_shape(works[i], works[j])) {
           taken[(size_t)j] = 1;
-          idx.push_back(j);
+          cls.push_back(j);
         }
-    if (idx.size() == 1) {
-      if (scs_solve(works[i], sols[i], infos[i], warm_start) == SCS_FAILED) rc = -1;
-      continue;
-    }
-    std::vector<std::unique_lock<std::mutex>> locks;
-    std::vector<hipStream_t> saved;
-    GroupSolve gs;
-    try {
-      for (int j : idx) locks.emplace_back(works[j]->mtx);
-      HIP_CHECK(hipSetDevice(works[i]->device));
-      gs.s = works[i]->stream;
-      for (int j : idx) {
-        gs.W.push_back(works[j]); gs.sols.push_back(sols[j]); gs.infos.push_back(infos[j]);
-        saved.push_back(works[j]->stream);
-        works[j]->stream = gs.s;  // every member's kernels go to the group's stream for the duration of the solve
-        works[j]->aa.stream = gs.s;
-      }
-      gs.build();
-      gs.run(warm_start);
-    } catch (const std::exception &e) {
-      set_last_error(e.what());
-      rc = -1;
-      (void)hipStreamSynchronize(gs.s);
-      for (int j : idx)
-        if (infos[j]->status_val == SCS_UNFINISHED || infos[j]->status[0] == 0) {
-          infos[j]->status_val = SCS_FAILED;
-          std::snprintf(infos[j]->status, sizeof(infos[j]->status), "failure");
-          fill_nan(sols[j]->x, works[j]->n);
-          fill_nan(sols[j]->y, works[j]->m);
-          fill_nan(sols[j]->s, works[j]->m);
-        }
-    }
-    for (size_t k = 0; k < saved.size(); ++k) {
-      works[idx[k]]->stream = saved[k];
-      works[idx[k]]->aa.stream = saved[k];
+    const int S = (int)cls.size();
+    int k = std::max((S + group_max - 1) / group_max, lanes > 1 ? std::min(lanes, S / group_min) : 1);
+    k = std::max(1, std::min(k, S));
+    for (int part = 0; part < k; ++part) {  // contiguous, near-equal parts
+      const int lo = (int)((long)S * part / k), hi = (int)((long)S * (part + 1) / k);
+      jobs.emplace_back(cls.begin() + lo, cls.begin() + hi);
     }
   }
-  return rc;
+  std::stable_sort(jobs.begin(), jobs.end(), [](const std::vector<int> &a, const std::vector<int> &b) { return a.size() > b.size(); });
+  const int nthreads = std::max(1, std::min(lanes, (int)jobs.size()));
+  std::atomic<size_t> next{0};
+  std::atomic<int> rc_all{0};
+  std::mutex err_mtx;
+  std::string first_err;
+  const int dflt_dev = current_device();
+  auto worker = [&]() {
+    (void)hipSetDevice(dflt_dev);
+    while (true) {
+      const size_t j = next.fetch_add(1);
+      if (j >= jobs.size()) break;
+      std::string err;
+      if (solve_one_group(works, sols, infos, jobs[j], warm_start, err) != 0) {
+        rc_all.store(-1);
+        std::lock_guard<std::mutex> g(err_mtx);
+        if (first_err.empty()) first_err = err;
+      }
+    }
+  };
+  if (nthreads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+  }
+  if (rc_all.load() != 0) set_last_error(first_err);
+  return rc_all.load();
 }
 
 scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {

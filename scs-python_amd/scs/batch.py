@@ -10,6 +10,11 @@ With RCCL the payload lives in HBM from the start: every solve copies its (x, y,
 device from the solver's buffers into its row of the payload tensor (scs_hip_solution_to_device)
 and only the 8 header scalars go up from the host — the gather reads the solutions where they are.
 
+Inside a rank the local shard is solved as ONE grouped solve (scs.solve_batch -> scs_hip_solve_batch,
+csrc/batch.hpp): equally shaped problems advance through the ADMM loop in lock step and share every
+kernel launch, which is what lifts small problems off the command-queue ceiling of "one problem per
+stream" (grouped=False restores that mode: `threads` solves in flight, one stream each).
+
     results = solve_sharded(problems)            # under torchrun, one rank per GPU
     # rank 0: list of dicts (x, y, s, info-subset) in the original order; other ranks: None
 
@@ -51,13 +56,10 @@ def unpack_result(row):
                      "dobj": float(row[5]), "solve_time": float(row[6]), "cg_iters": int(row[7])}}
 
 
-def _solve_into_row(data, cone, settings, row):
-    """default backend, device-resident result: solve, then x | y | s straight from the solver's HBM buffers into
-    `row` (a float64 CUDA tensor slice), header from the host.  Returns the info dict."""
-    import scs
+def _fill_row(solver, sol, row):
+    """x | y | s of the solver's last solve straight from its HBM buffers into `row` (a float64 CUDA tensor slice),
+    header from the host"""
     import torch
-    solver = scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
-    sol = solver.solve()
     info = sol["info"]
     n, m = sol["x"].size, sol["y"].size
     base = row.data_ptr() + 8 * _HDR
@@ -68,15 +70,48 @@ def _solve_into_row(data, cone, settings, row):
     return info
 
 
-def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
+def _solve_into_row(data, cone, settings, row):
+    """default backend, device-resident result: solve, then hand the result over in HBM.  Returns the info dict."""
+    import scs
+    solver = scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
+    return _fill_row(solver, solver.solve(), row)
+
+
+def _grouped_local_solve(local_problems, threads, timing=None):
+    """the local shard as one grouped solve: workspaces are set up `threads` at a time (scs_init releases the GIL),
+    then ONE scs.solve_batch call.  Returns (solvers, results)."""
+    import time
+    import scs
+    t0 = time.perf_counter()
+
+    def make(p):
+        data, cone, settings = p
+        return scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
+
+    if threads > 1 and len(local_problems) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            solvers = list(pool.map(make, local_problems))
+    else:
+        solvers = [make(p) for p in local_problems]
+    t1 = time.perf_counter()
+    results = scs.solve_batch(solvers)
+    if timing is not None:
+        timing["init_s"] = t1 - t0
+        timing["solve_s"] = time.perf_counter() - t1
+    return solvers, results
+
+
+def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1, grouped=True, timing=None):
     """problems: list of (data, cone, settings) — every rank passes the same list (or at least the
     same length and `dims` = [(n, m), ...]); only its own shard is touched.  Returns the ordered
     result list on rank 0 and None elsewhere.  Works without torch.distributed (world = 1).
 
-    threads > 1 solves that many problems of the local shard concurrently: every SCS instance owns
-    its HIP stream and lock and the backend releases the GIL for the whole solve (the reference's
-    contract for independent instances, R:test/test_thread_safety.py:78-93), so small problems —
-    whose kernels cannot fill 256 CUs — overlap on the device: "one problem per stream"."""
+    Default backend: the local shard is one grouped solve (see the module docstring); `threads` workspaces are
+    set up concurrently.  grouped=False (or an injected solve_fn): threads > 1 solves that many problems of the
+    local shard concurrently — every SCS instance owns its HIP stream and lock and the backend releases the GIL for
+    the whole solve (the reference's contract for independent instances, R:test/test_thread_safety.py:78-93):
+    "one problem per stream".  timing: optional dict, receives {"init_s", "solve_s"} of the local shard (grouped mode)."""
     import torch
     import torch.distributed as dist
 
@@ -97,7 +132,16 @@ def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
             device = torch.device("cuda", torch.cuda.current_device())
         payload = torch.zeros((per_rank, width), dtype=torch.float64, device=device)
         torch.cuda.synchronize(device)
-        if threads > 1 and len(mine) > 1:
+        if grouped:
+            import time
+            t0 = time.perf_counter()
+            solvers, results = _grouped_local_solve([problems[i] for i in mine], threads, timing)
+            for slot, (sv, res) in enumerate(zip(solvers, results)):
+                _fill_row(sv, res, payload[slot])
+            if timing is not None:
+                timing["local_s"] = time.perf_counter() - t0
+            del solvers
+        elif threads > 1 and len(mine) > 1:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=threads) as pool:
                 futs = [pool.submit(_solve_into_row, *problems[i], payload[slot]) for slot, i in enumerate(mine)]
@@ -118,7 +162,18 @@ def solve_sharded(problems, solve_fn=None, dims=None, device=None, threads=1):
                 out[i] = unpack_result(arr[slot])
         return out
     block = np.zeros((per_rank, width), dtype=np.float64)
-    if threads > 1 and len(mine) > 1:
+    if device_rows and grouped:
+        import time
+        t0 = time.perf_counter()
+        solvers, results = _grouped_local_solve([problems[i] for i in mine], threads, timing)
+        t1 = time.perf_counter()
+        for slot, res in enumerate(results):
+            block[slot] = pack_result(res, width)
+        if timing is not None:
+            timing["local_s"] = time.perf_counter() - t0
+            timing["pack_s"] = time.perf_counter() - t1
+        del solvers
+    elif threads > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=threads) as pool:
             futs = [pool.submit(solve_fn, *problems[i]) for i in mine]

@@ -27,6 +27,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* OSCS_OMP (oracle/Makefile target liboscs_omp.so): the all-core TIMING variant of the oracle (bench.py cpu_baseline).
+ * Element-wise loops and the mat-vecs run on OpenMP threads (per-row / per-column sums keep their order), reductions
+ * become tree sums: results agree with the sequential checker to rounding, not bit for bit — the tests use liboscs.so. */
+#ifdef OSCS_OMP
+#include <omp.h>
+#define O_PRAGMA(x) _Pragma(#x)
+#define O_PAR_FOR(n) O_PRAGMA(omp parallel for schedule(static) if ((n) > 16384))
+#define O_PAR_SUM(n, v) O_PRAGMA(omp parallel for schedule(static) reduction(+ : v) if ((n) > 16384))
+#define O_PAR_MAX(n, v) O_PRAGMA(omp parallel for schedule(static) reduction(max : v) if ((n) > 16384))
+#else
+#define O_PAR_FOR(n)
+#define O_PAR_SUM(n, v)
+#define O_PAR_MAX(n, v)
+#endif
+
 #define OMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define OMIN(a, b) (((a) < (b)) ? (a) : (b))
 #define OABS(x) (((x) < 0) ? -(x) : (x))

@@ -234,6 +234,7 @@ scs_int oscs_update(void *work, const scs_float *b, const scs_float *c) {
 
 static scs_float dot_r(const OWork *w, const scs_float *x, const scs_float *y) {
   scs_float ip = 0.;
+  O_PAR_SUM(w->l, ip)
   for (scs_int i = 0; i < w->l - 1; ++i) ip += x[i] * y[i] * w->diag_r[i];
   return ip;
 }
@@ -250,6 +251,7 @@ static scs_int project_lin_sys(OWork *w, scs_int iter) {
   scs_int n = w->n, l = w->l, i, status;
   scs_float *warm = NULL, tol = -1.0;
   memcpy(w->u_t, w->v, l * sizeof(scs_float));
+  O_PAR_FOR(l)
   for (i = 0; i < l - 1; ++i) w->u_t[i] *= (i < n ? 1 : -1) * w->diag_r[i];
   if (w->indirect) {
     scs_float nm_ws;
@@ -270,6 +272,7 @@ static scs_int project_lin_sys(OWork *w, scs_int iter) {
 
 static scs_int project_cones(OWork *w, scs_int iter) {
   scs_int i, n = w->n, l = w->l, status;
+  O_PAR_FOR(l)
   for (i = 0; i < l; ++i) w->u[i] = 2 * w->u_t[i] - w->v[i];
   status = o_proj_dual_cone(&w->u[n], w->cone, &w->diag_r[n]);
   if (iter < O_FEASIBLE_ITERS) w->u[l - 1] = 1.0;
@@ -530,6 +533,7 @@ scs_int oscs_solve(void *work, ScsSolution *sol, ScsInfo *info, scs_int warm_sta
     t = now_ms();
     if (project_cones(w, i) < 0) { info->status_val = SCS_FAILED; break; }
     t_cone += now_ms() - t;
+    O_PAR_FOR(l)
     for (scs_int j = 0; j < l; ++j) w->rsk[j] = (w->v[j] + w->u[j] - 2 * w->u_t[j]) * w->diag_r[j];
     if (i % O_CONVERGED_INTERVAL == 0) {
       populate_residual_struct(w, i);
@@ -537,6 +541,7 @@ scs_int oscs_solve(void *work, ScsSolution *sol, ScsInfo *info, scs_int warm_sta
       if (w->stgs.time_limit_secs > 0 && (now_ms() - t_start) > 1e3 * w->stgs.time_limit_secs) break;
     }
     if (w->stgs.adaptive_scale && i == w->r_orig.last_iter) update_scale(w, i);
+    O_PAR_FOR(l)
     for (scs_int j = 0; j < l; ++j) w->v[j] += w->stgs.alpha * (w->u[j] - w->u_t[j]);
     if (w->stgs.acceleration_lookback > 0 && i > 0 && i % w->stgs.acceleration_interval == 0) {
       t = now_ms();

@@ -8,12 +8,14 @@
 
 scs_float o_dot(const scs_float *x, const scs_float *y, scs_int n) {
   scs_float s = 0.;
+  O_PAR_SUM(n, s)
   for (scs_int i = 0; i < n; ++i) s += x[i] * y[i];
   return s;
 }
 
 scs_float o_norm_inf(const scs_float *x, scs_int n) {
   scs_float mx = 0.;
+  O_PAR_MAX(n, mx)
   for (scs_int i = 0; i < n; ++i) {
     scs_float a = OABS(x[i]);
     if (a > mx) mx = a;
@@ -24,10 +26,12 @@ scs_float o_norm_inf(const scs_float *x, scs_int n) {
 scs_float o_norm_2(const scs_float *x, scs_int n) { return sqrt(o_dot(x, x, n)); }
 
 void o_axpy(scs_float *y, const scs_float *x, scs_float a, scs_int n) {
+  O_PAR_FOR(n)
   for (scs_int i = 0; i < n; ++i) y[i] += a * x[i];
 }
 
 void o_scale(scs_float *x, scs_float a, scs_int n) {
+  O_PAR_FOR(n)
   for (scs_int i = 0; i < n; ++i) x[i] *= a;
 }
 
@@ -41,6 +45,7 @@ void o_accum_by_a(const ScsMatrix *A, const scs_float *x, scs_float *y) {
 
 /* y += A' x : column-major gather */
 void o_accum_by_atrans(const ScsMatrix *A, const scs_float *x, scs_float *y) {
+  O_PAR_FOR(A->n)
   for (scs_int j = 0; j < A->n; ++j) {
     scs_float acc = 0.;
     for (scs_int p = A->p[j]; p < A->p[j + 1]; ++p) acc += A->x[p] * x[A->i[p]];

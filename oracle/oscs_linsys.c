@@ -36,6 +36,9 @@ struct OLinSys {
   /* ---- indirect ---- */
   scs_float *p, *r, *Gp, *z, *M, *tmp;
   long tot_cg_its;
+  /* all-core timing variant only (OSCS_OMP): CSR copy of A for the row-parallel A x */
+  scs_int *csr_p, *csr_j;
+  scs_float *csr_x;
 };
 
 /* ------------------------------------------------------------------ MD  */
@@ -262,12 +265,24 @@ static void set_preconditioner(OLinSys *w) {
 static void mat_vec(OLinSys *w, const scs_float *x, scs_float *y) {
   scs_int i;
   scs_float *z = w->tmp;
-  memset(z, 0, w->m * sizeof(scs_float));
   memset(y, 0, w->n * sizeof(scs_float));
   if (w->P) o_accum_by_p(w->P, x, y);
+#ifdef OSCS_OMP
+  /* all-core timing variant: A x by rows over a CSR copy (each row summed in ascending column order, as the CSC
+   * scatter below does) */
+  O_PAR_FOR(w->m)
+  for (i = 0; i < w->m; ++i) {
+    scs_float acc = 0.;
+    for (scs_int q = w->csr_p[i]; q < w->csr_p[i + 1]; ++q) acc += w->csr_x[q] * x[w->csr_j[q]];
+    z[i] = acc / w->diag_r[w->n + i];
+  }
+#else
+  memset(z, 0, w->m * sizeof(scs_float));
   o_accum_by_a(w->A, x, z);
   for (i = 0; i < w->m; ++i) z[i] /= w->diag_r[w->n + i];
+#endif
   o_accum_by_atrans(w->A, z, y);
+  O_PAR_FOR(w->n)
   for (i = 0; i < w->n; ++i) y[i] += w->diag_r[i] * x[i];
 }
 
@@ -284,6 +299,7 @@ static scs_int pcg(OLinSys *w, const scs_float *s, scs_float *b, scs_int max_its
     memcpy(b, s, n * sizeof(scs_float));
   }
   if (o_norm_inf(r, n) < OMAX(tol, 1e-12)) return 0;
+  O_PAR_FOR(n)
   for (j = 0; j < n; ++j) z[j] = M[j] * r[j];
   ztr = o_dot(z, r, n);
   memcpy(p, z, n * sizeof(scs_float));
@@ -293,6 +309,7 @@ static scs_int pcg(OLinSys *w, const scs_float *s, scs_float *b, scs_int max_its
     o_axpy(b, p, alpha, n);
     o_axpy(r, Gp, -alpha, n);
     if (o_norm_inf(r, n) < tol) return i + 1;
+    O_PAR_FOR(n)
     for (j = 0; j < n; ++j) z[j] = M[j] * r[j];
     ztr_prev = ztr;
     ztr = o_dot(z, r, n);
@@ -316,6 +333,26 @@ OLinSys *o_init_lin_sys(const ScsMatrix *A, const ScsMatrix *P, const scs_float 
     w->M = (scs_float *)calloc(w->n, sizeof(scs_float));
     w->tmp = (scs_float *)calloc(w->m, sizeof(scs_float));
     set_preconditioner(w);
+#ifdef OSCS_OMP
+    {  /* CSR copy of (the current, equilibrated) A */
+      const scs_int nnz = A->p[A->n];
+      scs_int j, q, *cur;
+      w->csr_p = (scs_int *)calloc(w->m + 1, sizeof(scs_int));
+      w->csr_j = (scs_int *)malloc(OMAX(nnz, 1) * sizeof(scs_int));
+      w->csr_x = (scs_float *)malloc(OMAX(nnz, 1) * sizeof(scs_float));
+      for (q = 0; q < nnz; ++q) w->csr_p[A->i[q] + 1]++;
+      for (j = 0; j < w->m; ++j) w->csr_p[j + 1] += w->csr_p[j];
+      cur = (scs_int *)malloc(OMAX(w->m, 1) * sizeof(scs_int));
+      memcpy(cur, w->csr_p, w->m * sizeof(scs_int));
+      for (j = 0; j < A->n; ++j)
+        for (q = A->p[j]; q < A->p[j + 1]; ++q) {
+          const scs_int dst = cur[A->i[q]]++;
+          w->csr_j[dst] = j;
+          w->csr_x[dst] = A->x[q];
+        }
+      free(cur);
+    }
+#endif
     return w;
   }
   build_kkt(w);
@@ -370,5 +407,6 @@ void o_free_lin_sys(OLinSys *w) {
   free(w->Lp); free(w->Li); free(w->Parent); free(w->Lnz); free(w->Flag); free(w->Pattern);
   free(w->Lx); free(w->D); free(w->Y); free(w->bp); free(w->diag_base);
   free(w->p); free(w->r); free(w->Gp); free(w->z); free(w->M); free(w->tmp);
+  free(w->csr_p); free(w->csr_j); free(w->csr_x);
   free(w);
 }

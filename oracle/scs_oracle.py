@@ -15,7 +15,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboscs.so")
+# OSCS_LIB=omp (set before the first call, bench.py's all-core CPU leg only): the OpenMP TIMING build of the same
+# sources — element-wise loops / mat-vecs on all cores, tree reductions; the tests always use the sequential checker
+_OMP = os.environ.get("OSCS_LIB", "") == "omp"
+_LIB_PATH = os.path.join(_HERE, "liboscs_omp.so" if _OMP else "liboscs.so")
 
 c_int, c_dbl = C.c_int, C.c_double
 PI, PD = C.POINTER(c_int), C.POINTER(c_dbl)
@@ -72,7 +75,7 @@ class ScsInfo(C.Structure):
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "liboscs.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -113,8 +113,11 @@ def workload(name):
         return {"l": 2000000}, 1000000, 20, 12
     if name == "config4_psd":     # BASELINE.json configs[3]: PSD-heavy, 50 matrices of order 200 + l
         return {"l": 1000, "s": [200] * 50}, 335000, 30, 4
-    if name == "config3_mixed":   # BASELINE.json configs[2] without the box cone (bench leg; the tests add it)
-        return {"z": 100000, "l": 300000, "q": [20] * 5000, "ep": 50000, "ed": 50000, "p": [0.5, -0.5, 0.3] * 11111}, 500000, 20, 3
+    if name == "config3_mixed":   # BASELINE.json configs[2]: z / l / box (99,999 bounds) / q / ep / ed / p, m = 999,999
+        rng = np.random.default_rng(3)
+        return {"z": 100000, "l": 300000, "bu": rng.uniform(0.5, 2.0, 99999).tolist(), "bl": (-rng.uniform(0.5, 2.0, 99999)).tolist(),
+                "q": [20] * 5000, "ep": 50000, "ed": 50000,
+                "p": (rng.uniform(0.1, 0.9, 33333) * rng.choice([-1.0, 1.0], 33333)).tolist()}, 500000, 20, 3
     if name == "small_lp_soc":    # smoke / CI size
         return {"l": 2000, "q": [10] * 200}, 2000, 20, 7
     if name == "config5_small":   # one problem of the 512-problem batch

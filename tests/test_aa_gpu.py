@@ -312,8 +312,12 @@ def test_full_solve_acceleration_counts_track_oracle(hip, oracle, aa_mode, type1
     assert ri["iter"] >= 300 and gi["iter"] >= 300
     ga, ra = gi["aa_stats"], ri["aa_stats"]
     assert ga["n_accept"] > 0 and ra["n_accept"] > 0
-    # (observed: identical counts for lp_soc; the mixed-cone QP is more chaotic — Anderson steps amplify last-bit
-    # differences of the reductions — so it gets a wider margin)
+    # (observed: identical counts for lp_soc.  The mixed-cone QP is chaotic under acceleration: Anderson steps amplify
+    # last-bit differences of the reductions.  Seed sweep, profiles/r03_aa_drift_sweep.txt (tools/dbg/aa_drift_sweep.py,
+    # seeds 5..12, both types): HIP vs the oracle's CG variant -28 % .. +34 % (one outlier +80 %), median |drift| 10 % —
+    # and the oracle against ITSELF, LDL' vs CG linear solves on the same instances, -57 % .. +23 %.  The margin below is
+    # what this instance (seed 5: +11 % / -10 %) needs with room for a different reduction order, not a claim about
+    # the method.)
     tol = 0.1 if case == "lp_soc" else 0.4
     assert abs(gi["iter"] - ri["iter"]) <= tol * ri["iter"] + 25, (gi["iter"], ri["iter"])
     assert abs(ga["n_accept"] - ra["n_accept"]) <= tol * ra["iter"] + 2, (ga, ra)

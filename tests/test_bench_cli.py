@@ -40,7 +40,7 @@ def test_gpus_2_spawns_two_ranks_on_one_gpu_box():
     0 with the gloo backend (a 1-GPU box); rank 0 prints the one JSON line with n_gpus = 2 = the world size it saw,
     the batch leg covers every problem exactly once across the ranks."""
     cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "2", "--workload", "config2_lp_soc",
-           "--dist-backend", "gloo", "--force-device", "0", "--batch-problems", "12", "--batch-threads", "4"]
+           "--dist-backend", "gloo", "--force-device", "0", "--batch-problems", "12", "--batch-threads", "4", "--no-other-configs"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
@@ -57,7 +57,7 @@ def test_gpus_2_spawns_two_ranks_on_one_gpu_box():
 @pytest.mark.gpu
 def test_single_gpu_line_has_every_leg():
     cmd = [sys.executable, BENCH, "--steps", "20", "--warmup", "2", "--workload", "config2_lp_soc", "--cpu-iters", "3",
-           "--batch-problems", "8", "--batch-threads", "4"]
+           "--batch-problems", "8", "--batch-threads", "4", "--cpu-cap-s", "12", "--no-other-configs"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
@@ -66,7 +66,29 @@ def test_single_gpu_line_has_every_leg():
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
-    assert cb["direct_ldl"]["value"] > 0 and "infeasible" in cb["direct_ldl"]["target_and_config2"]
+    ldl = cb["direct_ldl"]
+    assert ldl["largest_finished"]["value"] > 0 and ldl["largest_finished"]["hip_same_workload_iters_per_s"] > 0
+    assert len(ldl["rungs"]) == 3 and ldl["first_not_finished"]["cap_s"] == 12.0 and "infeasible" in ldl["target_and_config2"]
+    assert cb["all_cores"]["cores"] == os.cpu_count() and cb["all_cores"]["value"] > 0
+    assert rf["traffic"] is None and rf["traffic_source"] is None  # (no committed counter pass for this workload)
     assert out["config"]["cg_steps_per_s"] > 0 and out["config"]["ms_per_cg_step"] > 0
     assert out["steady_window"]["aa_accepted_in_window"] >= 0
-    assert out["config5_batch"]["solved"] == 8
+    assert out["config5_batch"]["solved"] == 8 and "grouped" in out["config5_batch"]["workload"]
+    assert out["other_configs"] is None
+
+
+@pytest.mark.gpu
+def test_other_configs_lines_and_ungrouped_batch_leg():
+    """the lines of BASELINE configs 2-4 that ride along with the default run (config 3 with its box cone, config 4 with
+    the MFMA roofline), and the one-problem-per-stream batch mode kept for A/B"""
+    cmd = [sys.executable, BENCH, "--steps", "10", "--warmup", "1", "--workload", "small_lp_soc", "--no-cpu-baseline", "--no-steady",
+           "--batch-problems", "6", "--batch-threads", "3", "--batch-ungrouped"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    oc = out["other_configs"]
+    assert [o["config"]["workload"].split(":")[0] for o in oc] == ["config2_lp_soc", "config3_mixed", "config4_psd"]
+    assert "'bu': '99999 values'" in oc[1]["config"]["workload"] and "m=999999" in oc[1]["config"]["workload"]
+    assert oc[2]["roofline"]["bound"] == "mfma" and oc[2]["roofline"]["frac"] > 0 and oc[0]["roofline"]["bound"] == "hbm"
+    assert all(o["value"] > 0 and o["steps"] == o["config"]["admm_iters_timed"] for o in oc)
+    assert out["config5_batch"]["solved"] == 6 and "one problem per stream" in out["config5_batch"]["workload"]

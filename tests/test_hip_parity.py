@@ -233,6 +233,41 @@ def test_solve_infeasible_golden(hip, oracle, fname, prefix):
     assert np.isnan(got["x"]).all() and np.isnan(got["s"]).all()
 
 
+@pytest.mark.parametrize("fname,prefix", [("problems_std.npz", "std_unbdd_"), ("problems_rand.npz", "unbdd0_"),
+                                          ("problems_sdp.npz", "unbdd1_")])
+def test_solve_unbounded_golden(hip, oracle, fname, prefix):
+    """reference-generated unbounded instances (R:test/gen_random_cone_prob.py gen_unbounded): the HIP path next to
+    the oracle's LDL' — status, the certificate (R:test/test_solve_random_cone_prob.py:82-91) checked in numpy, and
+    the normalisation c'x = -1 both produce"""
+    data, K, _ = helpers.load_problem(fname, prefix)
+    got, ref = _solve_both(hip, oracle, data, K, eps_infeas=1e-7)
+    assert got["info"]["status"] == "unbounded" and ref["info"]["status"] == "unbounded"
+    for sol in (got, ref):
+        x, s = sol["x"], sol["s"]
+        assert np.linalg.norm(data["A"] @ x + s) < 1e-3 and data["c"] @ x < -0.1
+        assert abs(data["c"] @ x + 1.0) < 1e-9
+        np.testing.assert_allclose(s, oracle.proj_cone(s, K), atol=1e-4)
+        assert np.isnan(sol["y"]).all()
+    assert got["info"]["pobj"] == -np.inf and got["info"]["dobj"] == -np.inf
+    assert got["info"]["res_unbdd_a"] < 1e-6 and ref["info"]["res_unbdd_a"] < 1e-6
+
+
+def test_config1_lp_golden_against_stored_optimum_and_oracle(hip, oracle):
+    """BASELINE.json configs[0]: the reference-generated LP (K = {l: 4000}, n = 2000; tests/golden/make_golden.py, p*
+    cross-checked with HiGHS there) through the HIP path: stored optimum, the oracle's LDL' answer, certificate"""
+    data, K, p_star = helpers.load_problem("problem_config1_lp.npz", "lp_")
+    # (eps = 1e-6: at 1e-8 the indirect path needs more than the default 1e5 iterations on this degenerate LP)
+    got, ref = _solve_both(hip, oracle, data, K, eps_abs=1e-6, eps_rel=1e-6)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    assert abs(got["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
+    assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-5 * max(1.0, abs(p_star))
+    _assert_xys(got, ref, keys=("x", "s"))  # (m = 2n: degenerate primal, the dual is pinned by its certificate)
+    pri, dual, gap = helpers.kkt_certificate(data, got)
+    scale = max(1.0, np.abs(data["b"]).max(), np.abs(data["c"]).max(), abs(p_star))
+    assert pri < 1e-5 * scale and dual < 1e-5 * scale and gap < 1e-5 * scale
+    assert got["y"].min() > -1e-7 and got["s"].min() > -1e-7
+
+
 def test_lp_soc_generated_parity(hip, oracle):
     K, n, k, seed = pg.workload("small_lp_soc")
     data, p_star, (x0, y0, s0) = pg.gen_feasible(K, n, k, seed, lambda z, K: oracle.proj_cone(z, K, dual=True))

@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--cpu-cap-s", type=float, default=30.0, help="wall-clock cap of every CPU child (LDL' rungs, all-core CG)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="OpenMP threads of the multi-core CPU-CG leg (0: min(32, cores) — the best of 8..256 on the 2 x 64-core "
+                         "bench host, profiles/r03_cpu_threads.txt)")
     ap.add_argument("--no-steady", action="store_true",
                     help="skip the AA-inclusive window (iterations [%d, %d))" % (STEADY_MARK, STEADY_MARK + STEADY_SPAN))
     ap.add_argument("--no-batch", action="store_true", help="skip the config-5 batch leg")
@@ -452,19 +455,22 @@ def main():
                            verbose=False, acceleration_lookback=10, max_iters=200).solve(warm_start=False)
             hip_same = round(200 / (dgpu["info"]["solve_time"] * 1e-3), 1)
         # all cores: the OpenMP timing build of the same CPU-CG variant on the same workload (child process)
-        allc, allc_s, allc_to = run_child(child + ["cg", args.workload, str(ci), str(ncores)], max(args.cpu_cap_s, 60.0))
+        nthr = args.cpu_threads if args.cpu_threads > 0 else min(32, ncores)
+        allc, allc_s, allc_to = run_child(child + ["cg", args.workload, str(ci), str(nthr)], max(args.cpu_cap_s, 60.0))
         cpu_baseline = {
             "value": round(ci / (cpu_ms * 1e-3), 5), "unit": "ADMM iters/s", "cores": 1, "kind": "port",
             "sample": "first %d ADMM iterations (cold start, %d CG steps) of the same instance on the oracle's "
                       "CPU-CG variant: %.1f s; the HIP path runs the same %d iterations (%d CG steps) in %.3f s; "
                       "host has %d cores" % (ci, ref["info"]["cg_iters"], cpu_ms * 1e-3, ci, gsol["info"]["cg_iters"],
                                              gpu_ms * 1e-3, ncores),
-            "all_cores": ({"value": round(allc["iters_per_s"], 4), "unit": "ADMM iters/s", "cores": ncores, "kind": "port",
-                           "sample": "the same %d iterations (%d CG steps) with the OpenMP build of the oracle (row- / column-parallel "
-                                     "mat-vecs, parallel vector loops; cone projections and Anderson steps stay sequential): %.2f s"
-                                     % (ci, allc["cg_steps"], allc["solve_s"])}
-                          if allc else {"value": None, "cores": ncores, "sample": "did not finish within %.0f s" % max(args.cpu_cap_s, 60.0)
-                                        if allc_to else "child failed"}),
+            "multi_core": ({"value": round(allc["iters_per_s"], 4), "unit": "ADMM iters/s", "cores": nthr, "host_cores": ncores, "kind": "port",
+                            "sample": "the same %d iterations (%d CG steps) with the OpenMP build of the oracle (row- / column-parallel "
+                                      "mat-vecs, parallel vector loops; cone projections and Anderson steps stay sequential) on %d threads: "
+                                      "%.2f s.  More threads are SLOWER on this host (memory is first-touched by one thread, two NUMA "
+                                      "nodes: 8 / 16 / 32 / 64 / 128 / 256 threads = 3.1 / 3.9 / 4.1 / 2.2 / 0.9 / <0.07 iters/s, "
+                                      "profiles/r03_cpu_threads.txt)" % (ci, allc["cg_steps"], nthr, allc["solve_s"])}
+                           if allc else {"value": None, "cores": nthr, "host_cores": ncores,
+                                         "sample": "did not finish within %.0f s" % max(args.cpu_cap_s, 60.0) if allc_to else "child failed"}),
             "direct_ldl": {
                 "what": "oracle's sparse LDL' direct variant (min-degree ordering + up-looking LDL': the QDLDL path), 1 thread, random LPs "
                         "m = 2n with 50 nonzeros per column (the shape of BASELINE.json configs[0]), 200 iterations each; every rung a "

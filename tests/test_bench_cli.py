@@ -69,7 +69,7 @@ def test_single_gpu_line_has_every_leg():
     ldl = cb["direct_ldl"]
     assert ldl["largest_finished"]["value"] > 0 and ldl["largest_finished"]["hip_same_workload_iters_per_s"] > 0
     assert len(ldl["rungs"]) == 3 and ldl["first_not_finished"]["cap_s"] == 12.0 and "infeasible" in ldl["target_and_config2"]
-    assert cb["all_cores"]["cores"] == os.cpu_count() and cb["all_cores"]["value"] > 0
+    assert cb["multi_core"]["cores"] == min(32, os.cpu_count()) and cb["multi_core"]["value"] > 0
     assert rf["traffic"] is None and rf["traffic_source"] is None  # (no committed counter pass for this workload)
     assert out["config"]["cg_steps_per_s"] > 0 and out["config"]["ms_per_cg_step"] > 0
     assert out["steady_window"]["aa_accepted_in_window"] >= 0

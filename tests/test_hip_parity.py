@@ -261,7 +261,9 @@ def test_config1_lp_golden_against_stored_optimum_and_oracle(hip, oracle):
     assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
     assert abs(got["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
     assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-5 * max(1.0, abs(p_star))
-    _assert_xys(got, ref, keys=("x", "s"))  # (m = 2n: degenerate primal, the dual is pinned by its certificate)
+    # m = 2n: about n constraints are active at the optimum, so x sits on a nearly singular active set (two 1e-6
+    # certificates differ by 2e-4 of the largest entry) and the dual is not unique: x, s at 1e-3, y by its certificate
+    _assert_xys(got, ref, rtol=1e-3, keys=("x", "s"))
     pri, dual, gap = helpers.kkt_certificate(data, got)
     scale = max(1.0, np.abs(data["b"]).max(), np.abs(data["c"]).max(), abs(p_star))
     assert pri < 1e-5 * scale and dual < 1e-5 * scale and gap < 1e-5 * scale

@@ -403,6 +403,11 @@ def main():
                 continue
             line, _, _ = measure(wl, st, wu, steady=False, gather=False)
             line.pop("steady_window", None)
+            if wl == "config3_mixed":
+                line["config"]["why_so_many_cg_steps"] = (
+                    "conditioning, not cone kernels: R_y weighs the 100,000 zero-cone rows 1000 x heavier than the others "
+                    "(1/(1000 scale) vs 1/scale), the reduced system's condition number is ~1e3 and Jacobi-preconditioned CG needs "
+                    "~330 steps per solve; with the same rows declared `l` it needs 13 (profiles/r03_config3_cg_study.txt)")
             other.append(line)
 
     if rank != 0:

@@ -28,7 +28,7 @@
 
 namespace scship {
 
-constexpr int kAaMaxMem = 32;
+constexpr int kAaMaxMem = 32;  // columns per register block; the TSQR path takes histories up to this length
 constexpr int kAaMaxCols = 2 * kAaMaxMem + 1;
 
 // device result record of one solve (doubles): verdict, statistics, then gamma
@@ -81,10 +81,12 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_update(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------------ Gram path
-// one streaming pass over L (= S or Y) and Y:  row[j] = L_idx . Y_j,  col[j] = L_j . Y_idx,  w[j] = L_j . g
-// partial layout: part[(k*kAaMaxMem + j) * nb + b], k = 0 (row), 1 (col), 2 (w)
+// one streaming pass over L (= S or Y) and Y:  row[j] = L_idx . Y_j,  col[j] = L_j . Y_idx,  w[j] = L_j . g  for the
+// columns j0 <= j < min(j0 + kAaMaxMem, len) (histories longer than kAaMaxMem columns take one launch per block of
+// columns).  partial layout: part[(k*cap + j) * nb + b], k = 0 (row), 1 (col), 2 (w), cap = the history capacity
 __global__ __launch_bounds__(kVecThreads) void k_aa_dots(const double *__restrict__ L, const double *__restrict__ Y,
-                                                         const double *__restrict__ g, long dim, int len, int idx, double *part) {
+                                                         const double *__restrict__ g, long dim, int len, int idx, double *part,
+                                                         int j0, int cap) {
   __shared__ double sm[kVecThreads / 64];
   double row[kAaMaxMem], col[kAaMaxMem], w[kAaMaxMem];
 #pragma unroll
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_dots(const double *__restric
     const double li = Li[i], yi = Yi[i], gi = g[i];
 #pragma unroll
     for (int j = 0; j < kAaMaxMem; ++j) {
-      if (j < len) {
-        const double Lj = L[(size_t)dim * j + i], Yj = Y[(size_t)dim * j + i];
+      if (j0 + j < len) {
+        const double Lj = L[(size_t)dim * (j0 + j) + i], Yj = Y[(size_t)dim * (j0 + j) + i];
         row[j] += li * Yj;
         col[j] += Lj * yi;
         w[j] += Lj * gi;
@@ -104,22 +106,22 @@ __global__ __launch_bounds__(kVecThreads) void k_aa_dots(const double *__restric
   }
 #pragma unroll
   for (int j = 0; j < kAaMaxMem; ++j) {
-    if (j < len) {  // len is uniform across the grid
+    if (j0 + j < len) {  // len is uniform across the grid
       const double a = block_sum<kVecThreads>(row[j], sm);
       const double b = block_sum<kVecThreads>(col[j], sm);
       const double c = block_sum<kVecThreads>(w[j], sm);
       if (threadIdx.x == 0) {
-        part[((size_t)(0 * kAaMaxMem + j)) * gridDim.x + blockIdx.x] = a;
-        part[((size_t)(1 * kAaMaxMem + j)) * gridDim.x + blockIdx.x] = b;
-        part[((size_t)(2 * kAaMaxMem + j)) * gridDim.x + blockIdx.x] = c;
+        part[((size_t)(0 * cap + j0 + j)) * gridDim.x + blockIdx.x] = a;
+        part[((size_t)(1 * cap + j0 + j)) * gridDim.x + blockIdx.x] = b;
+        part[((size_t)(2 * cap + j0 + j)) * gridDim.x + blockIdx.x] = c;
       }
     }
   }
 }
 
-// out[0] = sum of norm partials (||g||^2); out[1 + k*kAaMaxMem + j] = reduced dots; res[AA_R_NORMG] = ||g||
+// out[0] = sum of norm partials (||g||^2); out[1 + k*cap + j] = reduced dots; res[AA_R_NORMG] = ||g||
 __global__ __launch_bounds__(kVecThreads) void k_fin_aa(const double *npart, int nnp, const double *part, int np, int len,
-                                                        double *out, double *res) {
+                                                        double *out, double *res, int cap) {
   __shared__ double sm[kVecThreads / 64];
   const double ng = part_sum(npart, nnp, sm);
   if (threadIdx.x == 0) {
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_aa(const double *npart, int
   __syncthreads();
   for (int k = 0; k < 3; ++k)
     for (int j = 0; j < len; ++j) {
-      const double v = part_sum(part + ((size_t)(k * kAaMaxMem + j)) * np, np, sm);
-      if (threadIdx.x == 0) out[1 + k * kAaMaxMem + j] = v;
+      const double v = part_sum(part + ((size_t)(k * cap + j)) * np, np, sm);
+      if (threadIdx.x == 0) out[1 + k * cap + j] = v;
       __syncthreads();
     }
 }
@@ -354,24 +356,17 @@ __global__ __launch_bounds__(64) void k_aa_solve(const double *__restrict__ R, i
 }
 
 // f -= D gamma;  optional relaxation: f = beta f + (1-beta) (x - S gamma).  ok != nullptr: the device-side verdict
-// of k_aa_solve (gamma sits right behind it); a rejected step leaves f untouched.
-__device__ __forceinline__ void d_aa_apply(double *f, const double *__restrict__ D,
-                                           const double *__restrict__ S, const double *__restrict__ xcur,
-                                           const double *__restrict__ gamma, long dim, int len,
+// of k_aa_solve (gamma sits right behind it); a rejected step leaves f untouched.  Any history length: the weights are
+// read as they are used (uniform addresses: scalar loads), the columns are subtracted in ascending order.
+__device__ __forceinline__ void d_aa_apply(double *f, const double *__restrict__ D, const double *__restrict__ S,
+                                           const double *__restrict__ xcur, const double *__restrict__ gamma, long dim, int len,
                                            double relaxation, const double *ok) {
   if (ok && !(*ok != 0.)) return;
-  double gm[kAaMaxMem];
-#pragma unroll
-  for (int j = 0; j < kAaMaxMem; ++j) gm[j] = j < len ? gamma[j] : 0.;
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < dim; i += (long)gridDim.x * kVecThreads) {
     double fi = f[i], xs = 0.;
-#pragma unroll
-    for (int j = 0; j < kAaMaxMem; ++j)
-      if (j < len) fi -= gm[j] * D[(size_t)dim * j + i];
+    for (int j = 0; j < len; ++j) fi -= gamma[j] * D[(size_t)dim * j + i];
     if (relaxation != 1.0) {
-#pragma unroll
-      for (int j = 0; j < kAaMaxMem; ++j)
-        if (j < len) xs += gm[j] * S[(size_t)dim * j + i];
+      for (int j = 0; j < len; ++j) xs += gamma[j] * S[(size_t)dim * j + i];
       fi = relaxation * fi + (1. - relaxation) * (xcur[i] - xs);
     }
     f[i] = fi;
@@ -467,7 +462,7 @@ struct DeviceAa {
     dim = dim_; mem = mem_; type1 = type1_ ? 1 : 0; regularization = regularization_; relaxation = relaxation_;
     safeguard_factor = safeguard_factor_; max_weight_norm = max_weight_norm_; stream = s;
     iter = 0; success = 0; st = ScsAaStats{}; pending_safeguard = false;
-    tsqr = tsqr_default();
+    tsqr = tsqr_default() && mem <= kAaMaxMem;  // (longer histories: the Gram path, a block of kAaMaxMem columns per launch)
     if (mem <= 0) return;
     for (DevBuf<double> *b : {&x, &f, &gprev}) b->alloc_zero((size_t)dim, s);
     for (DevBuf<double> *b : {&S, &Y, &D}) b->alloc_zero((size_t)dim * mem, s);
@@ -475,16 +470,21 @@ struct DeviceAa {
     spart.alloc_zero(kMaxVecBlocks, s);
     res.alloc_zero(AA_R_COUNT, s);
     bad.alloc_zero(1, s);
-    if (!h_pin) HIP_CHECK(hipHostMalloc((void **)&h_pin, sizeof(double) * 256));
+    if (mem > kAaMaxMem) {  // the Gram record (1 + 3 mem doubles) outgrows the shared pinned block
+      if (h_pin && owns_pin) (void)hipHostFree(h_pin);
+      h_pin = nullptr;
+      owns_pin = true;
+    }
+    if (!h_pin) HIP_CHECK(hipHostMalloc((void **)&h_pin, sizeof(double) * std::max(256, 2 + 3 * mem)));
     if (tsqr) {
       const int c = ncols();
       const size_t cap = (size_t)c * kTsqrWaves1 * mem;
       rbuf[0].alloc_zero(cap, s);
       rbuf[1].alloc_zero((size_t)c * kTsqrWaves2 * mem, s);
     } else {
-      part.alloc_zero((size_t)3 * kAaMaxMem * kMaxVecBlocks, s);
-      out.alloc_zero(1 + 3 * kAaMaxMem, s);
-      gamma.alloc_zero(kAaMaxMem, s);
+      part.alloc_zero((size_t)3 * mem * kMaxVecBlocks, s);
+      out.alloc_zero(1 + 3 * (size_t)mem, s);
+      gamma.alloc_zero((size_t)mem, s);
       M.assign((size_t)mem * mem, 0.0);
     }
   }
@@ -582,15 +582,16 @@ struct DeviceAa {
       }
     } else {
       const double *L = type1 ? S.p : Y.p;
-      hipLaunchKernelGGL(k_aa_dots, dim3(nb), dim3(kVecThreads), 0, stream, L, Y.p, gprev.p, dim, len, idx, part.p);
-      hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, npart.p, nb, part.p, nb, len, out.p, res.p);
-      HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * (1 + 3 * kAaMaxMem), hipMemcpyDeviceToHost, stream));
+      for (int j0 = 0; j0 < len; j0 += kAaMaxMem)
+        hipLaunchKernelGGL(k_aa_dots, dim3(nb), dim3(kVecThreads), 0, stream, L, Y.p, gprev.p, dim, len, idx, part.p, j0, mem);
+      hipLaunchKernelGGL(k_fin_aa, dim3(1), dim3(kVecThreads), 0, stream, npart.p, nb, part.p, nb, len, out.p, res.p, mem);
+      HIP_CHECK(hipMemcpyAsync(h_pin, out.p, sizeof(double) * (1 + 3 * (size_t)mem), hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
       const double *o = h_pin;
       last_norm_g = std::sqrt(o[0]);
       for (int j = 0; j < len; ++j) {
-        M[idx + mem * j] = o[1 + 0 * kAaMaxMem + j];  // row idx
-        M[j + mem * idx] = o[1 + 1 * kAaMaxMem + j];  // col idx
+        M[idx + mem * j] = o[1 + 0 * mem + j];  // row idx
+        M[j + mem * idx] = o[1 + 1 * mem + j];  // col idx
       }
       if (iter >= mem) {
         std::vector<double> A((size_t)len * len), w(len);
@@ -603,7 +604,7 @@ struct DeviceAa {
         const double reg = regularization * std::sqrt(nrm);
         if (regularization > 0)
           for (int i = 0; i < len; ++i) A[i + (size_t)len * i] += reg;
-        for (int j = 0; j < len; ++j) w[j] = o[1 + 2 * kAaMaxMem + j];
+        for (int j = 0; j < len; ++j) w[j] = o[1 + 2 * mem + j];
         const int rank = dense_solve(A.data(), w.data(), len);
         double nw = 0.;
         int code = AA_CODE_OK;

@@ -245,6 +245,7 @@ struct GroupSolve {
     active_d = active_buf.p;
   }
   void sync() {
+    HIP_CHECK(hipGetLastError());  // (launches are not checked one by one)
     HIP_CHECK(hipStreamSynchronize(s));
     lists_since_sync = 0;
     ++syncs;

@@ -437,8 +437,9 @@ __global__ __launch_bounds__(kBoxMultiThreads) void k_proj_box_round(const doubl
     tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (tk % gridDim.x != gridDim.x - 1) return;
+  if (tk != gridDim.x - 1) return;  // (the last arriver leaves the ticket at 0 for the next round's launch: no wrap-around, ever)
   if (threadIdx.x == 0) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double g = 0., h = 0.;
     for (unsigned b = 0; b < gridDim.x; ++b) {
       g += __hip_atomic_load(parts + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

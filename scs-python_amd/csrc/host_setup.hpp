@@ -50,8 +50,8 @@ inline bool build_cone(const ScsCone *k, HostCone &c) {
   if (k->cssize) c.cs.assign(k->cs, k->cs + k->cssize);
   if (k->psize) c.p.assign(k->p, k->p + k->psize);
   for (int q : c.q) if (q < 0) return false;
-  for (int s : c.s) if (s < 0 || s > 1024) return false;
-  for (int s : c.cs) if (s < 0 || s > 512) return false;  // projected through its 2k x 2k real embedding
+  for (int s : c.s) if (s < 0 || s > 8192) return false;   // (psd.hpp kPsdMaxH: 16 * 512)
+  for (int s : c.cs) if (s < 0 || s > 4096) return false;  // projected through its 2k x 2k real embedding
   for (double p : c.p) if (!(p >= -1 && p <= 1)) return false;
   long cnt = (long)c.z + c.l;
   c.off_box = (int)cnt; cnt += c.bsize;

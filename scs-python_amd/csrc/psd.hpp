@@ -58,7 +58,7 @@ constexpr int kPsdWLd = PSD_WLD;      // leading dimension of W
 constexpr int kPsdWsz = 16 * 17;  // 272 doubles reserved per S / W
 constexpr int kPsdWaveLds = 2 * kPsdWsz;  // per wave: S (also the 16x17 transpose scratch), W
 constexpr int kPsdWarmPeriod = 32;  // calls between two re-orthogonalisations of the warm-start basis V
-constexpr int kPsdMaxH = 64;  // pivots per step: order <= 1024
+constexpr int kPsdMaxH = 512;  // pivots per step: order <= 8192 (LDS schedule arrays; an order-8192 matrix needs 2.1 GB of scratch)
 #ifndef PSD_OFFTOL2
 #define PSD_OFFTOL2 1e-16
 #endif

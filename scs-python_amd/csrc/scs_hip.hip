@@ -738,6 +738,7 @@ struct ScsHipWork {
   }
 
   void read_flags() {
+    HIP_CHECK(hipGetLastError());  // launches are not checked one by one: a refused one is caught here
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     process_pending_flags();
@@ -774,6 +775,7 @@ struct ScsHipWork {
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
   }
   void sync_flags() {
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream));
     process_pending_flags();
   }
@@ -1002,6 +1004,7 @@ struct ScsHipWork {
   }
   bool finish_plain_iteration(int iter) {
     const int slot = iter & 1;
+    HIP_CHECK(hipGetLastError());  // a refused launch (hipLaunchKernelGGL reports nothing) surfaces here, once per iteration
     HIP_CHECK(hipEventSynchronize(ev_iter[slot]));
     const int *hf = h_flags_slot[slot];
     if (hf[F_STALL]) {
@@ -1298,16 +1301,27 @@ struct ScsHipWork {
     double box_t = 1.0;
     HIP_CHECK(hipMemcpyAsync(&box_t, sc.p + S_BOX_T, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    std::swap(box_bl.p, box_bl_orig.p);
-    std::swap(box_bu.p, box_bu_orig.p);
-    const int warm_keep = psd_warm;
-    psd_warm = 0;
-    if (cone.z + cone.l > 0)
-      hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(cone.z + cone.l, kConeThreads)), dim3(kConeThreads), 0, stream, tmp_m.p, cone.z, cone.l, dual);
-    project_nonlinear_cones(tmp_m.p, dual);
-    psd_warm = warm_keep;
-    std::swap(box_bl.p, box_bl_orig.p);
-    std::swap(box_bu.p, box_bu_orig.p);
+    {
+      // the caller's (unscaled) box bounds and a cold PSD start for this one projection; put back whatever happens
+      // (a refused launch throws out of project_nonlinear_cones)
+      struct Restore {
+        ScsHipWork *w;
+        int warm;
+        explicit Restore(ScsHipWork *w_) : w(w_), warm(w_->psd_warm) {
+          std::swap(w->box_bl.p, w->box_bl_orig.p);
+          std::swap(w->box_bu.p, w->box_bu_orig.p);
+          w->psd_warm = 0;
+        }
+        ~Restore() {
+          w->psd_warm = warm;
+          std::swap(w->box_bl.p, w->box_bl_orig.p);
+          std::swap(w->box_bu.p, w->box_bu_orig.p);
+        }
+      } restore(this);
+      if (cone.z + cone.l > 0)
+        hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(cone.z + cone.l, kConeThreads)), dim3(kConeThreads), 0, stream, tmp_m.p, cone.z, cone.l, dual);
+      project_nonlinear_cones(tmp_m.p, dual);
+    }
     const int nb = vb(m);
     hipLaunchKernelGGL(k_aa_diffsq, dim3(nb), dim3(kVecThreads), 0, stream, (const double *)rsk.p, (const double *)tmp_m.p, (long)m, part.p);
     std::vector<double> hp(nb);
@@ -1553,7 +1567,9 @@ static void upload_cone_meta(ScsHipWork *w) {
       if (2 * k > kPsdSmallMax) { ++big_total; max_order = std::max(max_order, 2 * k); }
     w->psd_max_np = (int)psd_np(std::max(max_order, 2));
     w->psd_max_tiles = w->psd_max_np / 16;
-    w->psd_split = big_total > 0 && big_total <= 128;  // one CU per matrix leaves at least half of the GPU idle
+    // split mode: one CU per matrix would leave at least half of the GPU idle.  Its V update keeps a 16-row strip of V in LDS
+    // (16 x NP doubles): orders above 1280 do not fit and take the one-workgroup-per-matrix kernel (any order up to 16 kPsdMaxH)
+    w->psd_split = big_total > 0 && big_total <= 128 && (size_t)16 * w->psd_max_np * sizeof(double) <= 160 * 1024;
     if (const char *env = getenv("SCS_HIP_PSD_SPLIT")) w->psd_split = big_total > 0 && env[0] == '1';  // A/B and tests
   }
   HIP_CHECK(hipStreamSynchronize(s));
@@ -1642,7 +1658,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   if (d->P && !validate_matrix(d->P, d->n, d->n)) throw std::runtime_error("invalid P matrix");
   if (!(stgs->max_iters > 0) || !(stgs->eps_abs >= 0) || !(stgs->eps_rel >= 0) || !(stgs->eps_infeas >= 0) ||
       !(stgs->alpha > 0 && stgs->alpha < 2) || !(stgs->rho_x > 0) || !(stgs->scale > 0) ||
-      !(stgs->acceleration_interval > 0) || stgs->acceleration_lookback < 0 || stgs->acceleration_lookback > kAaMaxMem ||
+      !(stgs->acceleration_interval > 0) || stgs->acceleration_lookback < 0 ||
       !(stgs->time_limit_secs >= 0))
     throw std::runtime_error("invalid settings");
   int ndev = 0;
@@ -2567,6 +2583,7 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
       hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
                          w.cone.z, w.cone.l, dual);
     w.project_nonlinear_cones(dx.p, dual);
+    HIP_CHECK(hipGetLastError());
     dx.download(x, m, ts.s);
     HIP_CHECK(hipStreamSynchronize(ts.s));
     return 0;
@@ -2694,7 +2711,7 @@ ScsHipAa *scs_hip_aa_init(scs_int dim, scs_int mem, scs_int type1, scs_float reg
                           scs_float safeguard_factor, scs_float max_weight_norm) {
   try {
     set_last_error("");
-    if (dim <= 0 || mem < 0 || mem > kAaMaxMem) throw std::runtime_error("invalid AA dimensions (lookback must be <= 32)");
+    if (dim <= 0 || mem < 0) throw std::runtime_error("invalid AA dimensions");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) throw std::runtime_error("libscs_hip: no HIP device available");
     std::unique_ptr<ScsHipAa> a(new ScsHipAa());
@@ -2735,9 +2752,10 @@ scs_int scs_hip_aa_safeguard(ScsHipAa *a, scs_float *f_new, scs_float *x_new) {
   try {
     set_last_error("");
     HIP_CHECK(hipSetDevice(a->device));
+    if (!a->aa.success) return 0;  // nothing to test (and no asynchronous upload of the caller's buffers left in flight)
     a->f.upload(f_new, (size_t)a->aa.dim, a->stream);
     a->x.upload(x_new, (size_t)a->aa.dim, a->stream);
-    if (!a->aa.safeguard(a->f.p, a->x.p, a->bad.p)) return 0;
+    a->aa.safeguard(a->f.p, a->x.p, a->bad.p);
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, a->bad.p, sizeof(int), hipMemcpyDeviceToHost, a->stream));
     a->f.download(f_new, (size_t)a->aa.dim, a->stream);

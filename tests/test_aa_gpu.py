@@ -110,6 +110,41 @@ def test_aa_steps_match_oracle(hip, oracle, aa_mode, type1, dim, mem):
 
 
 @pytest.mark.parametrize("type1", [True, False], ids=["type-I", "type-II"])
+@pytest.mark.parametrize("dim,mem", [(30000, 50), (9000, 80), (2000, 33)])
+def test_aa_lookback_beyond_the_register_block(hip, oracle, type1, dim, mem):
+    """acceleration_lookback > 32 (the reference accepts any, R:scs/scsobject.h:545): histories longer than one register
+    block take the Gram path a block of 32 columns per launch — step-by-step parity with the oracle as above.  The map
+    has a wide spectrum so that a 50 - 80 column history stays numerically independent for a while."""
+    rng = np.random.RandomState(mem)
+    d = rng.uniform(-0.95, 0.95, dim)
+    b = rng.randn(dim)
+    F = lambda x: b + d * x + 0.04 * np.roll(x, 1)  # noqa: E731
+    h = hip.AndersonAccelerator(dim, mem, type1=type1, regularization=1e-6)
+    o = oracle.OracleAA(dim, mem, type1=type1, regularization=1e-6)
+    n = _drive(h, o, F, rng.randn(dim), mem + 25, rtol=1e-6, check_gamma=False)
+    assert n > 0
+    sh, so = _same_counters(h, o)
+    assert sh["iter"] == mem + 25
+
+
+def test_full_solve_with_lookback_50_matches_oracle(hip, oracle):
+    """a whole solve with acceleration_lookback = 50 (was refused by this backend in rounds 1-2)"""
+    K, n, k, seed = pg.workload("small_lp_soc")
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    stg = dict(STG, acceleration_lookback=50, acceleration_interval=1, eps_abs=1e-7, eps_rel=1e-7)
+    got = hip.SCS(*args, **stg).solve(False, None, None, None)
+    ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
+    assert got["info"]["status"] == ref["info"]["status"] == "solved"
+    ga, ra = got["info"]["aa_stats"], ref["info"]["aa_stats"]
+    solves = lambda a: a["n_accept"] + a["n_reject_lapack"] + a["n_reject_rank0"] + a["n_reject_nonfinite"] + a["n_reject_weight_cap"]  # noqa: E731
+    assert ga["iter"] > 50 and solves(ga) > 0 and solves(ra) > 0, (ga, ra)  # the 50-column system was really solved
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+    for key in ("x", "y", "s"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=1e-4, atol=1e-4 * np.abs(ref[key]).max(), err_msg=key)
+
+
+@pytest.mark.parametrize("type1", [True, False], ids=["type-I", "type-II"])
 @pytest.mark.parametrize("relaxation,regularization", [(0.8, 1e-8), (1.0, 0.0), (1.3, 1e-4)])
 def test_aa_relaxation_and_regularization(hip, oracle, aa_mode, type1, relaxation, regularization):
     dim, mem = 20000, 5

@@ -270,6 +270,25 @@ def test_config1_lp_golden_against_stored_optimum_and_oracle(hip, oracle):
     assert got["y"].min() > -1e-7 and got["s"].min() > -1e-7
 
 
+@pytest.mark.parametrize("cone,order", [("s", 1500), ("cs", 600)])
+def test_psd_orders_beyond_1024(hip, cone, order):
+    """PSD order 1500 / complex PSD order 600 (embedding 1200): refused by this backend in rounds 1-2 (pivots per step
+    of the block-Jacobi kernels), valid for the reference (R:scs/scsobject.h:726-737).  Against LAPACK's eigh."""
+    rng = np.random.default_rng(order)
+    if cone == "s":
+        G = rng.standard_normal((order, order))
+        X = (G + G.T) / 2
+        z = helpers.sym_to_svec(X)
+        want = helpers.proj_dual_l_s_numpy(z, {"s": [order]})
+        got = hip.proj_cone(z, {"s": [order]}, dual=True)
+    else:
+        G = rng.standard_normal((order, order)) + 1j * rng.standard_normal((order, order))
+        z = helpers.herm_to_cvec((G + G.conj().T) / 2)
+        want = helpers.proj_hermitian_psd(z, order)
+        got = hip.proj_cone(z, {"cs": [order]}, dual=True)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(want).max())
+
+
 def test_lp_soc_generated_parity(hip, oracle):
     K, n, k, seed = pg.workload("small_lp_soc")
     data, p_star, (x0, y0, s0) = pg.gen_feasible(K, n, k, seed, lambda z, K: oracle.proj_cone(z, K, dual=True))

@@ -141,9 +141,10 @@ struct DeviceCsr {
   DevBuf<unsigned> peel_mask;
   DevBuf<int4> peel_blk;
   int npeel = 0, npeel_long = 0;
+  long peel_nnz = 0;  // nonzeros in the peeled rows
   // host: mark rows longer than `thresh`; one row block {row, row + 1, first nonzero, end} each.  false: nothing to peel
   bool make_peel(const int *rp_host, int thresh, hipStream_t s) {
-    peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
+    peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; peel_nnz = 0;
     if (getenv("SCS_HIP_CS_PEEL") && getenv("SCS_HIP_CS_PEEL")[0] == '0') return false;  // A/B: reject such patterns as round 1 did
     std::vector<int4> blk;
     std::vector<unsigned> mask;
@@ -158,7 +159,7 @@ struct DeviceCsr {
     // keeps the tail of the launch short), ties in row order: a fixed order, so the reduction partials are deterministic
     std::stable_sort(blk.begin(), blk.end(), [](const int4 &a, const int4 &b) { return a.w - a.z > b.w - b.z; });
     npeel_long = 0;
-    for (const int4 &b : blk) npeel_long += (b.w - b.z > kPeelLongRow) ? 1 : 0;
+    for (const int4 &b : blk) { npeel_long += (b.w - b.z > kPeelLongRow) ? 1 : 0; peel_nnz += b.w - b.z; }
     npeel = (int)blk.size();
     peel_mask.upload(mask.data(), mask.size(), s);
     peel_blk.upload(blk.data(), blk.size(), s);
@@ -222,18 +223,24 @@ struct DeviceCsr {
     std::vector<int> rp((size_t)rows + 1);  // row lengths decide what is peeled (O(rows) at init)
     rowptr.download(rp.data(), rp.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
-    if (sp > 1) {
-      make_peel(rp.data(), peel_threshold(sp), s);
-      ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, sp, peel_mask.p);
-    }
-    if (!ok) {
-      make_peel(rp.data(), peel_threshold(1), s);
-      ok = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, 1, peel_mask.p);
-    }
-    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; }
+    // For every split candidate: first WITHOUT peeling — what the count fields limit is a row's nonzeros inside ONE
+    // pass, and a long row whose columns are spread out (a uniformly denser matrix: 100 nonzeros per row over 1e6
+    // columns) has ~1 per pass — then, if a count overflowed, with the rows longer than a count field peeled off; and
+    // a layout whose peeled rows hold most of the nonzeros is not kept (the side launch would be the product).
+    auto attempt = [&](int split) {
+      clear_peel();
+      if (cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, nullptr)) return true;
+      if (!make_peel(rp.data(), peel_threshold(split), s)) return false;
+      if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
+      return cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, peel_mask.p);
+    };
+    if (sp > 1) ok = attempt(sp);
+    if (!ok) ok = attempt(1);
+    if (!ok) clear_peel();
     cs_after_build(s);
     return ok;
   }
+  void clear_peel() { peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; peel_nnz = 0; }
   bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, int kind) {
     cs.release();
     peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
@@ -242,24 +249,19 @@ struct DeviceCsr {
     HostCs h;
     bool ok = false;
     const int sp = cs_pick_split(kind);
-    auto host_mask = [&](int split) {  // the same rows make_peel marks
-      std::vector<unsigned> mk;
-      if (make_peel(rp, peel_threshold(split), s)) {
-        mk.assign(((size_t)rows + 31) / 32, 0u);
-        for (int r = 0; r < rows; ++r)
-          if (rp[r + 1] - rp[r] > peel_threshold(split)) mk[r >> 5] |= 1u << (r & 31);
-      }
-      return mk;
+    auto attempt = [&](int split) {  // same policy as build_cs_dev: unpeeled first, then the long rows peeled, capped
+      clear_peel();
+      if (build_cs(rp, ci, v, rows, cols, h, 0, split, nullptr)) return true;
+      if (!make_peel(rp, peel_threshold(split), s)) return false;
+      if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
+      std::vector<unsigned> mk(((size_t)rows + 31) / 32, 0u);
+      for (int r = 0; r < rows; ++r)
+        if (rp[r + 1] - rp[r] > peel_threshold(split)) mk[r >> 5] |= 1u << (r & 31);
+      return build_cs(rp, ci, v, rows, cols, h, 0, split, mk.data());
     };
-    if (sp > 1) {
-      const std::vector<unsigned> mk = host_mask(sp);
-      ok = build_cs(rp, ci, v, rows, cols, h, 0, sp, mk.empty() ? nullptr : mk.data());
-    }
-    if (!ok) {
-      const std::vector<unsigned> mk = host_mask(1);
-      ok = build_cs(rp, ci, v, rows, cols, h, 0, 1, mk.empty() ? nullptr : mk.data());
-    }
-    if (!ok) { peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; return false; }
+    if (sp > 1) ok = attempt(sp);
+    if (!ok) ok = attempt(1);
+    if (!ok) { clear_peel(); return false; }
     cs.from_host(h, s);
     cs_after_build(s);
     return true;

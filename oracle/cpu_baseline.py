@@ -47,7 +47,9 @@ def main():
         r = scs_oracle.solve(data, K, indirect=False, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False,
                              acceleration_lookback=10, max_iters=iters)
         ms = r["info"]["solve_time"]
-        print(json.dumps({"mode": "ldl", "m": m, "n": n, "nnz": int(data["A"].nnz), "iters": iters,
+        lss = r["info"].get("lin_sys_solver", "")
+        nnz_l = int(lss.split("nnz(L)=")[1]) if "nnz(L)=" in lss else None
+        print(json.dumps({"mode": "ldl", "m": m, "n": n, "nnz": int(data["A"].nnz), "nnz_L": nnz_l, "iters": iters,
                           "factorization_s": r["info"]["setup_time"] * 1e-3, "solve_s": ms * 1e-3,
                           "iters_per_s": iters / (ms * 1e-3)}))
     else:

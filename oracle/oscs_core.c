@@ -498,7 +498,8 @@ scs_int oscs_solve(void *work, ScsSolution *sol, ScsInfo *info, scs_int warm_sta
   long cg0 = o_lin_sys_cg_iters(w->p);
   memset(info, 0, sizeof(*info));
   info->setup_time = w->setup_time;
-  strcpy(info->lin_sys_solver, w->indirect ? "oracle-cpu-indirect-cg" : "oracle-cpu-direct-ldl");
+  if (w->indirect) strcpy(info->lin_sys_solver, "oracle-cpu-indirect-cg");
+  else snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "oracle-cpu-direct-ldl nnz(L)=%ld", o_lin_sys_nnz_l(w->p));
   /* per-solve state */
   w->sum_log_scale_factor = 0; w->n_log_scale_factor = 0; w->last_scale_update_iter = 0;
   w->scale_updates = 0; w->rejected_accel_steps = 0; w->accepted_accel_steps = 0; w->aa_norm = 0;

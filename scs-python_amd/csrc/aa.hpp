@@ -269,6 +269,163 @@ __global__ __launch_bounds__(64) void k_aa_tsqr(AaTall W, int rho, long tiles_pe
   d_aa_tsqr(W, rho, tiles_per_wave, out, out_ld);
 }
 
+// ---- level 1 of the reduction for the default histories (lookback 10: c = 21 type-I, c = 11 type-II), round 3 ----
+// Same Householder recurrences, tile by tile, as d_aa_tsqr — but the tile lives in REGISTERS (RHO rows per lane x C columns: no LDS
+// traffic for it, three wavefronts per SIMD instead of one), a workgroup carries four independent chains (one per wavefront), and the
+// C - k dot products of pivot k — the column's own norm included — are reduced TOGETHER by a reduce-scatter over the 64 lanes
+// (exchange half of the values with the lane 32 away, half of the rest with the lane 16 away, ...: ~N exchanges for N values instead
+// of a 7-step tree per value), then handed to every lane through 16 doubles of LDS.  Fixed exchange order: bitwise reproducible.
+// (level-1 launch at l = 3e6, c = 21: 1.28 ms with d_aa_tsqr -> see profiles/r03_aa_tsqr.txt)
+__device__ __forceinline__ void aa_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// v[0 .. NV) per lane -> v[0] = the 64-lane total of value number aa_rs_index<NV>(lane); NV a power of two <= 32.
+// An exchange with the lane `m` away is two ds_bpermute_b32 (byte index (lane ^ m) * 4, computed once per kernel: no
+// per-exchange index arithmetic — the kernel is VALU-bound, profiles/r03_aa_tsqr.txt) + two selects + one add.
+struct AaXor {
+  int idx[6];  // byte index of lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1
+  __device__ __forceinline__ explicit AaXor(int lane) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b) idx[b] = (lane ^ (32 >> b)) << 2;
+  }
+};
+__device__ __forceinline__ double aa_xchg(double v, int byte_idx) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// (compile-time recursion: the live count N and the step B must be constants, or the register array is indexed dynamically)
+template <int NV, int N, int B>
+__device__ __forceinline__ void aa_rs_step(double (&v)[NV], int lane, const AaXor &X) {
+  if constexpr (B < 6) {
+    constexpr int m = 32 >> B;
+    if constexpr (N > 1) {
+      constexpr int half = N / 2;
+      const bool up = (lane & m) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const double send = up ? v[i] : v[i + half], keep = up ? v[i + half] : v[i];
+        v[i] = keep + aa_xchg(send, X.idx[B]);
+      }
+      aa_rs_step<NV, half, B + 1>(v, lane, X);
+    } else {
+      v[0] += aa_xchg(v[0], X.idx[B]);
+      aa_rs_step<NV, 1, B + 1>(v, lane, X);
+    }
+  }
+}
+template <int NV>
+__device__ __forceinline__ void aa_reduce_scatter(double (&v)[NV], int lane, const AaXor &X) {
+  aa_rs_step<NV, NV, 0>(v, lane, X);
+}
+template <int N, int B>
+__device__ __forceinline__ int aa_rs_index_step(int lane) {
+  if constexpr (B < 6 && N > 1) return ((lane & (32 >> B)) ? N / 2 : 0) + aa_rs_index_step<N / 2, B + 1>(lane);
+  else return 0;
+}
+template <int NV>
+__device__ __forceinline__ int aa_rs_index(int lane) {
+  return aa_rs_index_step<NV, 0>(lane);
+}
+#ifndef AA_FAST_RHO
+#define AA_FAST_RHO 3
+#endif
+constexpr int kAaFastWaves = 4;  // chains per workgroup
+constexpr int kAaFastRho = AA_FAST_RHO;  // rows per lane and tile
+inline int aa_tsqr_fast_kind(int c, int npiv) { return (c == 21 && npiv == 10) ? 1 : (c == 11 && npiv == 10) ? 2 : 0; }
+
+template <int C, int NPIV, int K>
+__device__ __forceinline__ void aa_fast_pivot(double (&T)[C][kAaFastRho], double *E, double *bc, int lane, const AaXor &X) {
+  constexpr int RHO = kAaFastRho, NVAL = C - K;                 // values of this pivot: sigma, then the dots with columns K + 1 ..
+  constexpr int N0 = NVAL > 16 ? 16 : (NVAL > 8 ? 16 : (NVAL > 4 ? 8 : (NVAL > 2 ? 4 : 2)));
+  constexpr int REST = NVAL > 16 ? NVAL - 16 : 0;
+  constexpr int N1 = REST > 8 ? 16 : (REST > 4 ? 8 : (REST > 2 ? 4 : (REST > 0 ? 2 : 0)));
+  {
+    double d[N0];
+#pragma unroll
+    for (int i = 0; i < N0; ++i) {
+      d[i] = 0.;
+      if (i < NVAL) {
+#pragma unroll
+        for (int q = 0; q < RHO; ++q) d[i] += T[K][q] * T[K + i][q];
+      }
+    }
+    aa_reduce_scatter<N0>(d, lane, X);
+    bc[aa_rs_index<N0>(lane)] = d[0];
+  }
+  if constexpr (N1 > 0) {
+    double d[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      d[i] = 0.;
+      if (16 + i < NVAL) {
+#pragma unroll
+        for (int q = 0; q < RHO; ++q) d[i] += T[K][q] * T[K + 16 + i][q];
+      }
+    }
+    aa_reduce_scatter<N1>(d, lane, X);
+    bc[16 + aa_rs_index<N1>(lane)] = d[0];
+  }
+  aa_wave_sync();
+  const double sigma = bc[0], alpha = E[K * C + K];
+  if (sigma != 0.) {  // (wave-uniform; nothing below the diagonal otherwise — a NaN flows on into E)
+    const double nrm = sqrt(alpha * alpha + sigma);
+    const double beta = alpha >= 0. ? -nrm : nrm;
+    const double vp = alpha - beta;
+    const double tau = 1.0 / (nrm * (nrm + fabs(alpha)));  // 2 / v'v
+#pragma unroll
+    for (int i = 1; i < NVAL; ++i) {
+      const double ekj = E[K * C + K + i];
+      const double wj = tau * (vp * ekj + bc[i]);
+#pragma unroll
+      for (int q = 0; q < RHO; ++q) T[K + i][q] -= wj * T[K][q];
+      if (lane == 0) E[K * C + K + i] = ekj - wj * vp;
+    }
+    if (lane == 0) E[K * C + K] = beta;
+  }
+  aa_wave_sync();  // bc is rewritten by the next pivot, E row K + 1 read by it
+  if constexpr (K + 1 < NPIV) aa_fast_pivot<C, NPIV, K + 1>(T, E, bc, lane, X);
+}
+
+template <int C, int NPIV>
+__device__ __forceinline__ void d_aa_tsqr_fast(AaTall W, long tiles_per_wave, long nw, double *out, long out_ld) {
+  constexpr int RHO = kAaFastRho, TR = 64 * RHO;
+  __shared__ double lds[kAaFastWaves][NPIV * C + 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long gw = (long)blockIdx.x * kAaFastWaves + wv;
+  if (gw >= nw) return;
+  double *E = lds[wv], *bc = E + NPIV * C;
+  for (int t = lane; t < NPIV * C; t += 64) E[t] = 0.;
+  aa_wave_sync();
+  const AaXor X(lane);
+  const long ntiles = (W.rows + TR - 1) / TR;
+  const long t0 = gw * tiles_per_wave, t1 = t0 + tiles_per_wave < ntiles ? t0 + tiles_per_wave : ntiles;
+  for (long t = t0; t < t1; ++t) {
+    const long r0 = t * TR;
+    double T[C][RHO];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const double *col = aa_col(W, j);
+#pragma unroll
+      for (int q = 0; q < RHO; ++q) {
+        const long r = r0 + q * 64 + lane;
+        T[j][q] = r < W.rows ? col[r] : 0.;
+      }
+    }
+    aa_fast_pivot<C, NPIV, 0>(T, E, bc, lane, X);
+  }
+  for (int t = lane; t < NPIV * C; t += 64) {
+    const int i = t / C, j = t - i * C;
+    out[(size_t)j * out_ld + (size_t)gw * NPIV + i] = E[t];
+  }
+}
+template <int C, int NPIV>
+__global__ __launch_bounds__(64 * kAaFastWaves) void k_aa_tsqr_fast(AaTall W, long tiles_per_wave, long nw, double *out, long out_ld) {
+  d_aa_tsqr_fast<C, NPIV>(W, tiles_per_wave, nw, out, out_ld);
+}
+
 // One wavefront: the regularised len x len system from the final triangle R (column-major npiv x c, npiv = len),
 //   type-I : M = R_LL' R_LY (columns len .. 2 len - 1), w = R_LL' R_Lg;   type-II: M = R_YY' R_YY, w = R_YY' R_Yg,
 // LU with partial pivoting (row swaps, then eliminations, the order DeviceAa::dense_solve uses), then the rank / finite /
@@ -478,9 +635,9 @@ struct DeviceAa {
     if (!h_pin) HIP_CHECK(hipHostMalloc((void **)&h_pin, sizeof(double) * std::max(256, 2 + 3 * mem)));
     if (tsqr) {
       const int c = ncols();
-      const size_t cap = (size_t)c * kTsqrWaves1 * mem;
+      const size_t cap = (size_t)c * kTsqrWavesFast * mem;
       rbuf[0].alloc_zero(cap, s);
-      rbuf[1].alloc_zero((size_t)c * kTsqrWaves2 * mem, s);
+      rbuf[1].alloc_zero((size_t)c * 64 * mem, s);  // (second level: at most 64 chains)
     } else {
       part.alloc_zero((size_t)3 * mem * kMaxVecBlocks, s);
       out.alloc_zero(1 + 3 * (size_t)mem, s);
@@ -492,6 +649,12 @@ struct DeviceAa {
   int ncols() const { return type1 ? 2 * mem + 1 : mem + 1; }
 
   static constexpr int kTsqrWaves1 = 1024, kTsqrWaves2 = 16;
+  // chains of the register-tile level-1 kernel: enough wavefronts to put 2-3 on every SIMD of the chip (SCS_HIP_AA_WAVES1: lab)
+  static constexpr int kTsqrWavesFast = 4096;
+  static int fast_waves() {
+    static const int v = [] { const char *e = getenv("SCS_HIP_AA_WAVES1"); const int t = e ? atoi(e) : 0; return t > 0 && t <= kTsqrWavesFast ? t : 2048; }();
+    return v;
+  }
 
   // One launch of the TSQR reduction: the tall matrix it reads, its geometry and where its stacked triangles go
   struct TsqrLevel {
@@ -500,6 +663,7 @@ struct DeviceAa {
     long tiles_per_wave, nw, out_ld;
     double *out;
     size_t lds;
+    int fast = 0;  // aa_tsqr_fast_kind: level 1 of the default histories runs the register-tile kernel (1: c = 21, 2: c = 11)
   };
   // [L | Y | g] -> final npiv x c triangle (column-major, ld = npiv): the launches of the fixed reduction tree, in
   // order; the last level's `out` holds the triangle.  (Also read by the grouped solve, batch.hpp.)
@@ -508,18 +672,21 @@ struct DeviceAa {
     AaTall W{};
     W.L = type1 ? S.p : Y.p; W.Y = type1 ? Y.p : nullptr; W.g = gprev.p;
     W.ld = dim; W.rows = dim; W.nL = len; W.nY = type1 ? len : 0; W.c = W.nL + W.nY + 1; W.npiv = len;
-    const int c = W.c, rho = aa_pick_rho(c), TR = 64 * rho;
+    const int c = W.c, rho = aa_pick_rho(c);
     const size_t lds = aa_tsqr_lds(c, len, rho);
+    static const bool fast_on = [] { const char *e = getenv("SCS_HIP_AA_FAST"); return !(e && e[0] == '0'); }();  // A/B
     int level = 0, dst = 0;
     while (true) {
+      const int fast = fast_on ? aa_tsqr_fast_kind(c, len) : 0;  // (every level: the stacked triangles have the same c columns and pivots)
+      const int TR = 64 * (fast ? kAaFastRho : rho);
       const long ntiles = std::max(1L, (W.rows + TR - 1) / TR);
-      const long cap = level == 0 ? kTsqrWaves1 : kTsqrWaves2;
+      const long cap = fast ? (level == 0 ? fast_waves() : 64) : (level == 0 ? kTsqrWaves1 : kTsqrWaves2);
       long nw = ntiles <= 8 ? 1 : std::min(ntiles, cap);
       const long tpw = (ntiles + nw - 1) / nw;
       nw = (ntiles + tpw - 1) / tpw;
       double *o = rbuf[dst].p;
       const long out_ld = nw * len;
-      lv.push_back(TsqrLevel{W, rho, tpw, nw, out_ld, o, lds});
+      lv.push_back(TsqrLevel{W, rho, tpw, nw, out_ld, o, lds, fast});
       if (nw == 1) return lv;
       W.L = o; W.Y = nullptr; W.g = nullptr; W.ld = out_ld; W.rows = out_ld; W.nL = c; W.nY = 0;
       dst ^= 1;
@@ -528,8 +695,12 @@ struct DeviceAa {
   }
   const double *tsqr_factor(int len) {
     const std::vector<TsqrLevel> lv = tsqr_levels(len);
-    for (const TsqrLevel &L : lv)
-      hipLaunchKernelGGL(k_aa_tsqr, dim3((unsigned)L.nw), dim3(64), L.lds, stream, L.W, L.rho, L.tiles_per_wave, L.out, L.out_ld);
+    for (const TsqrLevel &L : lv) {
+      const dim3 gf((unsigned)((L.nw + kAaFastWaves - 1) / kAaFastWaves)), bf(64 * kAaFastWaves);
+      if (L.fast == 1) hipLaunchKernelGGL((k_aa_tsqr_fast<21, 10>), gf, bf, 0, stream, L.W, L.tiles_per_wave, L.nw, L.out, L.out_ld);
+      else if (L.fast == 2) hipLaunchKernelGGL((k_aa_tsqr_fast<11, 10>), gf, bf, 0, stream, L.W, L.tiles_per_wave, L.nw, L.out, L.out_ld);
+      else hipLaunchKernelGGL(k_aa_tsqr, dim3((unsigned)L.nw), dim3(64), L.lds, stream, L.W, L.rho, L.tiles_per_wave, L.out, L.out_ld);
+    }
     return lv.back().out;
   }
 

@@ -169,7 +169,9 @@ struct GroupSolve {
   SCS_GTABLE(kVecThreads, d_aa_update) t_aa_update;
   static constexpr int kMaxTsqrLevels = 4;  // (the reduction tree is 1024 -> 16 -> 1 wavefronts: at most three launches)
   SCS_GTABLE(64, d_aa_tsqr) t_aa_tsqr[kMaxTsqrLevels];
-  int n_tsqr = 0;
+  int n_tsqr = 0, tsqr_fast[kMaxTsqrLevels] = {0, 0, 0, 0};  // default histories: the register-tile kernel (aa.hpp aa_tsqr_fast_kind)
+  SCS_GTABLE(64 * kAaFastWaves, d_aa_tsqr_fast<21, 10>) t_aa_tsqr_f21[kMaxTsqrLevels];
+  SCS_GTABLE(64 * kAaFastWaves, d_aa_tsqr_fast<11, 10>) t_aa_tsqr_f11[kMaxTsqrLevels];
   SCS_GTABLE(64, d_aa_solve) t_aa_solve;
   SCS_GTABLE(kVecThreads, d_aa_apply) t_aa_apply;
   SCS_GTABLE(kVecThreads, d_aa_diffsq) t_aa_diffsq;
@@ -319,6 +321,13 @@ struct GroupSolve {
       n_tsqr = (int)lv0.size();
       if (n_tsqr > kMaxTsqrLevels) throw std::runtime_error("grouped solve: unexpected TSQR depth");
       for (size_t k = 0; k < lv0.size(); ++k) {
+        tsqr_fast[k] = lv0[k].fast;
+        if (tsqr_fast[k]) {
+          const int gxf = (int)((lv0[k].nw + kAaFastWaves - 1) / kAaFastWaves);
+          if (tsqr_fast[k] == 1) { t_aa_tsqr_f21[k].resize((size_t)G); t_aa_tsqr_f21[k].gx = gxf; }
+          else { t_aa_tsqr_f11[k].resize((size_t)G); t_aa_tsqr_f11[k].gx = gxf; }
+          continue;
+        }
         t_aa_tsqr[k].resize((size_t)G);
         t_aa_tsqr[k].gx = (int)lv0[k].nw;
         t_aa_tsqr[k].lds = lv0[k].lds;
@@ -397,7 +406,11 @@ struct GroupSolve {
         t_aa_seed.set(g, w->v_prev.p, w->v.p, a.x.p, a.f.p, a.gprev.p, a.dim);
         set_aa_update_record(g, 0);
         const std::vector<DeviceAa::TsqrLevel> lv = a.tsqr_levels(mem);
-        for (size_t k = 0; k < lv.size(); ++k) t_aa_tsqr[k].set(g, lv[k].W, lv[k].rho, lv[k].tiles_per_wave, lv[k].out, lv[k].out_ld);
+        for (size_t k = 0; k < lv.size(); ++k) {
+          if (tsqr_fast[k] == 1) t_aa_tsqr_f21[k].set(g, lv[k].W, lv[k].tiles_per_wave, lv[k].nw, lv[k].out, lv[k].out_ld);
+          else if (tsqr_fast[k] == 2) t_aa_tsqr_f11[k].set(g, lv[k].W, lv[k].tiles_per_wave, lv[k].nw, lv[k].out, lv[k].out_ld);
+          else t_aa_tsqr[k].set(g, lv[k].W, lv[k].rho, lv[k].tiles_per_wave, lv[k].out, lv[k].out_ld);
+        }
         t_aa_solve.set(g, lv.back().out, mem, a.ncols(), a.type1, a.regularization, a.max_weight_norm, a.npart.p, nb, a.res.p);
         t_aa_apply.set(g, w->v.p, a.D.p, a.S.p, a.x.p, a.res.p + AA_R_GAMMA, a.dim, mem, a.relaxation, a.res.p + AA_R_OK);
         t_gather_aa.set(g, a.res.p, aa_res_d.p + (size_t)g * AA_R_COUNT, (long)AA_R_COUNT);
@@ -438,7 +451,7 @@ struct GroupSolve {
     f(t_res_dual); f(t_fin_multi_p); f(t_fin_multi_d); f(t_gather_res); f(t_gather_fl); f(t_set_diag_r); f(t_precond);
     f(t_g_rhs); f(t_kkt_prep); f(t_spmv_rhs); f(t_zero_part); f(t_fin_tol); f(t_cg_init); f(t_fin_cg_init); f(t_zero_iters);
     f(t_kkt_y); f(t_copy_g); f(t_gather_aa); f(t_gg); f(t_fin_gg); f(t_v_rescale); f(t_aa_seed); f(t_aa_update);
-    for (int k = 0; k < n_tsqr; ++k) f(t_aa_tsqr[k]);
+    for (int k = 0; k < n_tsqr; ++k) { f(t_aa_tsqr_f21[k]); f(t_aa_tsqr_f11[k]); f(t_aa_tsqr[k]); }
     f(t_aa_solve); f(t_aa_apply); f(t_aa_diffsq); f(t_fin_safe); f(t_aa_restore);
   }
   void upload_all() {
@@ -600,7 +613,7 @@ struct GroupSolve {
         if (!aa_solved.empty()) {
           const int *ld = upload_list(aa_solved);
           const int cnt = (int)aa_solved.size();
-          for (int k = 0; k < n_tsqr; ++k) go(t_aa_tsqr[k], ld, cnt);
+          for (int k = 0; k < n_tsqr; ++k) { go(t_aa_tsqr_f21[k], ld, cnt); go(t_aa_tsqr_f11[k], ld, cnt); go(t_aa_tsqr[k], ld, cnt); }
           go(t_aa_solve, ld, cnt);
           go(t_aa_apply, ld, cnt);
           go(t_gather_aa, ld, cnt);

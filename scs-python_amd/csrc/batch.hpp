@@ -366,7 +366,8 @@ struct GroupSolve {
       if (t_box.used) t_box.set(g, uy + w->cone.off_box, w->box_bl.p, w->box_bu.p, w->cone.bsize, w->sc.p + S_BOX_T, 1, nostall);
       if (t_soc.used) t_soc.set(g, uy, w->soc_off.p, w->soc_dim.p, w->n_soc, nostall);
       if (t_psd.used)
-        t_psd.set(g, uy, PsdBatch{w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd}, w->psd_scratch.p, w->psd_warm, nostall);
+        t_psd.set(g, uy, PsdBatch{w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd}, w->psd_scratch.p, w->psd_warm, nostall,
+                  (const double *)(par + P_PSD_TOL2));
       if (t_exp_p.used) t_exp_p.set(g, uy + w->cone.off_ep, w->cone.ep, 0, nostall);
       if (t_exp_d.used) t_exp_d.set(g, uy + w->cone.off_ed, w->cone.ed, 1, nostall);
       if (t_pow.used) t_pow.set(g, uy + w->cone.off_p, w->pow_a.p, (int)w->cone.p.size(), nostall);
@@ -632,6 +633,7 @@ struct GroupSolve {
         p[P_RES_MIN] = cg_res_min[(size_t)g];
         p[P_IPOW] = std::pow((double)i + 1, 1.5);
         p[P_FIRST] = i < 1 ? 1.0 : 0.0;
+        p[P_PSD_TOL2] = ScsHipWork::psd_tol2_of(cg_res_min[(size_t)g]);
       }
       HIP_CHECK(hipMemcpyAsync(params_d.p, params_h, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
       tmp_list.clear();

@@ -63,6 +63,19 @@ constexpr int kPsdMaxH = 512;  // pivots per step: order <= 8192 (LDS schedule a
 #define PSD_OFFTOL2 1e-16
 #endif
 constexpr double kPsdOffTol2 = PSD_OFFTOL2;  // sweeps stop at ||offdiag||_F^2 <= this * ||A||_F^2 (see the reconstruction)
+// Inside the ADMM loop the stopping level follows the residuals, as the tolerance of the inexact linear solve does (vec.hpp k_fin_head):
+// tol2 points at the iteration's P_PSD_TOL2 = clamp(1e-2 * residual, 1e-8, 1e-3)^2 (scs_hip.hip psd_tol2_of; the residual is the
+// smaller of the normalised primal / dual residuals of the last convergence check).  While the iterate is far from the solution an
+// eigen-decomposition to 1e-8 buys nothing: the second-order reconstruction leaves O(|E|^3) of the remaining off-diagonal part E
+// (~5e-9 relative at |E| = 1e-4, measured on the special-spectra tests), orders below the residual it is tied to; from residual 1e-6
+// down the level IS the fixed 1e-8.  Measured (round 3): config 4, first 100 iterations: 3 sweeps per projection -> 1-2, 374 -> 531
+// iterations/s (a full solve to eps 1e-4: 1.37 -> 0.83 s in 650 -> 450 iterations); the 512 config-5 problems (5 small PSD cones
+// each): 460 200 -> 461 075 total iterations, quartiles unchanged.  The factor 1e-2 is deliberately timid: with 1e-1 (580
+// iterations/s) the golden SDP `feas0` at eps 1e-9 — an accelerated solve whose iteration count is chaotic anyway (650 .. 775
+// under 1e-9 perturbations of alpha) — once took 23 700 iterations instead of 750; with 1e-2 its worst observed run is 1900
+// (tools/dbg/psd_tol_effect.py, psd_tol_chaos.py).  SCS_HIP_PSD_TOL=fixed turns the coupling off.
+// nullptr (stand-alone projections, tests, the footer diagnostics): the fixed level above.
+__device__ __forceinline__ double psd_offtol2(const double *tol2) { return tol2 ? *tol2 : kPsdOffTol2; }
 constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int);
 
 struct PsdBatch {
@@ -384,8 +397,10 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
 //   k_psd_fmap: F = Pi_+(D + E) element by element; k_psd_gemm<R1>, <R2>: X+ = V F V'   7 / matrix (2 x 4 tiles per wavefront)
 // Same rotations, same MFMA sequences: bit-identical to MODE 0.
 template <int MODE>
-__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall) {
+__global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall,
+                                                          const double *tol2) {
   SCS_STALL_GUARD(stall);
+  const double offtol2 = psd_offtol2(tol2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // LDS: per wave S / transpose scratch (16x17) + W (16x17) doubles | red[16] | bc[2] | outer schedule (2*kPsdMaxH ints)
   double *lds = reinterpret_cast<double *>(smem_raw);
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 #if PSD_PROFILE >= 2
     if (tid == 0 && cidx == 0) printf("  block: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
 #endif
-    if (tid == 0) bc[0] = (off <= kPsdOffTol2 * tot || off == 0.) ? 1. : 0.;
+    if (tid == 0) bc[0] = (off <= offtol2 * tot || off == 0.) ? 1. : 0.;
     __syncthreads();
     const bool done = bc[0] != 0.;
     __syncthreads();
@@ -830,8 +845,9 @@ constexpr size_t kPsdMcLdsBytes = kPsdLdsBytes + 4 * kPsdMaxH * sizeof(int);  //
 // itself, keeps the results in registers, assembles the block in LDS, solves it and logs W_{t+1}: the 8 us pivot solve
 // disappears behind the 6 us of A tasks.  Same MFMA sequences on the same inputs: the same bits.
 __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int look_ahead, int *err,
-                                                              const int *stall) {
+                                                              const int *stall, const double *tol2) {
   SCS_STALL_GUARD(stall);
+  const double offtol2 = psd_offtol2(tol2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *lds = reinterpret_cast<double *>(smem_raw);
   double *red = lds + kPsdWaves * kPsdWaveLds;
@@ -1031,7 +1047,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
     }
     off = block_sum<kPsdThreads>(off, red);
     tot = block_sum<kPsdThreads>(tot, red);
-    if (tid == 0) bc[0] = (off <= kPsdOffTol2 * tot || off == 0.) ? 1. : 0.;
+    if (tid == 0) bc[0] = (off <= offtol2 * tot || off == 0.) ? 1. : 0.;
     __syncthreads();
     const bool done = bc[0] != 0.;
     __syncthreads();
@@ -1321,8 +1337,9 @@ constexpr int kPsdSmallMax = 32;
 constexpr int kPsdSLd = 33;
 
 __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm,
-                                                 const int *stall) {
+                                                 const int *stall, const double *tol2) {
   SCS_STALL_GUARD(stall);
+  const double offtol2 = psd_offtol2(tol2);
   __shared__ double S[32 * kPsdSLd], V[32 * kPsdSLd], T[32 * kPsdSLd];
   __shared__ double csc[16], css[16];
   const int lane = threadIdx.x, cidx = blockIdx.x;
@@ -1424,7 +1441,7 @@ __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *
 #if PSD_PROFILE >= 2
     if (lane == 0 && cidx == 0) printf("  small: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
 #endif
-    if (off <= kPsdOffTol2 * tot || off == 0.) break;
+    if (off <= offtol2 * tot || off == 0.) break;
 #if PSD_PROFILE
     prof[7] += 1.;
 #endif
@@ -1549,8 +1566,8 @@ __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *
 #endif
 }
 __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm,
-                                                       const int *stall) {
-  d_proj_psd_small(x, B, scratch, allow_warm, stall);
+                                                       const int *stall, const double *tol2) {
+  d_proj_psd_small(x, B, scratch, allow_warm, stall, tol2);
 }
 
 // ---------------------------------------------------------------------------

@@ -593,7 +593,7 @@ struct ScsHipWork {
         // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
         hipLaunchKernelGGL(k_psd_front, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(kPsdFrontThreads), 0, stream,
                            (const double *)base, B, psd_scratch.p, psd_warm, stall);
-        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
+        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         int mc = in_capture ? 1 : psd_mc_members(big);
@@ -604,7 +604,8 @@ struct ScsHipWork {
             int *err = fl.p + F_PERSIST_ERR;
             const int *st = stall;
             int la = psd_mc_look_ahead;
-            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st};
+            const double *tl = psd_tol2;
+            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl};
             if (psd_mc_coop) {
               const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
                                                              dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream);
@@ -616,10 +617,10 @@ struct ScsHipWork {
               }
             } else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
               hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
-                                 la, err, st);
+                                 la, err, st, tl);
           }
           if (mc <= 1)
-          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall);
+          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall, psd_tol2);
           hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
         }
@@ -627,12 +628,12 @@ struct ScsHipWork {
         hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
       } else {
-        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall);
+        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2);
       }
     }
     if (count > big) {
       PsdBatch B{off + big, order + big, woff + big, count - big};
-      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall, psd_tol2);
     }
   }
   // Members (CUs) per matrix for the split-mode sweeps: as many as fit when every matrix gets the same number and a
@@ -662,6 +663,15 @@ struct ScsHipWork {
     return std::max(G, 1);
   }
   bool in_capture = false;
+  // stopping level of the PSD sweeps (psd.hpp psd_offtol2): inside the ADMM loop the iteration's P_PSD_TOL2, else nullptr = fixed 1e-8
+  const double *psd_tol2 = nullptr;
+  static bool psd_tol_adaptive() { static const bool on = [] { const char *e = getenv("SCS_HIP_PSD_TOL"); return !(e && e[0] == 'f'); }(); return on; }  // SCS_HIP_PSD_TOL=fixed: A/B
+  static double psd_tol2_of(double res_min) {
+    if (!psd_tol_adaptive()) return kPsdOffTol2;
+    static const double kappa = [] { const char *e = getenv("SCS_HIP_PSD_TOL_K"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1e-2; }();  // (lab knob; see psd.hpp psd_offtol2 for why 1e-2)
+    const double t = std::min(std::max(kappa * res_min, 1e-8), 1e-3);
+    return t * t;
+  }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
 
   // AA (aa.hpp): f = v (map output), x = v_prev (map input); the safeguard verdict rides along with the CG flags
@@ -880,6 +890,7 @@ struct ScsHipWork {
     h_params[P_RES_MIN] = cg_res_min;  // residuals of the last convergence CHECK (not of a logging-only evaluation)
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
+    h_params[P_PSD_TOL2] = psd_tol2_of(cg_res_min);
   }
   // everything of project_lin_sys up to (and including) the fused, warm-started CG start
   void enqueue_lin_sys_head() {
@@ -939,7 +950,9 @@ struct ScsHipWork {
   void enqueue_cones() {  // (tau is formed in k_cone_pre's prologue from the k_tau_dots partials)
     hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
                        d_params, sc.p, part.p, vb(l - 1), diag_r.p, stall_fl);
+    psd_tol2 = d_params + P_PSD_TOL2;
     project_nonlinear_cones(u.p + n, 1);
+    psd_tol2 = nullptr;
   }
   void enqueue_v_update() {
     hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l, part_v.p, stall);
@@ -985,7 +998,9 @@ struct ScsHipWork {
       hipLaunchKernelGGL(k_cone_pre, dim3(vb(l)), dim3(kVecThreads), 0, stream, ut.p, u.p, v.p, g.p, n, m, cone.z, cone.l,
                          d_params, sc.p, part.p, vb(l - 1), diag_r.p, stall_fl);
       HIP_CHECK(hipEventRecord(ev_cone[slot][0], stream));
+      psd_tol2 = d_params + P_PSD_TOL2;
       project_nonlinear_cones(u.p + n, 1);
+      psd_tol2 = nullptr;
       HIP_CHECK(hipEventRecord(ev_cone[slot][1], stream));
       cone_sampled[slot] = true;
     } else {

@@ -36,7 +36,7 @@ enum : int {
 // computed from an unconverged linear solve; the host then lowers both flags and resumes from the intact CG state.
 
 // per-iteration host scalars, kept in mapped pinned memory so that captured hipGraphs stay static
-enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_COUNT = 8 };
+enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_PSD_TOL2, P_COUNT = 8 };
 
 __host__ __device__ inline int vec_blocks(long n) {
   long nb = (n + 4L * kVecThreads - 1) / (4L * kVecThreads);

@@ -210,7 +210,7 @@ struct GroupSolve {
   static bool member_ok(const ScsHipWork *w) {
     if (w->At.cs.ok || w->Ar.cs.ok || w->At.has_slab || w->Ar.has_slab) return false;
     if (w->has_P && (w->Pf.cs.ok || w->Pf.has_slab)) return false;
-    if (w->persist_wgs > 0 || !w->log_csv_filename.empty() || w->mark_iter >= 0) return false;
+    if (w->persist_wgs > 0 || !w->log_csv_filename.empty() || w->mark_iter >= 0 || w->stgs.verbose) return false;  // (a verbose member prints its own table: solved by scs_solve)
     if (w->n_psd_big > 0 || w->n_cs > 0 || w->n_soc_big > 0 || w->cone.bsize > kBoxMultiMin) return false;
     if (w->aa.mem > 0 && !w->aa.tsqr) return false;
     return true;
@@ -633,7 +633,7 @@ struct GroupSolve {
         p[P_RES_MIN] = cg_res_min[(size_t)g];
         p[P_IPOW] = std::pow((double)i + 1, 1.5);
         p[P_FIRST] = i < 1 ? 1.0 : 0.0;
-        p[P_PSD_TOL2] = ScsHipWork::psd_tol2_of(cg_res_min[(size_t)g]);
+        p[P_PSD_TOL2] = ScsHipWork::psd_tol2_of(W[(size_t)g]->psd_res_min);
       }
       HIP_CHECK(hipMemcpyAsync(params_d.p, params_h, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
       tmp_list.clear();
@@ -645,7 +645,8 @@ struct GroupSolve {
       if (has_P) go(t_spmv_pws, active_d, na);
       go(t_spmv_r0, active_d, na);
       go(t_fin_head, active_d, na);
-      finish_cg(active, active_d, 0, [&](int g) { return W[(size_t)g]->recent_cg_max() + 1; }, [&] {
+      static const int pred_mode = [] { const char *e = getenv("SCS_HIP_GROUP_PREDICT"); return e ? atoi(e) : 1; }();  // 0: max + 1 (lab)
+      finish_cg(active, active_d, 0, [&](int g) { return pred_mode ? W[(size_t)g]->recent_cg_q3() : W[(size_t)g]->recent_cg_max() + 1; }, [&] {
         // first synchronisation of the iteration: everything the host deferred
         for (int g : aa_solved) {
           ScsHipWork *w = W[(size_t)g];
@@ -692,7 +693,7 @@ struct GroupSolve {
           w->r.last_iter = i;
           w->consume_residuals(res_h + (size_t)g * kResRec);
           if (!check) continue;
-          w->cg_res_min = std::min(w->r.nm_pri_n, w->r.nm_dual_n);
+          w->note_check_residuals();
           cg_res_min[(size_t)g] = w->cg_res_min;
           if ((infos[(size_t)g]->status_val = w->has_converged(i)) != 0) { stop[(size_t)g] = 1; continue; }
           if (w->stgs.time_limit_secs > 0 && (now_ms() - t_start) > 1e3 * w->stgs.time_limit_secs) { stop[(size_t)g] = 1; continue; }

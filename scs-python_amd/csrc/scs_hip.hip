@@ -688,7 +688,22 @@ struct ScsHipWork {
   int cg_hist[8] = {8, 8, 8, 8, 8, 8, 8, 8}, cg_hist_pos = 0;  // CG steps of the last 8 linear solves (chunk sizing)
   void note_cg_iters(int it) { cg_hist[cg_hist_pos++ & 7] = it; }
   int recent_cg_max() const { int mx = 1; for (int v : cg_hist) mx = std::max(mx, v); return mx; }
+  int recent_cg_q3() const {  // third quartile of the last 8 linear solves (the grouped loop's prediction: a short round is cheap there)
+    int h[8];
+    std::copy(cg_hist, cg_hist + 8, h);
+    std::sort(h, h + 8);
+    return std::max(1, h[5]);
+  }
   double cg_res_min = 0;
+  // what the PSD stopping level follows (psd_tol2_of): the smallest of the residuals ANY termination test looks at —
+  // primal / dual residual and, for a problem drifting towards a certificate, the certificate's own residuals
+  double psd_res_min = 0;
+  void note_check_residuals() {
+    cg_res_min = std::min(r.nm_pri_n, r.nm_dual_n);
+    psd_res_min = cg_res_min;
+    for (double c : {r.res_infeas, r.res_unbdd_a, r.res_unbdd_p})
+      if (std::isfinite(c)) psd_res_min = std::min(psd_res_min, c);
+  }
   // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
   bool profile = false;
   double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
@@ -890,7 +905,7 @@ struct ScsHipWork {
     h_params[P_RES_MIN] = cg_res_min;  // residuals of the last convergence CHECK (not of a logging-only evaluation)
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
-    h_params[P_PSD_TOL2] = psd_tol2_of(cg_res_min);
+    h_params[P_PSD_TOL2] = psd_tol2_of(psd_res_min);
   }
   // everything of project_lin_sys up to (and including) the fused, warm-started CG start
   void enqueue_lin_sys_head() {
@@ -1377,6 +1392,7 @@ struct ScsHipWork {
     aa.reset(); aa.success = 0; aa.pending_safeguard = false; aa.st = ScsAaStats{};
     r = Residuals{};
     cg_res_min = 0;
+    psd_res_min = 0;
     tot_cg_iters = 0;
     prof_ms[0] = prof_ms[1] = 0;
     prof_n[0] = prof_n[1] = 0;
@@ -2010,7 +2026,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       if (csv) w->populate_residuals(i);
       if (check) {
         w->populate_residuals(i);
-        w->cg_res_min = std::min(w->r.nm_pri_n, w->r.nm_dual_n);
+        w->note_check_residuals();
         if ((info->status_val = w->has_converged(i)) != 0) {
           if (csv) w->log_csv_row(csv, i, now_ms() - t_start);
           break;

@@ -633,7 +633,7 @@ struct GroupSolve {
         p[P_RES_MIN] = cg_res_min[(size_t)g];
         p[P_IPOW] = std::pow((double)i + 1, 1.5);
         p[P_FIRST] = i < 1 ? 1.0 : 0.0;
-        p[P_PSD_TOL2] = ScsHipWork::psd_tol2_of(W[(size_t)g]->psd_res_min);
+        p[P_PSD_TOL2] = W[(size_t)g]->psd_tol2_for(i);
       }
       HIP_CHECK(hipMemcpyAsync(params_d.p, params_h, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
       tmp_list.clear();

@@ -63,17 +63,24 @@ constexpr int kPsdMaxH = 512;  // pivots per step: order <= 8192 (LDS schedule a
 #define PSD_OFFTOL2 1e-16
 #endif
 constexpr double kPsdOffTol2 = PSD_OFFTOL2;  // sweeps stop at ||offdiag||_F^2 <= this * ||A||_F^2 (see the reconstruction)
-// Inside the ADMM loop the stopping level follows the residuals, as the tolerance of the inexact linear solve does (vec.hpp k_fin_head):
-// tol2 points at the iteration's P_PSD_TOL2 = clamp(1e-2 * residual, 1e-8, 1e-3)^2 (scs_hip.hip psd_tol2_of; the residual is the
-// smaller of the normalised primal / dual residuals of the last convergence check).  While the iterate is far from the solution an
-// eigen-decomposition to 1e-8 buys nothing: the second-order reconstruction leaves O(|E|^3) of the remaining off-diagonal part E
-// (~5e-9 relative at |E| = 1e-4, measured on the special-spectra tests), orders below the residual it is tied to; from residual 1e-6
-// down the level IS the fixed 1e-8.  Measured (round 3): config 4, first 100 iterations: 3 sweeps per projection -> 1-2, 374 -> 531
-// iterations/s (a full solve to eps 1e-4: 1.37 -> 0.83 s in 650 -> 450 iterations); the 512 config-5 problems (5 small PSD cones
-// each): 460 200 -> 461 075 total iterations, quartiles unchanged.  The factor 1e-2 is deliberately timid: with 1e-1 (580
-// iterations/s) the golden SDP `feas0` at eps 1e-9 — an accelerated solve whose iteration count is chaotic anyway (650 .. 775
-// under 1e-9 perturbations of alpha) — once took 23 700 iterations instead of 750; with 1e-2 its worst observed run is 1900
-// (tools/dbg/psd_tol_effect.py, psd_tol_chaos.py).  SCS_HIP_PSD_TOL=fixed turns the coupling off.
+// Inside the ADMM loop — while the Anderson history is still filling, i.e. in the first lookback x interval iterations (always, without
+// acceleration) — the stopping level follows the residuals, as the tolerance of the inexact linear solve does (vec.hpp k_fin_head):
+// tol2 points at the iteration's P_PSD_TOL2 = clamp(level, 1e-8, 1e-3)^2, level = min(1e-2 * primal/dual residual, certificate
+// residuals) of the last convergence check (scs_hip.hip note_check_residuals / psd_tol2_of).  While the iterate is far from the
+// solution an eigen-decomposition to 1e-8 buys nothing: the second-order reconstruction leaves O(|E|^3) of the remaining off-diagonal
+// part E (~5e-9 relative at |E| = 1e-4, measured on the special-spectra tests), orders below the residual it is tied to; from
+// residual 1e-6 down the level IS the fixed 1e-8.  Measured (round 3): config 4, iterations 5..105: 3 sweeps per projection -> 1-2,
+// cone pass 1.8 -> 1.18 ms, 374 -> 495 iterations/s; a whole config-4 solve to 1e-4: 750 iterations in 1.5 s; the 512 config-5
+// problems (5 small PSD cones each): total iterations unchanged to 1 %.  Why it is this timid — factor 1e-2, certificate residuals
+// at full weight, off once Anderson extrapolates:
+//  * factor 1e-1 (551 iterations/s): the golden SDP `feas0` at eps 1e-9, an accelerated solve whose iteration count is chaotic anyway
+//    (650 .. 1050 under 1e-9 perturbations of alpha), took 7000 iterations instead of 750 (23 700 when the level stayed on for the
+//    whole solve); with 1e-2 its worst observed run is 1900 (tools/dbg/psd_tol_effect.py, psd_tol_chaos.py);
+//  * a problem drifting to an infeasibility / unboundedness certificate has a LARGE primal/dual residual for good: tied to that alone
+//    the sweeps stayed at 1e-3 and a golden infeasible instance never met eps_infeas (tools/dbg/psd_tol_infeas.py: all 18 golden
+//    certificate cases x the acceleration variants terminate as with the fixed level now);
+//  * plain ADMM tolerates inexact projections, the secant model of the acceleration does not (type-II steps at interval 1 stalled).
+// SCS_HIP_PSD_TOL=fixed turns the coupling off (SCS_HIP_PSD_TOL_K = the factor, lab knob).
 // nullptr (stand-alone projections, tests, the footer diagnostics): the fixed level above.
 __device__ __forceinline__ double psd_offtol2(const double *tol2) { return tol2 ? *tol2 : kPsdOffTol2; }
 constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * sizeof(double) + 2 * kPsdMaxH * sizeof(int);

@@ -666,10 +666,20 @@ struct ScsHipWork {
   // stopping level of the PSD sweeps (psd.hpp psd_offtol2): inside the ADMM loop the iteration's P_PSD_TOL2, else nullptr = fixed 1e-8
   const double *psd_tol2 = nullptr;
   static bool psd_tol_adaptive() { static const bool on = [] { const char *e = getenv("SCS_HIP_PSD_TOL"); return !(e && e[0] == 'f'); }(); return on; }  // SCS_HIP_PSD_TOL=fixed: A/B
-  static double psd_tol2_of(double res_min) {
-    if (!psd_tol_adaptive()) return kPsdOffTol2;
+  // ... and only while no Anderson extrapolation can happen yet (the history is still filling: iteration < lookback x interval;
+  // always, without acceleration): plain ADMM tolerates inexact projections, the secant model of the acceleration does not —
+  // with interval 1 and type-II steps a golden infeasible instance stalled for good (tools/dbg/psd_tol_infeas.py).
+  double psd_tol2_for(int iter) const {
+    const bool plain_phase = aa.mem <= 0 || (long)iter < (long)aa.mem * stgs.acceleration_interval;
+    return plain_phase ? psd_tol2_of(psd_res_min) : kPsdOffTol2;
+  }
+  static double psd_kappa() {
     static const double kappa = [] { const char *e = getenv("SCS_HIP_PSD_TOL_K"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1e-2; }();  // (lab knob; see psd.hpp psd_offtol2 for why 1e-2)
-    const double t = std::min(std::max(kappa * res_min, 1e-8), 1e-3);
+    return kappa;
+  }
+  static double psd_tol2_of(double level) {  // level = what note_check_residuals left in psd_res_min
+    if (!psd_tol_adaptive()) return kPsdOffTol2;
+    const double t = std::min(std::max(level, 1e-8), 1e-3);
     return t * t;
   }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
@@ -700,9 +710,10 @@ struct ScsHipWork {
   double psd_res_min = 0;
   void note_check_residuals() {
     cg_res_min = std::min(r.nm_pri_n, r.nm_dual_n);
-    psd_res_min = cg_res_min;
-    for (double c : {r.res_infeas, r.res_unbdd_a, r.res_unbdd_p})
-      if (std::isfinite(c)) psd_res_min = std::min(psd_res_min, c);
+    psd_res_min = psd_kappa() * cg_res_min;
+    if (std::isfinite(r.res_infeas)) psd_res_min = std::min(psd_res_min, r.res_infeas);
+    // (an unboundedness certificate needs BOTH of its residuals small; |Px| / -c'x is identically 0 for an LP)
+    if (std::isfinite(r.res_unbdd_a) && std::isfinite(r.res_unbdd_p)) psd_res_min = std::min(psd_res_min, std::max(r.res_unbdd_a, r.res_unbdd_p));
   }
   // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
   bool profile = false;
@@ -905,7 +916,9 @@ struct ScsHipWork {
     h_params[P_RES_MIN] = cg_res_min;  // residuals of the last convergence CHECK (not of a logging-only evaluation)
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
-    h_params[P_PSD_TOL2] = psd_tol2_of(psd_res_min);
+    h_params[P_PSD_TOL2] = psd_tol2_for(iter);
+    static const bool dbg_tol = getenv("SCS_HIP_DEBUG_TOL") != nullptr;  // tools/dbg/run_ahead_tol.py
+    if (dbg_tol) std::fprintf(stderr, "[scs-hip] iter %d slot %d: res_min %.17g psd level %.3e tol2 %.3e\n", iter, slot, cg_res_min, psd_res_min, h_params[P_PSD_TOL2]);
   }
   // everything of project_lin_sys up to (and including) the fused, warm-started CG start
   void enqueue_lin_sys_head() {
@@ -1127,6 +1140,11 @@ struct ScsHipWork {
   }
 
   void project_lin_sys(int iter, bool graph) {
+    // The parameter block is host memory the kernels read in place, and the cones of the previous iteration (enqueued, not
+    // waited for) read P_PSD_TOL2 from this slot.  It moves after convergence checks (the stream is idle then) and ONCE
+    // more, when the residual-tied level is switched off (psd_tol2_for): wait before overwriting it.  (Run-ahead
+    // iterations alternate between two slots instead: enqueue_plain_iteration.)
+    if (n_psd + n_cs > 0 && psd_tol2_for(iter) != h_params_base[P_PSD_TOL2]) HIP_CHECK(hipStreamSynchronize(stream));
     set_iter_params(iter);
     ensure_v_norm();
     if (persist_wgs > 0) {

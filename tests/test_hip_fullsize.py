@@ -211,13 +211,15 @@ def test_config4_shaped_qp_matches_constructed_solution_entrywise(hip):
     (test above: certificate + p*), so this is the strictly convex QP of the same shape — s = [200] * 50 + l,
     m = 1 006 000 — whose (x, y, s) is unique and known by construction (LAPACK eigh projections, independent of the
     oracle and of the HIP kernels): entry-wise agreement at 1e-4 of the largest entry, through the split-mode MFMA
-    eigen-solve path with warm starts"""
+    eigen-solve path with warm starts.  Solved at eps 1e-8: at 1e-7 the dual's entry-wise error is 0.7e-4 .. 1.6e-4 of
+    the largest entry (the accuracy eps buys, measured with either PSD stopping level — tools/dbg/config4_qp_entry.py),
+    i.e. on the bar itself; at 1e-8 it is 5e-6"""
     import scs
     import helpers
     K = {"l": 1000, "s": [200] * 50}
     data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, 335000, 30, 44, helpers.proj_dual_l_s_numpy)
     assert data["A"].shape == (1006000, 335000)
-    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-7, eps_rel=1e-7, verbose=False,
+    sol = scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=1e-8, eps_rel=1e-8, verbose=False,
                   max_iters=20000).solve()
     info = sol["info"]
     assert info["status"] == "solved", info

@@ -128,6 +128,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
                          % (args.gpus, world, args.gpus))
 
+    # before ANY HIP runtime is loaded (torch's comes first): the same default scs._scs_hip sets — see its _runtime_env
+    if os.environ.get("SCS_HIP_RUNTIME_ENV", "1") != "0":
+        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
     import torch  # first: its bundled HIP runtime must be the one in the process
     import torch.distributed as dist
     import numpy as np
@@ -205,6 +208,13 @@ def main():
         solver = scs.SCS(data, K, max_iters=steps, **common)
         if not os.environ.get("BENCH_NO_INSITU"):
             solver._solver._set_profiling(True)
+        # Quiet start: some 0.1-0.3 s after host pages that the runtime had pinned for a copy are released (the previous
+        # workload's matrix, the generator's temporaries) the kernel driver evicts this process's queues for 30-80 ms — one
+        # hole in the middle of whatever runs then; a 40 ms config-2 solve took 115 ms in ~40 % of the default runs
+        # (~10 % with GPU_PINNED_MIN_XFER_SIZE raised as above; profiles/r03_queue_eviction.txt).  Everything of this
+        # workload is allocated and warmed up by now: let that pass before the clock starts.
+        torch.cuda.synchronize()
+        time.sleep(0.4)
         # ---------------- timed region: exactly K ADMM iterations ----------------
         barrier()
         t0 = time.perf_counter()

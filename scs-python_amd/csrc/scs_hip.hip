@@ -60,6 +60,22 @@ static double now_ms() {
 //    one stream anyway).  Streams are never destroyed.
 //  * one pinned, device-mapped block per workspace holds all its host-side scalars / flags; finished workspaces
 //    return their block to a free list.
+// Runtime configuration set when this library is loaded (before the HIP runtime reads its flags at the first API call; an
+// existing value is kept, SCS_HIP_RUNTIME_ENV=0 leaves the environment alone): GPU_PINNED_MIN_XFER_SIZE (MiB).  Below it
+// the runtime stages copies from / to pageable memory through its own pinned buffers; above it it pins the CALLER's pages
+// (a userptr registration with the kernel driver), and some time after such pages are released or unmapped the driver
+// evicts every queue of this process for 30-80 ms.  Measured (tools/dbg/config2_inflow.py, profiles/r03_queue_eviction.txt):
+// a config-2 solve of 40 ms takes 115 ms in ~40 % of the runs that follow another workload's release; ONE hole of 30-80 ms
+// between two already-queued kernels in the rocprofv3 trace; 0 of 48 with the threshold raised; own staging of every
+// transfer >= 64 KiB, or hipHostRegister / hipHostUnregister around the copy, did not remove it (28 % / 46 %).  Cost: scs_init
+// of the metric workload 81 -> 86 ms, the 40 MB of x, y, s at the end of a solve 2 ms later.
+// (priority 101: before this library's own HIP module constructor talks to the runtime; scs/_scs_hip.py and bench.py set the
+// same default before they load the runtime at all)
+__attribute__((constructor(101))) static void scs_hip_runtime_env() {
+  const char *off = getenv("SCS_HIP_RUNTIME_ENV");
+  if (!(off && off[0] == '0')) setenv("GPU_PINNED_MIN_XFER_SIZE", "1000000", 0);
+}
+
 struct StreamPool {
   struct Dev { std::vector<hipStream_t> streams; std::vector<int> users; };
   std::mutex mtx;
@@ -679,7 +695,8 @@ struct ScsHipWork {
   }
   static double psd_tol2_of(double level) {  // level = what note_check_residuals left in psd_res_min
     if (!psd_tol_adaptive()) return kPsdOffTol2;
-    const double t = std::min(std::max(level, 1e-8), 1e-3);
+    static const double cap = [] { const char *e = getenv("SCS_HIP_PSD_TOL_MAX"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1e-3; }();  // (lab knob)
+    const double t = std::min(std::max(level, 1e-8), cap);
     return t * t;
   }
   int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
@@ -1047,10 +1064,26 @@ struct ScsHipWork {
     static const bool on = getenv("SCS_HIP_DEBUG_PIPE") != nullptr;
     return on;
   }
+  // host wait for an event: SCS_HIP_WAIT=block -> hipEventSynchronize, spin -> poll hipEventQuery (lab knob)
+  static int wait_mode() {
+    static const int m = [] { const char *e = getenv("SCS_HIP_WAIT"); return e && e[0] == 's' ? 1 : 0; }();
+    return m;
+  }
+  static void wait_event(hipEvent_t e) {
+    if (wait_mode() == 1) {
+      for (;;) {
+        const hipError_t q = hipEventQuery(e);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) HIP_CHECK(q);
+        __builtin_ia32_pause();
+      }
+    }
+    HIP_CHECK(hipEventSynchronize(e));
+  }
   bool finish_plain_iteration(int iter) {
     const int slot = iter & 1;
     HIP_CHECK(hipGetLastError());  // a refused launch (hipLaunchKernelGGL reports nothing) surfaces here, once per iteration
-    HIP_CHECK(hipEventSynchronize(ev_iter[slot]));
+    wait_event(ev_iter[slot]);
     const int *hf = h_flags_slot[slot];
     if (hf[F_STALL]) {
       ++pipe_stalls;

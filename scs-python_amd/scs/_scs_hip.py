@@ -112,7 +112,17 @@ def _preload_hip_runtime():
             pass
 
 
+def _runtime_env():
+    """Runtime configuration that must be in the environment BEFORE the HIP runtime reads its flags (csrc/scs_hip.hip
+    scs_hip_runtime_env has the measurements): keep the runtime from pinning the caller's pageable arrays for host <->
+    device copies — the driver evicts the process's queues for 30-80 ms some time after such pages are released.
+    An existing value wins; SCS_HIP_RUNTIME_ENV=0 leaves the environment alone."""
+    if os.environ.get("SCS_HIP_RUNTIME_ENV", "1") != "0":
+        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
+
+
 def _load():
+    _runtime_env()
     path = os.path.join(_HERE, _LIB_NAME)
     if not os.path.exists(path):
         raise ImportError(

@@ -66,9 +66,9 @@ static double now_ms() {
 // (a userptr registration with the kernel driver), and some time after such pages are released or unmapped the driver
 // evicts every queue of this process for 30-80 ms.  Measured (tools/dbg/config2_inflow.py, profiles/r03_queue_eviction.txt):
 // a config-2 solve of 40 ms takes 115 ms in ~40 % of the runs that follow another workload's release; ONE hole of 30-80 ms
-// between two already-queued kernels in the rocprofv3 trace; 0 of 48 with the threshold raised; own staging of every
-// transfer >= 64 KiB, or hipHostRegister / hipHostUnregister around the copy, did not remove it (28 % / 46 %).  Cost: scs_init
-// of the metric workload 81 -> 86 ms, the 40 MB of x, y, s at the end of a solve 2 ms later.
+// between two already-queued kernels in the rocprofv3 trace; ~10 % with the threshold raised (own staging of every transfer or
+// hipHostRegister / hipHostUnregister around the copy: 8-28 % / 46 %).  Cost: scs_init of the metric workload 81 -> 88 ms; x, y, s leave through
+// a pinned mirror of the workspace instead (download_solution), which is as fast as the pinning path was.
 // (priority 101: before this library's own HIP module constructor talks to the runtime; scs/_scs_hip.py and bench.py set the
 // same default before they load the runtime at all)
 __attribute__((constructor(101))) static void scs_hip_runtime_env() {
@@ -577,6 +577,48 @@ struct ScsHipWork {
   DevBuf<int> fl;
   DevBuf<double> solx, soly, sols;
   bool sol_on_device = false;  // solx/soly/sols hold the final (x, y, s) of the last solve
+  // large solutions leave through a pinned mirror owned by the workspace (the caller's arrays are never handed to the runtime,
+  // see scs_hip_runtime_env): three DMA copies in flight, each array moved on by a few host threads as soon as it has landed
+  double *sol_pin = nullptr;
+  hipEvent_t sol_ev[3] = {nullptr, nullptr, nullptr};
+  static constexpr size_t kSolMirrorMin = (size_t)1 << 20;  // bytes of x | y | s from which the mirror is used
+  static void spread_memcpy(void *dst, const void *src, size_t bytes) {
+    const int nt = bytes >= ((size_t)8 << 20) ? 4 : 1;
+    if (nt == 1) { std::memcpy(dst, src, bytes); return; }
+    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    for (int t = 1; t < nt; ++t) {
+      const size_t o = std::min(bytes, part * t), c = std::min(bytes - o, part);
+      th[t - 1] = std::thread([=] { if (c) std::memcpy((char *)dst + o, (const char *)src + o, c); });
+    }
+    std::memcpy(dst, src, std::min(bytes, part));
+    for (int t = 1; t < nt; ++t) th[t - 1].join();
+  }
+  void ensure_solution_mirror() {  // (scs_init calls this: pinning 40 MB costs milliseconds)
+    const size_t bytes = sizeof(double) * ((size_t)n + 2 * (size_t)m);
+    if (sol_pin || bytes < kSolMirrorMin) return;
+    HIP_CHECK(hipHostMalloc((void **)&sol_pin, bytes, hipHostMallocDefault));
+    for (auto &e : sol_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  void download_solution(ScsSolution *sol) {
+    const size_t bytes = sizeof(double) * ((size_t)n + 2 * (size_t)m);
+    if (bytes < kSolMirrorMin) {
+      solx.download(sol->x, n, stream);
+      soly.download(sol->y, m, stream);
+      sols.download(sol->s, m, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      return;
+    }
+    ensure_solution_mirror();
+    double *hx = sol_pin, *hy = sol_pin + n, *hs = sol_pin + n + m;
+    solx.download(hx, n, stream); HIP_CHECK(hipEventRecord(sol_ev[0], stream));
+    soly.download(hy, m, stream); HIP_CHECK(hipEventRecord(sol_ev[1], stream));
+    sols.download(hs, m, stream); HIP_CHECK(hipEventRecord(sol_ev[2], stream));
+    HIP_CHECK(hipEventSynchronize(sol_ev[0])); spread_memcpy(sol->x, hx, sizeof(double) * n);
+    HIP_CHECK(hipEventSynchronize(sol_ev[1])); spread_memcpy(sol->y, hy, sizeof(double) * m);
+    HIP_CHECK(hipEventSynchronize(sol_ev[2])); spread_memcpy(sol->s, hs, sizeof(double) * m);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
   int part_len = 0;
 
   // cones
@@ -756,6 +798,8 @@ struct ScsHipWork {
       if (h_params_base) (void)hipHostFree(h_params_base);
       for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
     }
+    if (sol_pin) (void)hipHostFree(sol_pin);
+    for (auto &e : sol_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
     for (auto &es : ev_prof) for (auto &e : es) if (e) (void)hipEventDestroy(e);
     for (auto &es : ev_cone) for (auto &e : es) if (e) (void)hipEventDestroy(e);
@@ -1544,12 +1588,9 @@ struct ScsHipWork {
         break;
     }
     hipLaunchKernelGGL(k_scale3, dim3(vb((long)n + m)), dim3(kVecThreads), 0, stream, solx.p, soly.p, sols.p, n, m, fx, fy, fs);
-    solx.download(sol->x, n, stream);
-    soly.download(sol->y, m, stream);
-    sols.download(sol->s, m, stream);
     // (nothing is left running when scs_solve returns: a device-wide synchronize issued by the caller right after an
     // un-synchronised kernel was measured to take 25 ms on this runtime)
-    HIP_CHECK(hipStreamSynchronize(stream));
+    download_solution(sol);
     sol_on_device = true;
     {
       double cs = 0.;
@@ -1905,6 +1946,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->h.alloc_zero(l, s);
   for (DevBuf<double> *b : {&w->cg_b, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_M, &w->ws}) b->alloc_zero(n, s);
   w->tmp_m.alloc_zero(m, s);
+  w->ensure_solution_mirror();
   w->solx.alloc_zero(n, s);
   w->soly.alloc_zero(m, s);
   w->sols.alloc_zero(m, s);

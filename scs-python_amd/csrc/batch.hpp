@@ -580,7 +580,17 @@ struct GroupSolve {
     upload_active();
     std::vector<int> tmp_list;
     const bool stats = getenv("SCS_HIP_GROUP_STATS") != nullptr;
+    InterruptListener ctrlc;  // (scs_hip.hip: Ctrl-C ends every member that is still running with SCS_SIGINT)
     for (int i = 0; !active.empty(); ++i) {
+      if (InterruptListener::interrupted()) {
+        sync();
+        for (int g : active) {
+          infos[(size_t)g]->status_val = SCS_SIGINT;
+          W[(size_t)g]->finish_solve(sols[(size_t)g], infos[(size_t)g], i, t_start, t_lin, t_cone, t_acc, /*grouped=*/true);
+        }
+        active.clear();
+        break;
+      }
       ++lockstep_iters;
       const int na = (int)active.size();
       if (stats && (i % 200 == 0 || (i < 200 && i % 50 == 0)))

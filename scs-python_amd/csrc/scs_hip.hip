@@ -16,6 +16,7 @@
 //   v  += alpha (u - u_t)
 #include <atomic>
 #include <chrono>
+#include <csignal>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -182,6 +183,120 @@ struct DeviceCsr {
     HIP_CHECK(hipStreamSynchronize(s));
     return true;
   }
+  // ---- virtual rows (spmv_cs.hpp CsView::Rr): long rows cut into pieces that ride in the passes ----
+  struct VirtPlan {
+    int R = 0, rpt = 0, nchunks = 0, Rr = 0, Rp = 0, V = 0;
+    std::vector<int2> rowinfo;  // per row {first piece, pieces} or {-1, 0}
+  };
+  static bool virt_enabled() {  // SCS_HIP_CS_VIRT=0: long rows go to the CSR-stream side launch whole (round 2)
+    const char *e = getenv("SCS_HIP_CS_VIRT");
+    return !(e && e[0] == '0');
+  }
+  // rows longer than lp nonzeros -> ceil(len / lp) pieces; fills the peel mask / row blocks {row, row + 1, first piece, end}
+  bool plan_virtual(const int *rp, int lp, VirtPlan &P, hipStream_t s) {
+    clear_peel();
+    P.rowinfo.assign((size_t)rows, int2{-1, 0});
+    std::vector<int4> blk;
+    std::vector<unsigned> mask(((size_t)rows + 31) / 32, 0u);
+    long V = 0;
+    for (int r = 0; r < rows; ++r) {
+      const int len = rp[r + 1] - rp[r];
+      if (len <= lp) continue;
+      const int np = (len + lp - 1) / lp;
+      P.rowinfo[(size_t)r] = int2{(int)V, np};
+      blk.push_back(int4{r, r + 1, (int)V, (int)V + np});
+      mask[(size_t)r >> 5] |= 1u << (r & 31);
+      V += np;
+      peel_nnz += len;
+      if (V > 500000000L) return false;
+    }
+    if (blk.empty()) return false;
+    P.V = (int)V;
+    const long total = (long)rows + V;
+    if (total > 2000000000L) return false;
+    cs_pick_geometry((int)total, P.R, P.rpt, 1);
+    for (;;) {  // every chunk: Rr real-row slots + Rp piece slots
+      P.nchunks = (int)((total + P.R - 1) / P.R);
+      P.Rp = (P.V + P.nchunks - 1) / P.nchunks;
+      P.Rr = P.R - P.Rp;
+      if (P.Rr >= 1 && (long)P.nchunks * P.Rr >= rows) break;
+      P.R += 64;
+      while (P.R > kCsThreads * P.rpt) P.rpt *= 2;
+      if (P.rpt > 16) return false;
+    }
+    npeel = (int)blk.size();
+    npeel_long = 0;  // (a row's pieces are few: one wavefront adds them)
+    peel_mask.upload(mask.data(), mask.size(), s);
+    peel_blk.upload(blk.data(), blk.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    return true;
+  }
+  void adopt_virtual(const VirtPlan &P, hipStream_t s) {
+    cs.rows = rows;
+    cs.Rr = P.Rr; cs.Rp = P.Rp; cs.npieces = P.V;
+    cs.tpart.alloc_zero((size_t)P.V, s);
+  }
+  bool build_virtual_dev(const DeviceCsr &T, const int *rp, int lp, hipStream_t s) {
+    VirtPlan P;
+    if (!plan_virtual(rp, lp, P, s)) return false;
+    DevBuf<int2> d_info;
+    DevBuf<int> vslot;
+    d_info.upload(P.rowinfo.data(), P.rowinfo.size(), s);
+    vslot.alloc((size_t)nnz);
+    hipLaunchKernelGGL(k_cs_vslot, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, T.rowptr.p, T.col.p, cols, (long)nnz, rowptr.p, col.p,
+                       d_info.p, P.Rr, P.Rp, P.R, vslot.p);
+    HIP_CHECK(hipStreamSynchronize(s));  // (P.rowinfo is read by the upload)
+    const bool built = cs.build_from_transpose(P.nchunks * P.R, cols, T.rowptr.p, vslot.p, T.val.p, nnz, s, 1, nullptr, P.R, P.rpt);
+    if (getenv("SCS_HIP_SETUP_TIMING"))
+      std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d: rows longer than %d in pieces (%d rows, %ld of %ld nonzeros, %d pieces; chunks of %d + %d slots, %d rows per lane): %s\n",
+                   rows, cols, lp, npeel, peel_nnz, (long)nnz, P.V, P.Rr, P.Rp, P.rpt, built ? "built" : "a count field overflowed");
+    if (!built) { clear_peel(); return false; }
+    adopt_virtual(P, s);
+    return true;
+  }
+  bool build_virtual_host(const int *rp, const int *ci, const double *v, int lp, hipStream_t s, HostCs &h) {
+    VirtPlan P;
+    if (!plan_virtual(rp, lp, P, s)) return false;
+    const long slots = (long)P.nchunks * P.R;
+    std::vector<int> vrp((size_t)slots + 1, 0), vci((size_t)nnz), where((size_t)nnz);
+    std::vector<double> vv((size_t)nnz);
+    auto slot_of = [&](int r, int k) {
+      const int2 info = P.rowinfo[(size_t)r];
+      return info.x < 0 ? cs_slot_of_row(r, P.Rr, P.R) : cs_slot_of_piece(info.x + k % info.y, P.Rr, P.Rp, P.R);
+    };
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < rp[r + 1] - rp[r]; ++k) vrp[(size_t)slot_of(r, k) + 1]++;
+    for (long i = 0; i < slots; ++i) vrp[(size_t)i + 1] += vrp[(size_t)i];
+    std::vector<int> fill(vrp.begin(), vrp.end() - 1);
+    for (int r = 0; r < rows; ++r)  // rows in order, a row's nonzeros in ascending column order: every slot ends up ascending
+      for (int k = 0; k < rp[r + 1] - rp[r]; ++k) {
+        const int d = fill[(size_t)slot_of(r, k)]++;
+        vci[(size_t)d] = ci[rp[r] + k];
+        vv[(size_t)d] = v[rp[r] + k];
+      }
+    const bool built = build_cs(vrp.data(), vci.data(), vv.data(), (int)slots, cols, h, P.rpt, 1, nullptr, P.R);
+    if (!built) { clear_peel(); return false; }
+    h.rows = rows;
+    virt_host_plan = P;
+    return true;
+  }
+  VirtPlan virt_host_plan;
+  // pieces per pass to aim for (x the passes a chunk is expected to have = the piece length): smaller pieces, more slots
+  std::vector<int> virt_piece_lengths() const {
+    const long npass_est = std::max<long>(1, (long)nnz / kCsTargetWgs / kCsPass);
+    const int whole = peel_threshold(1);  // rows a count field holds stay whole (and keep the oracle's summation order)
+    std::vector<int> out;
+    for (int per_pass : {24, 12, 6}) {
+      const int lp = (int)std::max<long>(whole, std::min<long>(per_pass * npass_est, 1L << 20));
+      if (out.empty() || out.back() != lp) out.push_back(lp);
+    }
+    return out;
+  }
+  static std::vector<int> peel_ladder() {  // SCS_HIP_CS_PEEL_LADDER=0: rows longer than a count field at once (round 2)
+    const char *e = getenv("SCS_HIP_CS_PEEL_LADDER");
+    if (e && e[0] == '0') return {1};
+    return {32, 16, 8, 4, 2, 1};
+  }
   int peel_threshold(int split) const {
     int R, rpt;
     cs_pick_geometry(rows, R, rpt, split);
@@ -246,9 +361,23 @@ struct DeviceCsr {
     auto attempt = [&](int split) {
       clear_peel();
       if (cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, nullptr)) return true;
-      if (!make_peel(rp.data(), peel_threshold(split), s)) return false;
-      if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
-      return cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, peel_mask.p);
+      // the long rows cut into pieces that ride in the passes (one workgroup per chunk: split 1) ...
+      if (virt_enabled())
+        for (int lp : virt_piece_lengths())
+          if (build_virtual_dev(T, rp.data(), lp, s)) return true;
+      // ... or, failing that, peeled as FEW rows as the count fields allow: a row of 500 nonzeros has ~50 in each of its chunk's ten passes and
+      // rides in them (its gathers share lines with the other rows' there); thresholds from 32 x the field down to the field
+      for (int mult : peel_ladder()) {
+        if (!make_peel(rp.data(), peel_threshold(split) * mult, s)) continue;  // (no row that long: next rung)
+        if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
+        const bool built = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, peel_mask.p);
+        if (getenv("SCS_HIP_SETUP_TIMING"))
+          std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d, split %d: rows longer than %d peeled (%d rows, %ld of %ld nonzeros): %s\n",
+                       rows, cols, split, peel_threshold(split) * mult, npeel, peel_nnz, (long)nnz, built ? "built" : "a count field overflowed");
+        if (built) return true;
+      }
+      clear_peel();
+      return false;
     };
     if (sp > 1) ok = attempt(sp);
     if (!ok) ok = attempt(1);
@@ -263,22 +392,31 @@ struct DeviceCsr {
     const char *env = getenv("SCS_HIP_SLAB");
     if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
     HostCs h;
-    bool ok = false;
+    bool ok = false, virt_host = false;
     const int sp = cs_pick_split(kind);
     auto attempt = [&](int split) {  // same policy as build_cs_dev: unpeeled first, then the long rows peeled, capped
       clear_peel();
       if (build_cs(rp, ci, v, rows, cols, h, 0, split, nullptr)) return true;
-      if (!make_peel(rp, peel_threshold(split), s)) return false;
-      if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
-      std::vector<unsigned> mk(((size_t)rows + 31) / 32, 0u);
-      for (int r = 0; r < rows; ++r)
-        if (rp[r + 1] - rp[r] > peel_threshold(split)) mk[r >> 5] |= 1u << (r & 31);
-      return build_cs(rp, ci, v, rows, cols, h, 0, split, mk.data());
+      if (virt_enabled())
+        for (int lp : virt_piece_lengths())
+          if (build_virtual_host(rp, ci, v, lp, s, h)) { virt_host = true; return true; }
+      for (int mult : peel_ladder()) {
+        const int thresh = peel_threshold(split) * mult;
+        if (!make_peel(rp, thresh, s)) continue;
+        if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
+        std::vector<unsigned> mk(((size_t)rows + 31) / 32, 0u);
+        for (int r = 0; r < rows; ++r)
+          if (rp[r + 1] - rp[r] > thresh) mk[r >> 5] |= 1u << (r & 31);
+        if (build_cs(rp, ci, v, rows, cols, h, 0, split, mk.data())) return true;
+      }
+      clear_peel();
+      return false;
     };
     if (sp > 1) ok = attempt(sp);
     if (!ok) ok = attempt(1);
     if (!ok) { clear_peel(); return false; }
     cs.from_host(h, s);
+    if (virt_host) adopt_virtual(virt_host_plan, s);
     cs_after_build(s);
     return true;
   }
@@ -1478,9 +1616,15 @@ struct ScsHipWork {
     if (persist_wgs > 0)
       std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (PCG, persistent %dx%d-wave kernel)",
                     persist_wgs, 4 * persist_ng);
-    else
-      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV, PCG)",
-                    At.cs.ok ? "column-sorted pass" : At.has_slab ? "L2-blocked slab" : "CSR-stream");
+    else {
+      // what became of rows too long for the pass layout's count fields (A / A' / P): cut into pieces that ride in the passes, or
+      // peeled off and summed from the plain CSR by the side launch
+      const bool pieces = (Ar.cs.ok && Ar.cs.npieces > 0) || (At.cs.ok && At.cs.npieces > 0) || (has_P && Pf.cs.ok && Pf.cs.npieces > 0);
+      const bool peeled = !pieces && ((Ar.cs.ok && Ar.npeel > 0) || (At.cs.ok && At.npeel > 0) || (has_P && Pf.cs.ok && Pf.npeel > 0));
+      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV%s, PCG)",
+                    At.cs.ok ? "column-sorted pass" : At.has_slab ? "L2-blocked slab" : "CSR-stream",
+                    pieces ? ", long rows in pieces" : peeled ? ", long rows peeled" : "");
+    }
     // per-solve state
     sum_log_scale_factor = 0; n_log_scale_factor = 0; last_scale_update_iter = 0; scale_updates = 0;
     rejected_accel = 0; accepted_accel = 0; aa_norm = 0;
@@ -1577,6 +1721,12 @@ struct ScsHipWork {
         info->pobj = INFINITY; info->dobj = INFINITY;
         std::snprintf(info->status, sizeof(info->status), "%s",
                       info->status_val == SCS_INFEASIBLE ? "infeasible" : "infeasible (inaccurate - reached max_iters)");
+        break;
+      case SCS_SIGINT:  // stopped by Ctrl-C: nothing is returned, as after a failure
+        fx = fy = fs = NAN;
+        info->gap = info->res_pri = info->res_dual = NAN;
+        info->pobj = info->dobj = NAN;
+        std::snprintf(info->status, sizeof(info->status), "interrupted");
         break;
       default:
         fx = fs = -1. / r.ctx_tau;
@@ -2016,8 +2166,40 @@ static void fill_nan(double *p, long nelem) {
   for (long i = 0; i < nelem; ++i) p[i] = NAN;
 }
 
+// ---- Ctrl-C: the reference builds its core with -DCTRLC=1 (R:meson.build:118) and reports SCS_SIGINT = -5, "interrupted"
+// (R:scs/py/__init__.py:20).  While at least one solve runs, SIGINT is caught here (the previous disposition — Python's handler — comes
+// back when the last one returns); every ADMM loop looks at the flag once per iteration and stops with that status and NaN vectors,
+// as a failure does.  A ctypes / glue call into a multi-second device loop is otherwise uninterruptible.  SCS_HIP_CTRLC=0: hands off.
+struct InterruptListener {
+  static std::atomic<int> &flag() { static std::atomic<int> f{0}; return f; }
+  static void on_sigint(int) { flag().store(1, std::memory_order_relaxed); }
+  static bool enabled() { static const bool on = [] { const char *e = getenv("SCS_HIP_CTRLC"); return !(e && e[0] == '0'); }(); return on; }
+  static std::mutex &mtx() { static std::mutex m; return m; }
+  static int &users() { static int u = 0; return u; }
+  static struct sigaction &saved() { static struct sigaction sa; return sa; }
+  InterruptListener() {
+    if (!enabled()) return;
+    std::lock_guard<std::mutex> g(mtx());
+    if (users()++ == 0) {
+      flag().store(0);
+      struct sigaction sa;
+      std::memset(&sa, 0, sizeof(sa));
+      sa.sa_handler = on_sigint;
+      sigemptyset(&sa.sa_mask);
+      sigaction(SIGINT, &sa, &saved());
+    }
+  }
+  ~InterruptListener() {
+    if (!enabled()) return;
+    std::lock_guard<std::mutex> g(mtx());
+    if (--users() == 0) sigaction(SIGINT, &saved(), nullptr);
+  }
+  static bool interrupted() { return enabled() && flag().load(std::memory_order_relaxed) != 0; }
+};
+
 static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) {
   std::lock_guard<std::mutex> lock(w->mtx);
+  InterruptListener ctrlc;
   HIP_CHECK(hipSetDevice(w->device));
   const double t_start = now_ms();
   const int n = w->n, m = w->m;
@@ -2070,6 +2252,10 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   int enq_upto = -1;  // run-ahead: last iteration already in the queue
   w->mark_ms = -1;
   for (i = 0; i < max_iters; ++i) {
+    if (InterruptListener::interrupted()) {
+      info->status_val = SCS_SIGINT;
+      break;
+    }
     if (i == w->mark_iter) {
       HIP_CHECK(hipStreamSynchronize(s));
       w->mark_ms = now_ms() - t_start;
@@ -2272,6 +2458,7 @@ static scs_int solve_one_group(ScsWork **works, ScsSolution **sols, ScsInfo **in
 scs_int scs_hip_solve_batch(ScsWork **works, ScsSolution **sols, ScsInfo **infos, scs_int count, scs_int warm_start) {
   if (!works || !sols || !infos || count < 0) return -1;
   set_last_error("");
+  InterruptListener ctrlc;  // for the whole call: members solved one after the other all see the same Ctrl-C
   for (int i = 0; i < count; ++i) {
     if (!works[i] || !sols[i] || !infos[i]) { set_last_error("scs_hip_solve_batch: null entry"); return -1; }
     for (int j = 0; j < i; ++j)

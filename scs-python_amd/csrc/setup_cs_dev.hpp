@@ -87,6 +87,34 @@ __global__ __launch_bounds__(1024) void k_cs_scatter(const int *__restrict__ tpt
   }
 }
 
+// Virtual rows (spmv_cs.hpp CsView::Rr): the row SLOT of every nonzero of T.  rowinfo[r] = {first piece, pieces} of a split row,
+// {-1, 0} otherwise; the k-th nonzero (ascending column) of a split row goes to piece k mod np — k by binary search of the
+// nonzero's column (the row of T holding position p) in M's own CSR row.
+__host__ __device__ inline int cs_slot_of_row(int r, int Rr, int R) { return (r / Rr) * R + r % Rr; }
+__host__ __device__ inline int cs_slot_of_piece(int p, int Rr, int Rp, int R) { return (p / Rp) * R + Rr + p % Rp; }
+__global__ __launch_bounds__(256) void k_cs_vslot(const int *__restrict__ tptr, const int *__restrict__ trow, int trows, long nnz,
+                                                  const int *__restrict__ mrowptr, const int *__restrict__ mcol,
+                                                  const int2 *__restrict__ rowinfo, int Rr, int Rp, int R, int *__restrict__ vslot) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  const int r = trow[p];
+  const int2 info = rowinfo[r];
+  if (info.x < 0) { vslot[p] = cs_slot_of_row(r, Rr, R); return; }
+  int lo = 0, hi = trows;  // the row of T (= column of M) holding position p: tptr[lo] <= p < tptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tptr[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int c = lo;
+  int a = mrowptr[r], b = mrowptr[r + 1];  // first position with mcol >= c
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (mcol[mid] < c) a = mid + 1; else b = mid;
+  }
+  const int k = a - mrowptr[r];
+  vslot[p] = cs_slot_of_piece(info.x + k % info.y, Rr, Rp, R);
+}
+
 // one workgroup: passes of every (chunk, part).  pass_info = {first stream position, nonzeros, first column, chunk}
 __global__ __launch_bounds__(1024) void k_cs_cut(const int *__restrict__ hoff, int nblocks, int nchunks, int split, long nnz,
                                                  const int *__restrict__ s_col, int max_pass, int *passptr, int4 *pass_info, int *fail) {
@@ -209,9 +237,12 @@ struct DeviceCs {
   DevBuf<double> scratch;    // in-kernel combine of split layouts (CsView::scratch / ticket); empty: partial outputs
   DevBuf<unsigned> ticket;
   int rows = 0, cols = 0, nchunks = 0, R = 0, npass = 0, rpt = 0, split = 1;
+  int Rr = 0, Rp = 0, npieces = 0;  // virtual rows (CsView): real-row / piece slots per chunk, pieces in all
+  DevBuf<double> tpart;             // their sums
   bool ok = false;
   void release() {
-    passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release(); scratch.release(); ticket.release();
+    passptr.release(); pinfo.release(); idx.release(); val.release(); meta.release(); scratch.release(); ticket.release(); tpart.release();
+    Rr = Rp = npieces = 0;
     ok = false;
   }
   bool combine() const { return ok && split > 1 && ticket.p != nullptr; }
@@ -225,9 +256,12 @@ struct DeviceCs {
     CsView v{passptr.p, pinfo.p, idx.p, val.p, meta.p, rows, cols, nchunks, R, npass, rpt, split};
     v.scratch = scratch.p;
     v.ticket = ticket.p;
+    v.Rr = Rr; v.Rp = Rp; v.npieces = npieces; v.tpart = tpart.p;
     return v;
   }
   void from_host(const HostCs &h, hipStream_t s) {
+    Rr = Rp = npieces = 0;
+    tpart.release();
     rows = h.rows; cols = h.cols; nchunks = h.nchunks; R = h.R; npass = h.npass; rpt = h.rpt; split = h.split;
     passptr.upload(h.passptr.data(), h.passptr.size(), s);
     pinfo.upload(h.pinfo.data(), h.pinfo.size(), s);
@@ -239,11 +273,13 @@ struct DeviceCs {
   }
   // layout for the matrix M (rows_ x cols_) whose TRANSPOSE is the CSR (tptr, trow, tval) with cols_ rows.
   // false (and nothing kept) when the pattern does not fit the format: the caller keeps its other layouts.
+  // force_R / force_rpt: the caller's geometry (virtual rows: `trow` holds row SLOTS, rows_ = nchunks * R of them)
   bool build_from_transpose(int rows_, int cols_, const int *tptr, const int *trow, const double *tval, long nnz, hipStream_t s,
-                            int split_ = 1, const unsigned *peel = nullptr) {
+                            int split_ = 1, const unsigned *peel = nullptr, int force_R = 0, int force_rpt = 0) {
     release();
     rows = rows_; cols = cols_; split = split_;
     cs_pick_geometry(rows, R, rpt, split);
+    if (force_R > 0) { R = force_R; rpt = force_rpt; }
     nchunks = (rows + R - 1) / R;
     const int nblocks = (int)((nnz + kCsBlock - 1) / kCsBlock);
     if (nnz <= 0 || nchunks > kCsMaxChunks || (long)nchunks * nblocks > (long)kScanTile * kScanTile || nnz > 2000000000L) return false;

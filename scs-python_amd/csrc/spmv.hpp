@@ -620,7 +620,9 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_slab(SlabView A, const do
 // flight, then a fixed shuffle tree.  (A row this long is no longer summed in the oracle's sequential order: 1e-13 rel.)
 constexpr int kPeelRowsPerWg = kSpmvThreads / 64, kPeelLongRow = 2048;
 inline int peel_wgs_for(int npeel, int nlong) { return nlong + (npeel - nlong + kPeelRowsPerWg - 1) / kPeelRowsPerWg; }
-template <class Epi>
+// PIECES (virtual rows of the column-sorted layout): blk[i] = {row, row + 1, first piece, end} and A.val = the piece sums the
+// pass kernel left behind — the same tree over those instead of over products.
+template <class Epi, bool PIECES = false>
 __global__ __launch_bounds__(kSpmvThreads) void k_spmv_peeled(CsrView A, const double *__restrict__ x, Epi epi, const int *done_flag) {
   if (done_flag && *done_flag) return;
   __shared__ double red[kSpmvThreads / 64];
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(kSpmvThreads) void k_spmv_peeled(CsrView A, const d
     const int4 bi = A.blk[i];
     row = bi.x;
 #pragma unroll 8
-    for (int k = bi.z + first; k < bi.w; k += step) acc += A.val[k] * x[A.col[k]];
+    for (int k = bi.z + first; k < bi.w; k += step) acc += PIECES ? A.val[k] : A.val[k] * x[A.col[k]];
   }
   if (whole_wg) {
     acc = block_sum<kSpmvThreads>(acc, red);
@@ -741,7 +743,12 @@ inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const
       S.nlong = M.nlong;
       S.pstride = nmain + M.peel_wgs();
       S.pbase = nmain;
-      hipLaunchKernelGGL(k_spmv_peeled<Epi>, dim3(M.peel_wgs()), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag);
+      if (M.cs.npieces > 0) {  // virtual rows: the long rows' nonzeros rode in the passes; add up their pieces
+        S.val = M.cs.tpart;
+        hipLaunchKernelGGL((k_spmv_peeled<Epi, true>), dim3(M.peel_wgs()), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag);
+      } else {
+        hipLaunchKernelGGL((k_spmv_peeled<Epi, false>), dim3(M.peel_wgs()), dim3(kSpmvThreads), 0, s, S, x, epi, done_flag);
+      }
     }
     return;
   }

@@ -54,7 +54,20 @@ struct CsView {
   // and done by a CSR-stream side launch on the plain CSR (spmv.hpp launch_spmv); their epilogue is skipped here.
   const unsigned *peel = nullptr;
   int pstride = 0, pbase = 0;  // reduction partials: slot stride / first slot (0: this launch's own workgroup count / 0)
+  // Virtual rows (round 3): the R row slots of a chunk are Rr REAL rows (chunk c: rows c * Rr ...) followed by Rp PIECE slots
+  // (pieces c * Rp ...).  A row too long for the count fields has no nonzeros in its own slot (its `peel` bit is set: no epilogue
+  // here); its nonzeros are dealt round-robin — the k-th of the row to piece k mod np — to np piece slots, which spreads every
+  // piece over all passes of its chunk (a piece holds 1/np of what the row has in any column range) and the pieces over all
+  // chunks.  A piece slot's sum goes to tpart[piece]; spmv.hpp launch_spmv adds a row's pieces (fixed wave tree) and runs the
+  // epilogue on the finished row.  Plain layouts: Rr = R, Rp = 0.
+  int Rr = 0, Rp = 0, npieces = 0;
+  double *tpart = nullptr;
 };
+__host__ __device__ inline int cs_rr(const CsView &A) { return A.Rr > 0 ? A.Rr : A.R; }
+// slot (row-local index rl of chunk c) -> what the finished sum is: a real row's (epilogue) or a piece's (stored)
+template <class Epi>
+__device__ __forceinline__ void cs_slot_done(const CsView &A, const Epi &epi, int part, int c, int rl, double s, double *sums, double *maxs,
+                                             bool finished);
 __host__ __device__ inline bool cs_is_peeled(const unsigned *peel, int r) { return peel && ((peel[r >> 5] >> (r & 31)) & 1u); }
 
 // bits per row count in a run descriptor; 16 rows per lane use two words (8 counts each)
@@ -123,10 +136,10 @@ __host__ __device__ inline int cs_store_pos(int q) {
 // format's bit fields (a pass wider than 2^19 columns, or more nonzeros of one row in one pass than the count
 // field holds): the caller keeps the slab / CSR-stream layout.
 inline bool build_cs(const int *rowptr, const int *col, const double *val, int rows, int cols, HostCs &out, int force_rpt = 0,
-                     int split = 1, const unsigned *peel = nullptr) {
+                     int split = 1, const unsigned *peel = nullptr, int force_R = 0) {
   int R, rpt;
   cs_pick_geometry(rows, R, rpt, split);
-  if (force_rpt > 0) { rpt = force_rpt; R = kCsThreads * rpt; }
+  if (force_rpt > 0) { rpt = force_rpt; R = force_R > 0 ? force_R : kCsThreads * rpt; }
   const int nchunks = (rows + R - 1) / R;
   const int cb = cs_count_bits(rpt);
   const unsigned maxcnt = (1u << cb) - 1;
@@ -211,6 +224,22 @@ __device__ __forceinline__ void cs_epilogue(const Epi &epi, int split, int part,
     if (split > 1) { epi.split(r, s, part, sums, maxs); return; }
   }
   epi(r, s, sums, maxs);
+}
+
+template <class Epi>
+__device__ __forceinline__ void cs_slot_done(const CsView &A, const Epi &epi, int part, int c, int rl, double s, double *sums, double *maxs,
+                                             bool finished) {
+  const int Rr = cs_rr(A);
+  if (rl < Rr) {
+    const int r = c * Rr + rl;
+    if (r < A.rows && !cs_is_peeled(A.peel, r)) {
+      if (finished) epi(r, s, sums, maxs);  // (in-kernel combine: the plain epilogue on finished rows)
+      else cs_epilogue(epi, A.split, part, r, s, sums, maxs);
+    }
+  } else if (rl < A.R) {
+    const int p = c * A.Rp + (rl - Rr);
+    if (p < A.npieces) A.tpart[p] = s;
+  }
 }
 
 // Row sums of one pass from the LDS product buffer: m = {first slot of the lane's run | the lane's RPT counts}.
@@ -313,8 +342,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs(CsView A, const double *
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    cs_slot_done(A, epi, part, c, j * kCsThreads + tid, acc[j], sums, maxs, false);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
     const int nslot = A.pstride > 0 ? A.pstride : (int)gridDim.x, slot = A.pbase + wg;
@@ -429,8 +457,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_ga(CsView A, const doubl
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
+    cs_slot_done(A, epi, part, c, j * kCsThreads + tid, acc[j], sums, maxs, false);
   }
   if constexpr (Epi::kSums > 0 || Epi::kMaxs > 0) {
     const int nslot = A.pstride > 0 ? A.pstride : (int)gridDim.x, slot = A.pbase + wg;
@@ -658,11 +685,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
   }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
-    const int rl = j * kCsThreads + tid, r = c * A.R + rl;
-    if (rl < A.R && r < A.rows && !cs_is_peeled(A.peel, r)) {
-      if (combine) epi(r, acc[j], sums, maxs);  // finished rows: the plain epilogue
-      else cs_epilogue(epi, A.split, part, r, acc[j], sums, maxs);
-    }
+    cs_slot_done(A, epi, part, c, j * kCsThreads + tid, acc[j], sums, maxs, combine);
   }
   CS_TL_STAMP(4);
   CS_TL_FLUSH();

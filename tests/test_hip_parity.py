@@ -838,6 +838,15 @@ def test_spmv_skewed_patterns_keep_the_layout(hip, oracle, monkeypatch, pattern,
             np.testing.assert_allclose(got[mode][k][~short], ref[k][~short], rtol=1e-12, atol=1e-12 * np.abs(ref[k]).max())
     for k in (0, 1):
         np.testing.assert_array_equal(got["device"][k], got["host"][k])
+    # round 3: the long rows ride in the passes as pieces (default); SCS_HIP_CS_VIRT=0 = the side launch of round 2 sums them
+    # whole from the plain CSR.  Rows the passes keep whole have the same bits either way; long rows agree to the tree's rounding.
+    monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
+    old = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
+    for k in (0, 1):
+        short = lens[k] <= 63
+        if split == "0" or k == 0:  # (A' with peeled rows keeps two workgroups per chunk: partial sums; with pieces it is one)
+            np.testing.assert_array_equal(old[k][short], got["host"][k][short])
+        np.testing.assert_allclose(old[k], got["host"][k], rtol=0, atol=1e-12 * np.abs(ref[k]).max())
 
 
 def test_solve_with_dense_rows_stays_on_the_column_sorted_layout(hip, oracle, monkeypatch):
@@ -860,6 +869,12 @@ def test_solve_with_dense_rows_stays_on_the_column_sorted_layout(hip, oracle, mo
     stg = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False)
     got = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
     assert "column-sorted" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]
+    assert "long rows in pieces" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]  # (round 2: "peeled")
+    monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
+    old = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
+    assert "long rows peeled" in old["info"]["lin_sys_solver"], old["info"]["lin_sys_solver"]
+    assert old["info"]["status"] == "solved" and abs(old["info"]["iter"] - got["info"]["iter"]) <= 50
+    monkeypatch.delenv("SCS_HIP_CS_VIRT")
     monkeypatch.setenv("SCS_HIP_SLAB", "0")
     ref = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
     assert "CSR-stream" in ref["info"]["lin_sys_solver"]

@@ -336,3 +336,58 @@ def test_cs_cone_reference_cases(scs):
     np.testing.assert_allclose(sol["x"], [-10.0, 0.0, 0.0, -10.0], atol=1e-3)
     with pytest.raises(ValueError):  # dims: cs=[2] is 4 rows, not 3
         scs.SCS({"A": sp.eye(3, 3, format="csc"), "b": np.ones(3), "c": np.ones(3)}, {"cs": [2]})
+
+
+# ---- Ctrl-C: R:meson.build:118 (-DCTRLC=1), status SIGINT = -5 (R:scs/py/__init__.py:20) ----
+_SIGINT_CHILD = r'''
+import json, os, sys, time
+sys.path[:0] = [os.path.join(ROOT, "scs-python_amd"), os.path.join(ROOT, "tests"), ROOT]
+os.environ["SCS_HIP_GROUP_MIN"] = "2"  # three equally shaped members ARE a group (default: 16)
+import numpy as np
+import scs, problem_gen as pg
+from scs import _scs_hip
+proj = lambda z, K: _scs_hip.proj_cone(z, K, dual=True)
+K = {"l": 3000, "q": [10] * 100}
+def make(seed):
+    data, _, _ = pg.gen_feasible(K, 1500, 8, seed, proj)
+    return scs.SCS(data, K, linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0,
+                   max_iters=100000000, verbose=False)
+solvers = [make(7 + i) for i in range(GROUP)]
+print("READY", flush=True)
+t = time.time()
+sols = scs.solve_batch(solvers) if GROUP > 1 else [solvers[0].solve()]
+out = [{"status": s["info"]["status"], "status_val": s["info"]["status_val"], "iter": s["info"]["iter"],
+        "x_nan": bool(np.isnan(s["x"]).all() and np.isnan(s["y"]).all() and np.isnan(s["s"]).all())} for s in sols]
+# the listener is gone again: Python's own handler is back (a second Ctrl-C would raise KeyboardInterrupt)
+import signal
+out.append({"handler_restored": signal.getsignal(signal.SIGINT) is signal.default_int_handler, "seconds": time.time() - t})
+print(json.dumps(out), flush=True)
+'''
+
+
+@pytest.mark.parametrize("group", [1, 3], ids=["scs_solve", "solve_batch"])
+def test_sigint_stops_the_device_loop_with_status_interrupted(scs, tmp_path, group):
+    """A ctypes call into a device loop that would run for hours: SIGINT is caught by the library while a solve runs, the loop
+    stops at the next iteration and reports status "interrupted" (-5) with NaN vectors (the reference's CTRLC=1 behaviour);
+    afterwards Python's handler is in place again."""
+    import json, os, signal, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sigint_child.py"
+    script.write_text("ROOT = %r\nGROUP = %d\n" % (root, group) + _SIGINT_CHILD)
+    p = subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        line = p.stdout.readline()
+        assert line.strip() == "READY", (line, p.stderr.read() if p.poll() is not None else "")
+        time.sleep(3.0)  # the solve is under way (it would not end by itself)
+        assert p.poll() is None
+        p.send_signal(signal.SIGINT)
+        out, err = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 0, err[-2000:]
+    res = json.loads([x for x in out.splitlines() if x.startswith("[")][-1])
+    for r in res[:-1]:
+        assert r["status"] == "interrupted" and r["status_val"] == -5 and r["x_nan"], r
+        assert r["iter"] > 100
+    assert res[-1]["handler_restored"] and res[-1]["seconds"] < 30

@@ -192,8 +192,11 @@ struct DeviceCsr {
     const char *e = getenv("SCS_HIP_CS_VIRT");
     return !(e && e[0] == '0');
   }
-  // rows longer than lp nonzeros -> ceil(len / lp) pieces; fills the peel mask / row blocks {row, row + 1, first piece, end}
+  // rows longer than max(lp, what a count field holds) nonzeros -> ceil(len / lp) pieces (rows a field holds stay whole and keep
+  // the oracle's summation order; a piece's run is added by ONE lane, so pieces are short whatever the field would hold);
+  // fills the peel mask / row blocks {row, row + 1, first piece, end}
   bool plan_virtual(const int *rp, int lp, VirtPlan &P, hipStream_t s) {
+    const int long_thresh = std::max(lp, peel_threshold(1));
     clear_peel();
     P.rowinfo.assign((size_t)rows, int2{-1, 0});
     std::vector<int4> blk;
@@ -201,7 +204,7 @@ struct DeviceCsr {
     long V = 0;
     for (int r = 0; r < rows; ++r) {
       const int len = rp[r + 1] - rp[r];
-      if (len <= lp) continue;
+      if (len <= long_thresh) continue;
       const int np = (len + lp - 1) / lp;
       P.rowinfo[(size_t)r] = int2{(int)V, np};
       blk.push_back(int4{r, r + 1, (int)V, (int)V + np});
@@ -248,8 +251,8 @@ struct DeviceCsr {
     HIP_CHECK(hipStreamSynchronize(s));  // (P.rowinfo is read by the upload)
     const bool built = cs.build_from_transpose(P.nchunks * P.R, cols, T.rowptr.p, vslot.p, T.val.p, nnz, s, 1, nullptr, P.R, P.rpt);
     if (getenv("SCS_HIP_SETUP_TIMING"))
-      std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d: rows longer than %d in pieces (%d rows, %ld of %ld nonzeros, %d pieces; chunks of %d + %d slots, %d rows per lane): %s\n",
-                   rows, cols, lp, npeel, peel_nnz, (long)nnz, P.V, P.Rr, P.Rp, P.rpt, built ? "built" : "a count field overflowed");
+      std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d: rows longer than %d in pieces of <= %d (%d rows, %ld of %ld nonzeros, %d pieces; chunks of %d + %d slots, %d rows per lane): %s\n",
+                   rows, cols, std::max(lp, peel_threshold(1)), lp, npeel, peel_nnz, (long)nnz, P.V, P.Rr, P.Rp, P.rpt, built ? "built" : "a count field overflowed");
     if (!built) { clear_peel(); return false; }
     adopt_virtual(P, s);
     return true;
@@ -284,12 +287,8 @@ struct DeviceCsr {
   // pieces per pass to aim for (x the passes a chunk is expected to have = the piece length): smaller pieces, more slots
   std::vector<int> virt_piece_lengths() const {
     const long npass_est = std::max<long>(1, (long)nnz / kCsTargetWgs / kCsPass);
-    const int whole = peel_threshold(1);  // rows a count field holds stay whole (and keep the oracle's summation order)
     std::vector<int> out;
-    for (int per_pass : {24, 12, 6}) {
-      const int lp = (int)std::max<long>(whole, std::min<long>(per_pass * npass_est, 1L << 20));
-      if (out.empty() || out.back() != lp) out.push_back(lp);
-    }
+    for (int per_pass : {24, 12, 6}) out.push_back((int)std::min<long>(per_pass * npass_est, 1L << 20));
     return out;
   }
   static std::vector<int> peel_ladder() {  // SCS_HIP_CS_PEEL_LADDER=0: rows longer than a count field at once (round 2)

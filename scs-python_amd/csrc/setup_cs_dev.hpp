@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_cs_fill(const int4 *__restrict__ pass_
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int n = cnt[cs_row_key(j * kCsThreads + tid, RPT)];
-    if (n > (1 << CB) - 1) atomicExch(fail, 1);
+    if (n > cs_peel_threshold(RPT)) atomicExch(fail, 1);  // (build_cs: the field's capacity, and never more than 2048 per pass)
     const unsigned long long nb = (unsigned long long)(n & ((1 << CB) - 1));
     if (RPT < 16 || j < 8) w |= nb << (16 + CB * j);
     else w1 |= nb << (CB * (j - 8));

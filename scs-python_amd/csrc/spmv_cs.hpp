@@ -142,7 +142,10 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
   if (force_rpt > 0) { rpt = force_rpt; R = force_R > 0 ? force_R : kCsThreads * rpt; }
   const int nchunks = (rows + R - 1) / R;
   const int cb = cs_count_bits(rpt);
-  const unsigned maxcnt = (1u << cb) - 1;
+  // longest run of one row inside one pass: what the count field holds, and not more than 2048 — the lane that owns the row adds its
+  // run sequentially (a 70 000-nonzero budget row left whole made every pass of its chunk wait 8191 dependent adds: a solve of 6 s
+  // took 87 s, tools/dbg/dense_rows_solve.py); longer rows are cut into pieces (CsView::Rr) or peeled by the caller
+  const unsigned maxcnt = (unsigned)cs_peel_threshold(rpt);
   out.rows = rows; out.cols = cols; out.R = R; out.rpt = rpt; out.nchunks = nchunks; out.split = split;
   out.passptr.assign((size_t)nchunks * split + 1, 0);
   out.pinfo.clear(); out.idx.clear(); out.val.clear(); out.meta.clear();

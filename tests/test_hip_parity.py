@@ -870,10 +870,15 @@ def test_solve_with_dense_rows_stays_on_the_column_sorted_layout(hip, oracle, mo
     got = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
     assert "column-sorted" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]
     assert "long rows in pieces" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]  # (round 2: "peeled")
+    # a budget row left WHOLE in the passes (one lane adding its 8191 products of every pass one after the other) made this solve
+    # take 87 s instead of ~1 s for a while in round 3: rows with more than 2048 nonzeros in a pass never ride whole
+    assert got["info"]["solve_time"] < 30e3, got["info"]["solve_time"]
     monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
     old = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
     assert "long rows peeled" in old["info"]["lin_sys_solver"], old["info"]["lin_sys_solver"]
-    assert old["info"]["status"] == "solved" and abs(old["info"]["iter"] - got["info"]["iter"]) <= 50
+    # (long rows are summed in another order: an accelerated solve to 1e-7 lands a few per cent of iterations away — 3450 / 3600 / 3575
+    # with pieces / peeled / CSR-stream)
+    assert old["info"]["status"] == "solved" and abs(old["info"]["iter"] - got["info"]["iter"]) <= 0.15 * got["info"]["iter"]
     monkeypatch.delenv("SCS_HIP_CS_VIRT")
     monkeypatch.setenv("SCS_HIP_SLAB", "0")
     ref = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)

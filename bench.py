@@ -31,7 +31,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
     ranks, each rank's shard ONE grouped solve (scs.solve_batch: the problems share every kernel launch), one
     gather of the solutions; aggregate ADMM iters/s.
   * other_configs (N=1): one bench line each for BASELINE.json configs[1..3] (config 3 with its box cone, config 4
-    with the MFMA roofline of the batched PSD projection).
+    with the MFMA roofline of the batched PSD projection), plus two lines at the metric workload's size with other sparsity
+    patterns: power-law row lengths (layout robustness) and banded (the locality ceiling of K1 / K2, always the LAST line).
 """
 import argparse
 import json
@@ -408,7 +409,8 @@ def main():
     other = None
     if world == 1 and not args.no_other_configs:
         other = []
-        for wl, st, wu in (("config2_lp_soc", 100, 10), ("config3_mixed", 20, 3), ("config4_psd", 100, 5), ("banded_lp", 20, 2)):
+        for wl, st, wu in (("config2_lp_soc", 100, 10), ("config3_mixed", 20, 3), ("config4_psd", 100, 5), ("powerlaw_lp", 20, 2),
+                           ("banded_lp", 20, 2)):
             if wl == args.workload:
                 continue
             line, _, _ = measure(wl, st, wu, steady=False, gather=False)
@@ -418,6 +420,11 @@ def main():
                     "conditioning, not cone kernels: R_y weighs the 100,000 zero-cone rows 1000 x heavier than the others "
                     "(1/(1000 scale) vs 1/scale), the reduced system's condition number is ~1e3 and Jacobi-preconditioned CG needs "
                     "~330 steps per solve; with the same rows declared `l` it needs 13 (profiles/r03_config3_cg_study.txt)")
+            if wl == "powerlaw_lp":
+                line["config"]["why_this_line"] = (
+                    "not a BASELINE config: the metric workload's size with Pareto(1.3) row lengths (up to 20 000 nonzeros per row) — "
+                    "layout robustness: rows too long for the pass layout's count fields ride in the passes as pieces "
+                    "(round 2: summed whole by a side launch, K1 164.6 us, 152.6 iters/s; profiles/r03_patterns.txt)")
             if wl == "banded_lp":
                 line["config"]["why_this_line"] = (
                     "not a BASELINE config: the metric workload's size with a banded pattern — the same K1 / K2 kernels when the gathers "

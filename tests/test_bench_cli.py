@@ -87,9 +87,10 @@ def test_other_configs_lines_and_ungrouped_batch_leg():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     oc = out["other_configs"]
-    assert [o["config"]["workload"].split(":")[0] for o in oc] == ["config2_lp_soc", "config3_mixed", "config4_psd", "banded_lp"]
+    assert [o["config"]["workload"].split(":")[0] for o in oc] == ["config2_lp_soc", "config3_mixed", "config4_psd", "powerlaw_lp", "banded_lp"]
     assert "'bu': '99999 values'" in oc[1]["config"]["workload"] and "m=999999" in oc[1]["config"]["workload"]
     assert oc[2]["roofline"]["bound"] == "mfma" and oc[2]["roofline"]["frac"] > 0 and oc[0]["roofline"]["bound"] == "hbm"
     assert all(o["value"] > 0 and o["steps"] == o["config"]["admm_iters_timed"] for o in oc)
-    assert oc[3]["roofline"]["frac"] > oc[0]["roofline"]["frac"]  # gathers with locality: the ceiling of the decomposition
+    assert oc[-1]["roofline"]["frac"] > oc[0]["roofline"]["frac"]  # gathers with locality: the ceiling of the decomposition
+    assert oc[3]["roofline"]["bound"] == "hbm" and "row lengths" in oc[3]["config"]["why_this_line"]  # power-law rows: the pass layout is kept
     assert out["config5_batch"]["solved"] == 6 and "one problem per stream" in out["config5_batch"]["workload"]

@@ -71,6 +71,10 @@ int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans
  * evaluates y += M x by walking it exactly as the kernel does (slot scatter, per-lane runs, pass order, partial sums).
  * No GPU needed.  Returns 0, 1 if the pattern does not fit the format, -1 on error. */
 int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split);
+/* Same walk for the virtual-row variant of that layout (round 3): rows longer than max(piece_len, what a count field
+ * holds) are cut into pieces of at most piece_len nonzeros that ride in the passes; the pieces of a row are then added
+ * the way the device does it (64 lanes striding over them, shuffle tree).  Returns 1 when no row is that long. */
+int scs_hip_cs_layout_host_spmv_pieces(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int piece_len);
 
 /* Time `reps` launches of the A (transpose=0) or A' (transpose=1) SpMV kernel
  * with HIP events on the launch stream; inputs already resident in HBM.

@@ -184,10 +184,7 @@ struct DeviceCsr {
     return true;
   }
   // ---- virtual rows (spmv_cs.hpp CsView::Rr): long rows cut into pieces that ride in the passes ----
-  struct VirtPlan {
-    int R = 0, rpt = 0, nchunks = 0, Rr = 0, Rp = 0, V = 0;
-    std::vector<int2> rowinfo;  // per row {first piece, pieces} or {-1, 0}
-  };
+  using VirtPlan = CsVirtPlan;
   static bool virt_enabled() {  // SCS_HIP_CS_VIRT=0: long rows go to the CSR-stream side launch whole (round 2)
     const char *e = getenv("SCS_HIP_CS_VIRT");
     return !(e && e[0] == '0');
@@ -196,41 +193,13 @@ struct DeviceCsr {
   // the oracle's summation order; a piece's run is added by ONE lane, so pieces are short whatever the field would hold);
   // fills the peel mask / row blocks {row, row + 1, first piece, end}
   bool plan_virtual(const int *rp, int lp, VirtPlan &P, hipStream_t s) {
-    const int long_thresh = std::max(lp, peel_threshold(1));
     clear_peel();
-    P.rowinfo.assign((size_t)rows, int2{-1, 0});
-    std::vector<int4> blk;
-    std::vector<unsigned> mask(((size_t)rows + 31) / 32, 0u);
-    long V = 0;
-    for (int r = 0; r < rows; ++r) {
-      const int len = rp[r + 1] - rp[r];
-      if (len <= long_thresh) continue;
-      const int np = (len + lp - 1) / lp;
-      P.rowinfo[(size_t)r] = int2{(int)V, np};
-      blk.push_back(int4{r, r + 1, (int)V, (int)V + np});
-      mask[(size_t)r >> 5] |= 1u << (r & 31);
-      V += np;
-      peel_nnz += len;
-      if (V > 500000000L) return false;
-    }
-    if (blk.empty()) return false;
-    P.V = (int)V;
-    const long total = (long)rows + V;
-    if (total > 2000000000L) return false;
-    cs_pick_geometry((int)total, P.R, P.rpt, 1);
-    for (;;) {  // every chunk: Rr real-row slots + Rp piece slots
-      P.nchunks = (int)((total + P.R - 1) / P.R);
-      P.Rp = (P.V + P.nchunks - 1) / P.nchunks;
-      P.Rr = P.R - P.Rp;
-      if (P.Rr >= 1 && (long)P.nchunks * P.Rr >= rows) break;
-      P.R += 64;
-      while (P.R > kCsThreads * P.rpt) P.rpt *= 2;
-      if (P.rpt > 16) return false;
-    }
-    npeel = (int)blk.size();
+    if (!cs_plan_virtual(rp, rows, lp, std::max(lp, peel_threshold(1)), P)) return false;
+    npeel = (int)P.blk.size();
     npeel_long = 0;  // (a row's pieces are few: one wavefront adds them)
-    peel_mask.upload(mask.data(), mask.size(), s);
-    peel_blk.upload(blk.data(), blk.size(), s);
+    peel_nnz = P.long_nnz;
+    peel_mask.upload(P.mask.data(), P.mask.size(), s);
+    peel_blk.upload(P.blk.data(), P.blk.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
     return true;
   }
@@ -260,26 +229,7 @@ struct DeviceCsr {
   bool build_virtual_host(const int *rp, const int *ci, const double *v, int lp, hipStream_t s, HostCs &h) {
     VirtPlan P;
     if (!plan_virtual(rp, lp, P, s)) return false;
-    const long slots = (long)P.nchunks * P.R;
-    std::vector<int> vrp((size_t)slots + 1, 0), vci((size_t)nnz), where((size_t)nnz);
-    std::vector<double> vv((size_t)nnz);
-    auto slot_of = [&](int r, int k) {
-      const int2 info = P.rowinfo[(size_t)r];
-      return info.x < 0 ? cs_slot_of_row(r, P.Rr, P.R) : cs_slot_of_piece(info.x + k % info.y, P.Rr, P.Rp, P.R);
-    };
-    for (int r = 0; r < rows; ++r)
-      for (int k = 0; k < rp[r + 1] - rp[r]; ++k) vrp[(size_t)slot_of(r, k) + 1]++;
-    for (long i = 0; i < slots; ++i) vrp[(size_t)i + 1] += vrp[(size_t)i];
-    std::vector<int> fill(vrp.begin(), vrp.end() - 1);
-    for (int r = 0; r < rows; ++r)  // rows in order, a row's nonzeros in ascending column order: every slot ends up ascending
-      for (int k = 0; k < rp[r + 1] - rp[r]; ++k) {
-        const int d = fill[(size_t)slot_of(r, k)]++;
-        vci[(size_t)d] = ci[rp[r] + k];
-        vv[(size_t)d] = v[rp[r] + k];
-      }
-    const bool built = build_cs(vrp.data(), vci.data(), vv.data(), (int)slots, cols, h, P.rpt, 1, nullptr, P.R);
-    if (!built) { clear_peel(); return false; }
-    h.rows = rows;
+    if (!build_cs_virtual(rp, ci, v, rows, cols, P, h)) { clear_peel(); return false; }
     virt_host_plan = P;
     return true;
   }
@@ -2764,7 +2714,16 @@ int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans
   }
 }
 
+static int cs_layout_host_spmv_impl(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split, int piece_len);
 int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split) {
+  return cs_layout_host_spmv_impl(A, x, y, transpose, rpt, split, 0);
+}
+// piece_len > 0: the virtual-row layout (spmv_cs.hpp CsView::Rr) — rows longer than max(piece_len, what a count field holds) cut into
+// pieces of at most piece_len nonzeros, walked the way the kernels walk it: pass kernel, then one wavefront per long row over its pieces
+int scs_hip_cs_layout_host_spmv_pieces(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int piece_len) {
+  return cs_layout_host_spmv_impl(A, x, y, transpose, 0, 1, piece_len);
+}
+static int cs_layout_host_spmv_impl(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split, int piece_len) {
   try {
     set_last_error("");
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid matrix");
@@ -2794,7 +2753,16 @@ int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_floa
             mk[r >> 5] |= 1u << (r & 31);
           }
     }
-    if (!build_cs(rp, ci, v, rows, cols, h, rpt, split, mk.empty() ? nullptr : mk.data())) return 1;
+    CsVirtPlan P;
+    const bool pieces = piece_len > 0;
+    if (pieces) {
+      int R0, rpt0;
+      cs_pick_geometry(rows, R0, rpt0, 1);
+      mk.clear();
+      if (!cs_plan_virtual(rp, rows, piece_len, std::max(piece_len, cs_peel_threshold(rpt0)), P)) return 1;
+      if (!build_cs_virtual(rp, ci, v, rows, cols, P, h)) return 1;
+    } else if (!build_cs(rp, ci, v, rows, cols, h, rpt, split, mk.empty() ? nullptr : mk.data())) return 1;
+    std::vector<double> tpart((size_t)P.V, 0.0);
     if (!mk.empty())
       for (int r = 0; r < rows; ++r)
         if (cs_is_peeled(mk.data(), r)) {
@@ -2833,10 +2801,30 @@ int scs_hip_cs_layout_host_spmv(const ScsMatrix *A, const scs_float *x, scs_floa
         if (part == 0) tot = acc;
         else for (size_t i = 0; i < tot.size(); ++i) tot[i] += acc[i];
       }
+      const int Rr = pieces ? P.Rr : h.R;
       for (int rl = 0; rl < h.R; ++rl) {
-        const long r = (long)c * h.R + rl;
-        if (r < rows) y[r] += tot[rl];
+        if (rl < Rr) {
+          const long r = (long)c * Rr + rl;
+          if (r < rows && !(pieces && cs_is_peeled(P.mask.data(), (int)r))) y[r] += tot[rl];
+        } else {
+          const long p = (long)c * P.Rp + (rl - Rr);
+          if (p < P.V) tpart[(size_t)p] = tot[rl];
+        }
       }
+    }
+    for (const int4 &b : P.blk) {  // k_spmv_peeled<Epi, PIECES>: lanes stride over the row's pieces, then the wave's shuffle tree
+      double lane[64];
+      for (int l = 0; l < 64; ++l) {
+        double a = 0.;
+        for (int k = b.z + l; k < b.w; k += 64) a += tpart[(size_t)k];
+        lane[l] = a;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        double nxt[64];
+        for (int l = 0; l < 64; ++l) nxt[l] = lane[l] + (l + o < 64 ? lane[l + o] : lane[l]);
+        std::memcpy(lane, nxt, sizeof(lane));
+      }
+      y[b.x] += lane[0];
     }
     return 0;
   } catch (const std::exception &e) {

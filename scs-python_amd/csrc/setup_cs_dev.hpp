@@ -90,8 +90,6 @@ __global__ __launch_bounds__(1024) void k_cs_scatter(const int *__restrict__ tpt
 // Virtual rows (spmv_cs.hpp CsView::Rr): the row SLOT of every nonzero of T.  rowinfo[r] = {first piece, pieces} of a split row,
 // {-1, 0} otherwise; the k-th nonzero (ascending column) of a split row goes to piece k mod np — k by binary search of the
 // nonzero's column (the row of T holding position p) in M's own CSR row.
-__host__ __device__ inline int cs_slot_of_row(int r, int Rr, int R) { return (r / Rr) * R + r % Rr; }
-__host__ __device__ inline int cs_slot_of_piece(int p, int Rr, int Rp, int R) { return (p / Rp) * R + Rr + p % Rp; }
 __global__ __launch_bounds__(256) void k_cs_vslot(const int *__restrict__ tptr, const int *__restrict__ trow, int trows, long nnz,
                                                   const int *__restrict__ mrowptr, const int *__restrict__ mcol,
                                                   const int2 *__restrict__ rowinfo, int Rr, int Rp, int R, int *__restrict__ vslot) {

@@ -214,6 +214,74 @@ inline bool build_cs(const int *rowptr, const int *col, const double *val, int r
 }
 
 
+// ---- virtual rows (CsView::Rr): planning and the host builder ----
+__host__ __device__ inline int cs_slot_of_row(int r, int Rr, int R) { return (r / Rr) * R + r % Rr; }
+__host__ __device__ inline int cs_slot_of_piece(int p, int Rr, int Rp, int R) { return (p / Rp) * R + Rr + p % Rp; }
+struct CsVirtPlan {
+  int R = 0, rpt = 0, nchunks = 0, Rr = 0, Rp = 0, V = 0;
+  long long_nnz = 0;
+  std::vector<int2> rowinfo;   // per row {first piece, pieces} or {-1, 0}
+  std::vector<int4> blk;       // per long row {row, row + 1, first piece, end}
+  std::vector<unsigned> mask;  // bit r: long row (no epilogue in the pass kernel)
+};
+// rows longer than long_thresh nonzeros -> ceil(len / lp) pieces; the geometry of the slot space.  false: nothing to cut / too big
+inline bool cs_plan_virtual(const int *rp, int rows, int lp, int long_thresh, CsVirtPlan &P) {
+  P = CsVirtPlan{};
+  P.rowinfo.assign((size_t)rows, int2{-1, 0});
+  P.mask.assign(((size_t)rows + 31) / 32, 0u);
+  long V = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int len = rp[r + 1] - rp[r];
+    if (len <= long_thresh) continue;
+    const int np = (len + lp - 1) / lp;
+    P.rowinfo[(size_t)r] = int2{(int)V, np};
+    P.blk.push_back(int4{r, r + 1, (int)V, (int)V + np});
+    P.mask[(size_t)r >> 5] |= 1u << (r & 31);
+    V += np;
+    P.long_nnz += len;
+    if (V > 500000000L) return false;
+  }
+  if (P.blk.empty()) return false;
+  P.V = (int)V;
+  const long total = (long)rows + V;
+  if (total > 2000000000L) return false;
+  cs_pick_geometry((int)total, P.R, P.rpt, 1);
+  for (;;) {  // every chunk: Rr real-row slots + Rp piece slots
+    P.nchunks = (int)((total + P.R - 1) / P.R);
+    P.Rp = (P.V + P.nchunks - 1) / P.nchunks;
+    P.Rr = P.R - P.Rp;
+    if (P.Rr >= 1 && (long)P.nchunks * P.Rr >= rows) break;
+    P.R += 64;
+    while (P.R > kCsThreads * P.rpt) P.rpt *= 2;
+    if (P.rpt > 16) return false;
+  }
+  return true;
+}
+// the layout of the slot space: a CSR over nchunks * R slots (a row's nonzeros in ascending column order keep that order inside
+// every piece), then build_cs with the plan's geometry.  out.rows = the REAL row count.
+inline bool build_cs_virtual(const int *rp, const int *ci, const double *v, int rows, int cols, const CsVirtPlan &P, HostCs &out) {
+  const long slots = (long)P.nchunks * P.R, nnz = rp[rows];
+  std::vector<int> vrp((size_t)slots + 1, 0), vci((size_t)nnz);
+  std::vector<double> vv((size_t)nnz);
+  auto slot_of = [&](int r, int k) {
+    const int2 info = P.rowinfo[(size_t)r];
+    return info.x < 0 ? cs_slot_of_row(r, P.Rr, P.R) : cs_slot_of_piece(info.x + k % info.y, P.Rr, P.Rp, P.R);
+  };
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < rp[r + 1] - rp[r]; ++k) vrp[(size_t)slot_of(r, k) + 1]++;
+  for (long i = 0; i < slots; ++i) vrp[(size_t)i + 1] += vrp[(size_t)i];
+  std::vector<int> fill(vrp.begin(), vrp.end() - 1);
+  for (int r = 0; r < rows; ++r)
+    for (int k = 0; k < rp[r + 1] - rp[r]; ++k) {
+      const int d = fill[(size_t)slot_of(r, k)]++;
+      vci[(size_t)d] = ci[rp[r] + k];
+      vv[(size_t)d] = v[rp[r] + k];
+    }
+  if (!build_cs(vrp.data(), vci.data(), vv.data(), (int)slots, cols, out, P.rpt, 1, nullptr, P.R)) return false;
+  out.rows = rows;
+  return true;
+}
+
 // split == 1: the finished row goes through the epilogue functor.  split == 2: `s` is the partial sum of the
 // workgroup's half of the row — only epilogues that are linear in it (a `split` member: EpiGp, EpiPartial) may be
 // launched on such a layout (launch_spmv routes the others through EpiPartial + k_epi_finish).

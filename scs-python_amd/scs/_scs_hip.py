@@ -718,6 +718,20 @@ def cs_layout_host_spmv(A, x, transpose=False, rpt=0, split=1):
     return y
 
 
+def cs_layout_host_spmv_pieces(A, x, transpose=False, piece_len=24):
+    """HOST-ONLY: the same walk for the virtual-row variant of the layout — rows too long for the count fields cut into pieces of
+    at most piece_len nonzeros that ride in the passes, a row's pieces added as the device adds them; None when no row is that
+    long or the pattern does not fit.  (tests, no GPU needed)"""
+    M, keep = _matrix(A)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(A.shape[1] if transpose else A.shape[0])
+    rc = _lib.scs_hip_cs_layout_host_spmv_pieces(C.byref(M), _pd(xx), _pd(y), 1 if transpose else 0, int(piece_len))
+    if rc == 1:
+        return None
+    _check(rc)
+    return y
+
+
 def spmv_bench(A, transpose=False, reps=20):
     M, keep = _matrix(A)
     ms = _lib.scs_hip_spmv_bench(C.byref(M), 1 if transpose else 0, int(reps))

@@ -132,3 +132,47 @@ def test_layout_rejects_very_wide_sparse_chunks(hip):
     # very wide and very sparse: every pass is cut at 2^19 columns => mostly padding => rejected
     W = pg.random_sparse(20000, 3000000, 1, rng)
     assert hip.cs_layout_host_spmv(W, np.ones(W.shape[1]), rpt=0) is None
+
+
+def test_long_rows_as_pieces_in_the_passes(hip, oracle):
+    """Round 3: a row too long for the count fields keeps an empty slot and its k-th nonzero goes to piece k mod np; the pieces are
+    extra row slots of every chunk, their sums are added per row by one wavefront (64 lanes striding, shuffle tree).  Walked on the
+    host exactly as the kernels do it: rows that stay whole keep the oracle's bits, cut rows agree to the rounding of the tree;
+    every piece length that builds gives the same answer to that accuracy; nothing to cut -> None."""
+    rng = np.random.default_rng(11)
+    m, n = 60000, 50000
+    lens = np.minimum((rng.pareto(1.2, m) * 3 + 1).astype(np.int64), 9000)
+    rows = np.repeat(np.arange(m), lens)
+    cols = rng.integers(0, n, size=rows.size)
+    A = sparse.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    rl = np.diff(A.tocsr().indptr)
+    assert rl.max() > 4000
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    ref = oracle.spmv(A, x)
+    whole = rl <= 4095  # 60000 rows -> 256 rows per chunk, one row per lane: 13-bit counts, rows up to 2048 ... 4095 may stay whole
+    for piece_len in (6, 24, 100):
+        got = hip.cs_layout_host_spmv_pieces(A, x, piece_len=piece_len)
+        assert got is not None
+        short = rl <= 2048
+        np.testing.assert_array_equal(got[short], ref[short])
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+        assert (got[~whole] != 0).all()
+    # the transposed product has no long rows (columns are uniform): nothing to cut
+    assert np.diff(A.indptr).max() < 64
+    assert hip.cs_layout_host_spmv_pieces(A, y, transpose=True, piece_len=24) is None
+    # a dense row and a dense column at 8 rows per lane (6-bit counts): both orientations are cut
+    nb = 2400000
+    rb = np.concatenate([rng.integers(0, 300000, nb), np.full(40000, 17), np.arange(300000)])
+    cb = np.concatenate([rng.integers(0, 40000, nb), np.arange(40000), np.full(300000, 3)])
+    B = sparse.csc_matrix((rng.standard_normal(rb.size), (rb, cb)), shape=(300000, 40000))
+    B.sum_duplicates()
+    B.sort_indices()
+    xb, yb = rng.standard_normal(40000), rng.standard_normal(300000)
+    for tr, v in ((False, xb), (True, yb)):
+        got, refb = hip.cs_layout_host_spmv_pieces(B, v, transpose=tr, piece_len=24), oracle.spmv(B, v, trans=tr)
+        assert got is not None
+        np.testing.assert_allclose(got, refb, rtol=0, atol=1e-13 * np.abs(refb).max())
+        lens_b = np.diff(B.indptr) if tr else np.diff(B.tocsr().indptr)
+        np.testing.assert_array_equal(got[lens_b <= 63], refb[lens_b <= 63])

@@ -838,6 +838,11 @@ def test_spmv_skewed_patterns_keep_the_layout(hip, oracle, monkeypatch, pattern,
             np.testing.assert_allclose(got[mode][k][~short], ref[k][~short], rtol=1e-12, atol=1e-12 * np.abs(ref[k]).max())
     for k in (0, 1):
         np.testing.assert_array_equal(got["device"][k], got["host"][k])
+    # the device product IS the host walk of the virtual-row layout (one of the piece lengths the builder tries), bit for bit
+    if pattern != "banded":
+        npass_est = max(1, A.nnz // 256 // 8192)
+        walks = [hip.cs_layout_host_spmv_pieces(A, x, piece_len=pp * npass_est) for pp in (24, 12, 6)]
+        assert any(w is not None and np.array_equal(w, got["device"][0]) for w in walks)
     # round 3: the long rows ride in the passes as pieces (default); SCS_HIP_CS_VIRT=0 = the side launch of round 2 sums them
     # whole from the plain CSR.  Rows the passes keep whole have the same bits either way; long rows agree to the tree's rounding.
     monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")

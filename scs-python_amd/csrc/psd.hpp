@@ -1343,6 +1343,24 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
 constexpr int kPsdSmallMax = 32;
 constexpr int kPsdSLd = 33;
 
+// dot product of the one-wavefront kernel's small GEMMs: the terms are added in index order (same bits as the plain loop), but four
+// pairs of LDS reads are in flight at a time — a lone wavefront has nothing else to cover the LDS latency with (round 3: the four
+// GEMM loops took 20 of the kernel's 48 us at order 20)
+template <class FA, class FB>
+__device__ __forceinline__ double psd_small_dot(int N, FA a_at, FB b_at) {
+  double acc = 0.;
+  int kk = 0;
+  for (; kk + 4 <= N; kk += 4) {
+    const double a0 = a_at(kk), a1 = a_at(kk + 1), a2 = a_at(kk + 2), a3 = a_at(kk + 3);
+    const double b0 = b_at(kk), b1 = b_at(kk + 1), b2 = b_at(kk + 2), b3 = b_at(kk + 3);
+    acc += a0 * b0;
+    acc += a1 * b1;
+    acc += a2 * b2;
+    acc += a3 * b3;
+  }
+  for (; kk < N; ++kk) acc += a_at(kk) * b_at(kk);
+  return acc;
+}
 __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *scratch, int allow_warm,
                                                  const int *stall, const double *tol2) {
   SCS_STALL_GUARD(stall);
@@ -1414,16 +1432,13 @@ __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *
   if (warm) {  // S <- V' S V
     for (int e = lane; e < N * N; e += 64) {
       const int j = e / N, i = e - j * N;
-      double acc = 0.;
-      for (int k = 0; k < N; ++k) acc += S[i + ld * k] * V[k + ld * j];
-      T[i + ld * j] = acc;
+      T[i + ld * j] = psd_small_dot(N, [&](int k) { return S[i + ld * k]; }, [&](int k) { return V[k + ld * j]; });
     }
     wave_sync();
     for (int e = lane; e < N * N; e += 64) {
       const int j = e / N, i = e - j * N;
       if (i < j) continue;
-      double acc = 0.;
-      for (int k = 0; k < N; ++k) acc += V[k + ld * i] * T[k + ld * j];
+      const double acc = psd_small_dot(N, [&](int k) { return V[k + ld * i]; }, [&](int k) { return T[k + ld * j]; });
       S[i + ld * j] = acc;
       S[j + ld * i] = acc;
     }
@@ -1551,16 +1566,13 @@ __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *
   wave_sync();
   for (int e = lane; e < N * N; e += 64) {  // S <- V F
     const int j = e / N, i = e - j * N;
-    double acc = 0.;
-    for (int kk = 0; kk < N; ++kk) acc += V[i + ld * kk] * T[kk + ld * j];
-    S[i + ld * j] = acc;
+    S[i + ld * j] = psd_small_dot(N, [&](int kk) { return V[i + ld * kk]; }, [&](int kk) { return T[kk + ld * j]; });
   }
   wave_sync();
   for (int e = lane; e < n * n; e += 64) {  // X+ = (V F) V', lower triangle
     const int j = e / n, i = e - j * n;
     if (i < j) continue;
-    double acc = 0.;
-    for (int kk = 0; kk < N; ++kk) acc += S[i + ld * kk] * V[j + ld * kk];
+    const double acc = psd_small_dot(N, [&](int kk) { return S[i + ld * kk]; }, [&](int kk) { return V[j + ld * kk]; });
     const long base = (long)j * n - (long)j * (j - 1) / 2;
     X[base + (i - j)] = (i == j) ? acc : acc * sq2;
   }

@@ -56,12 +56,12 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < x.size(); ++i) x[i] = x0[i] * (1.0 + pert * call) + pert * call * nd(g);
     HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipEventRecord(e0));
-    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, nullptr);
+    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, (const int *)nullptr, (const double *)nullptr);
     else if (split) {
       const int ntile = (int)np / 16;
       const dim3 gg(psd_gemm_wgs(ntile), (unsigned)cnt), gb(kPsdGemmThreads);
       hipLaunchKernelGGL(k_psd_front, dim3(ntile, cnt), dim3(kPsdFrontThreads), 0, 0, (const double *)d_x, B, d_scr, 1, (const int *)nullptr);
-      hipLaunchKernelGGL(k_proj_psd<3>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
+      hipLaunchKernelGGL(k_proj_psd<3>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       for (int round = 0; round < 3; ++round) {
@@ -69,20 +69,21 @@ int main(int argc, char **argv) {
           int G = mc, rnd = round;
           const int *st = nullptr;
           int la = getenv("PSD_LAB_LA0") ? 0 : 1;  // look-ahead (one barrier per step)
-          void *args[] = {&B, &d_scr, &rnd, &G, &la, &d_err, &st};
+          const double *tl = nullptr;
+          void *args[] = {&B, &d_scr, &rnd, &G, &la, &d_err, &st, &tl};
           if (getenv("PSD_LAB_PLAIN"))  // ordinary launch (e.g. under rocprofv3)
-            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdMcLdsBytes, 0, B, d_scr, rnd, G, la, d_err, st);
+            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdMcLdsBytes, 0, B, d_scr, rnd, G, la, d_err, st, tl);
           else
           HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads),
                                                args, (unsigned)kPsdMcLdsBytes, 0));
         } else
-        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, nullptr);
+        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, (const int *)nullptr, (const double *)nullptr);
         hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
       hipLaunchKernelGGL(k_psd_fmap, dim3(ntile, cnt), dim3(256), 0, 0, B, d_scr, (const int *)nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
       hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
-    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, nullptr);
+    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr);
     HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     double st[8];

@@ -667,6 +667,7 @@ struct ScsHipWork {
   // large solutions leave through a pinned mirror owned by the workspace (the caller's arrays are never handed to the runtime,
   // see scs_hip_runtime_env): three DMA copies in flight, each array moved on by a few host threads as soon as it has landed
   double *sol_pin = nullptr;
+  bool sol_pin_refused = false;
   hipEvent_t sol_ev[3] = {nullptr, nullptr, nullptr};
   static constexpr size_t kSolMirrorMin = (size_t)1 << 20;  // bytes of x | y | s from which the mirror is used
   static void spread_memcpy(void *dst, const void *src, size_t bytes) {
@@ -683,20 +684,24 @@ struct ScsHipWork {
   }
   void ensure_solution_mirror() {  // (scs_init calls this: pinning 40 MB costs milliseconds)
     const size_t bytes = sizeof(double) * ((size_t)n + 2 * (size_t)m);
-    if (sol_pin || bytes < kSolMirrorMin) return;
-    HIP_CHECK(hipHostMalloc((void **)&sol_pin, bytes, hipHostMallocDefault));
+    if (sol_pin || sol_pin_refused || bytes < kSolMirrorMin) return;
+    if (hipHostMalloc((void **)&sol_pin, bytes, hipHostMallocDefault) != hipSuccess) {  // (no pinned memory left: the runtime's own staging)
+      (void)hipGetLastError();
+      sol_pin = nullptr;
+      sol_pin_refused = true;
+      return;
+    }
     for (auto &e : sol_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   void download_solution(ScsSolution *sol) {
-    const size_t bytes = sizeof(double) * ((size_t)n + 2 * (size_t)m);
-    if (bytes < kSolMirrorMin) {
+    ensure_solution_mirror();
+    if (!sol_pin) {
       solx.download(sol->x, n, stream);
       soly.download(sol->y, m, stream);
       sols.download(sol->s, m, stream);
       HIP_CHECK(hipStreamSynchronize(stream));
       return;
     }
-    ensure_solution_mirror();
     double *hx = sol_pin, *hy = sol_pin + n, *hs = sol_pin + n + m;
     solx.download(hx, n, stream); HIP_CHECK(hipEventRecord(sol_ev[0], stream));
     soly.download(hy, m, stream); HIP_CHECK(hipEventRecord(sol_ev[1], stream));

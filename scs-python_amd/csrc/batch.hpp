@@ -565,11 +565,6 @@ struct GroupSolve {
     for (int g : su) W[(size_t)g]->v_norm_fresh = false;
   }
 
-  static int handoff_max() {  // SCS_HIP_GROUP_HANDOFF: members left at which the rest is solved by scs_solve's loop (0: never)
-    static const int v = [] { const char *e = getenv("SCS_HIP_GROUP_HANDOFF"); return e ? atoi(e) : 2; }();
-    return v;
-  }
-  int handed_off = 0;
   // ---- the lock-step loop ----
   void run(int warm_start) {
     t_start = now_ms();
@@ -770,26 +765,11 @@ struct GroupSolve {
         lists_since_sync = 0;  // finish_solve synchronised
         upload_active();
       }
-      // The last stragglers leave the lock step: a lone small problem advances at 0.11 ms per iteration through scs_solve's own
-      // loop against 0.17 ms here (tools/dbg/small_iter_latency.py), and the batch's wall clock is its longest member's
-      // (profiles/r03_batch_shard_sim.txt).  Everything a member's state consists of lives in its own workspace — the grouped
-      // kernels worked on it through the argument records — except its flag block, which goes back now.
-      if (!active.empty() && (int)active.size() <= handoff_max()) {
-        HIP_CHECK(hipStreamSynchronize(s));
-        for (int g : active) {
-          ScsHipWork *w = W[(size_t)g];
-          HIP_CHECK(hipMemcpyAsync(w->fl.p, fl_of(g), sizeof(int) * F_COUNT, hipMemcpyDeviceToDevice, s));
-          solve_loop(w, sols[(size_t)g], infos[(size_t)g], i + 1, t_start, t_lin, t_cone, t_acc, nullptr);
-          ++handed_off;
-        }
-        active.clear();
-        break;
-      }
     }
     HIP_CHECK(hipStreamSynchronize(s));
     if (getenv("SCS_HIP_GROUP_STATS"))
-      std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %d members finished by scs_solve's loop, %.1f ms\n",
-                   G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, handed_off, now_ms() - t_start);
+      std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %.1f ms\n",
+                   G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, now_ms() - t_start);
   }
 };
 

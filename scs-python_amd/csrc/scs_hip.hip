@@ -2151,15 +2151,16 @@ struct InterruptListener {
   static bool interrupted() { return enabled() && flag().load(std::memory_order_relaxed) != 0; }
 };
 
-static scs_int solve_loop(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, int i0, double t_start, double t_lin, double t_cone, double t_acc,
-                          FILE *csv);
 static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) {
   std::lock_guard<std::mutex> lock(w->mtx);
   InterruptListener ctrlc;
   HIP_CHECK(hipSetDevice(w->device));
   const double t_start = now_ms();
   const int n = w->n, m = w->m;
+  const long l = w->l;
+  hipStream_t s = w->stream;
   w->begin_solve(sol, info, warm_start);
+  double t_lin = 0, t_cone = 0, t_acc = 0;
   FILE *csv = nullptr;
   if (!w->log_csv_filename.empty()) {
     csv = std::fopen(w->log_csv_filename.c_str(), "w");
@@ -2184,19 +2185,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     std::printf(" iter | pri res | dua res |   gap   |   obj   |  scale  | time (s)\n");
     std::printf("------------------------------------------------------------------\n");
   }
-  return solve_loop(w, sol, info, 0, t_start, 0., 0., 0., csv);
-}
 
-// The ADMM loop from iteration i0 on, then the finalisation.  i0 = 0: right after begin_solve.  i0 > 0: the workspace is in the state
-// i0 finished iterations left it in — the grouped solve (batch.hpp) hands its last one or two unfinished members over here, because
-// a lone small problem advances faster through this loop (whole iterations queued ahead, kernel arguments in registers: 0.11 ms per
-// iteration) than through the grouped kernels (argument records in HBM, one host round trip per iteration: 0.17 ms).
-static scs_int solve_loop(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, int i0, double t_start, double t_lin, double t_cone, double t_acc,
-                          FILE *csv) {
-  const int n = w->n, m = w->m;
-  const long l = w->l;
-  hipStream_t s = w->stream;
-  const bool verbose = w->stgs.verbose != 0;
   int i;
   const int max_iters = w->stgs.max_iters;
   // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
@@ -2215,8 +2204,8 @@ static scs_int solve_loop(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, int i0
     return true;
   };
   int enq_upto = -1;  // run-ahead: last iteration already in the queue
-  if (i0 == 0) w->mark_ms = -1;
-  for (i = i0; i < max_iters; ++i) {
+  w->mark_ms = -1;
+  for (i = 0; i < max_iters; ++i) {
     if (InterruptListener::interrupted()) {
       info->status_val = SCS_SIGINT;
       break;

@@ -9,13 +9,14 @@ proj = lambda z, K: _scs_hip.proj_cone(z, K, dual=True)
 K, n, k, seed = pg.workload("config5_small")
 datas = [pg.gen_feasible(K, n, k, seed + i, proj)[0] for i in range(2)]
 mode = sys.argv[1]
-kw = dict(linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=3000, verbose=False)
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+kw = dict(linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=ITERS, verbose=False)
 if mode == "group2":
     ss = [scs.SCS(d, K, **kw) for d in datas]
     scs.solve_batch(ss)
     t = time.perf_counter(); r = scs.solve_batch(ss); el = time.perf_counter() - t
-    print(mode, "%.1f us per lock-step iteration" % (el / 3000 * 1e6), r[0]["info"]["lin_sys_solver"])
+    print(mode, "%.1f us per lock-step iteration" % (el / ITERS * 1e6), r[0]["info"]["lin_sys_solver"])
 else:
     s = scs.SCS(datas[0], K, **kw); s.solve()
     t = time.perf_counter(); r = s.solve(); el = time.perf_counter() - t
-    print(mode, "%.1f us per iteration" % (el / 3000 * 1e6), r["info"]["lin_sys_solver"], "cg/iter %.2f" % (r["info"]["cg_iters"] / 3000))
+    print(mode, "%.1f us per iteration" % (el / ITERS * 1e6), r["info"]["lin_sys_solver"], "cg/iter %.2f" % (r["info"]["cg_iters"] / ITERS))

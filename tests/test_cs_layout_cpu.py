@@ -176,3 +176,27 @@ def test_long_rows_as_pieces_in_the_passes(hip, oracle):
         np.testing.assert_allclose(got, refb, rtol=0, atol=1e-13 * np.abs(refb).max())
         lens_b = np.diff(B.indptr) if tr else np.diff(B.tocsr().indptr)
         np.testing.assert_array_equal(got[lens_b <= 63], refb[lens_b <= 63])
+
+
+@pytest.mark.parametrize("shape,row_len,piece_len", [((300, 6000), 5000, 24), ((1, 40000), 40000, 6), ((5000, 3000), 2500, 100),
+                                                     ((70000, 20000), 3000, 7)])
+def test_pieces_when_every_row_is_long(hip, oracle, shape, row_len, piece_len):
+    """edge geometries of the virtual-row layout: EVERY row is cut (the real-row slots stay empty), a single row, more pieces than
+    rows (the chunk geometry grows: more rows per lane), a tall matrix whose first 40 rows are long — against the oracle"""
+    rng = np.random.default_rng(shape[0] + row_len)
+    m, n = shape
+    nlong = m if m <= 5000 else 40
+    rows = np.repeat(np.arange(nlong), row_len)
+    cols = np.concatenate([rng.choice(n, row_len, replace=False) for _ in range(nlong)])
+    if nlong < m:  # the other rows: 5 nonzeros each
+        rows = np.concatenate([rows, np.repeat(np.arange(nlong, m), 5)])
+        cols = np.concatenate([cols, rng.integers(0, n, 5 * (m - nlong))])
+    A = sparse.csc_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=shape)
+    A.sum_duplicates()
+    A.sort_indices()
+    x = rng.standard_normal(n)
+    got, ref = hip.cs_layout_host_spmv_pieces(A, x, piece_len=piece_len), oracle.spmv(A, x)
+    assert got is not None
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    rl = np.diff(A.tocsr().indptr)
+    np.testing.assert_array_equal(got[rl <= 63], ref[rl <= 63])

@@ -2054,7 +2054,10 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->solx.alloc_zero(n, s);
   w->soly.alloc_zero(m, s);
   w->sols.alloc_zero(m, s);
-  w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->At.nwg(), w->Ar.nwg(), w->has_P ? std::max(w->Pf.nblk, w->Pf.nwg()) : 0, kMaxVecBlocks}) * 8;
+  // (x 8 until round 3: the residual epilogues leave 9 and 10 values per workgroup — with more than 1638 workgroups, i.e. the CSR-stream
+  // layout of a matrix beyond ~3.4 M nonzeros, their partials ran past the buffer: a memory fault at 9419 row blocks)
+  w->part_len = std::max({w->At.nblk, w->Ar.nblk, w->At.nwg(), w->Ar.nwg(), w->has_P ? std::max(w->Pf.nblk, w->Pf.nwg()) : 0, kMaxVecBlocks}) *
+                kMaxEpiReductions;
   w->part.alloc_zero(w->part_len, s);
   w->part2.alloc_zero(2 * kMaxVecBlocks, s);
   w->part_v.alloc_zero(kMaxVecBlocks, s);
@@ -2935,7 +2938,7 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
     w.diag_r.upload(dr.data(), w.l, s);
     for (DevBuf<double> *b : {&w.cg_b, &w.cg_p, &w.cg_r, &w.cg_Gp, &w.cg_M, &w.ws}) b->alloc_zero(n, s);
     w.tmp_m.alloc_zero(m, s);
-    w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, w.At.nwg(), w.Ar.nwg(), kMaxVecBlocks}) * 8, s);
+    w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, w.At.nwg(), w.Ar.nwg(), kMaxVecBlocks}) * kMaxEpiReductions, s);
     w.part2.alloc_zero(2 * kMaxVecBlocks, s);
     w.sc.alloc_zero(S_COUNT, s);
     w.fl.alloc_zero(F_COUNT, s);

@@ -716,9 +716,12 @@ __global__ __launch_bounds__(kEpiFinishThreads) void k_epi_finish(const double *
   }
 }
 
+// reduction partials an epilogue leaves per workgroup (kSums + kMaxs): the callers' partial buffers hold this many per workgroup
+constexpr int kMaxEpiReductions = 10;  // EpiResDual: 4 sums + 6 maxima
 template <class Epi>
 inline void launch_spmv(const SpmvMat &M, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
                         int *step_counter = nullptr) {
+  static_assert(Epi::kSums + Epi::kMaxs <= kMaxEpiReductions, "partial buffers are sized for kMaxEpiReductions values per workgroup");
   if (M.use_cs) {
     if (M.cs.nchunks <= 0) return;
     CsView V = M.cs;

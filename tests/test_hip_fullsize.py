@@ -226,3 +226,31 @@ def test_config4_shaped_qp_matches_constructed_solution_entrywise(hip):
     assert abs(info["pobj"] - p_star) <= 1e-6 * max(1.0, abs(p_star))
     for key, ref in (("x", x0), ("y", y0), ("s", s0)):
         np.testing.assert_allclose(sol[key], ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(), err_msg=key)
+
+
+def test_power_law_rows_at_the_metric_size_iterate_as_the_csr_stream_layout(hip, monkeypatch):
+    """the metric workload's size with Pareto(1.3) row lengths (up to 20 000 nonzeros per row): the rows too long for the pass layout's
+    6-bit count fields ride in the passes as pieces (8 rows per lane, ~80 000 piece slots) and every fused CG epilogue / residual product
+    runs on them through the piece-sum launch.  The instance converges slowly (a solve to 1e-4 needs far more than 1500 iterations:
+    tools/dbg/powerlaw_solve.py), so this checks 12 plain ADMM iterations (no acceleration: nothing chaotic) against the same
+    iterations on the plain CSR-stream layout (9419 row blocks: the size at which the residual epilogues' partials overran their buffer
+    until round 3) — same iterates to the accuracy of the inexact linear solves, same residuals, CG step counts within 3 %."""
+    import scs
+    K, n, k, seed = pg.workload("powerlaw_lp")
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: hip.proj_cone(z, K, dual=True), pattern=pg.workload_pattern("powerlaw_lp"))
+    assert np.diff(data["A"].tocsr().indptr).max() > 5000
+    stg = dict(linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=12, acceleration_lookback=0,
+               verbose=False)
+    got = scs.SCS(data, K, **stg).solve()
+    assert "long rows in pieces" in got["info"]["lin_sys_solver"], got["info"]["lin_sys_solver"]
+    monkeypatch.setenv("SCS_HIP_SLAB", "0")
+    ref = scs.SCS(data, K, **stg).solve()
+    assert "CSR-stream" in ref["info"]["lin_sys_solver"]
+    assert got["info"]["iter"] == ref["info"]["iter"] == 12
+    # (12 iterations: this far from the solution the iteration amplifies rounding — where an inexact CG solve stops flips with the order of
+    # the row sums — and after 150 iterations ALL four layouts have drifted apart by per cents: tools/dbg/powerlaw_layouts.py)
+    assert abs(got["info"]["cg_iters"] - ref["info"]["cg_iters"]) <= 2
+    for key in ("x", "y", "s"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=0, atol=1e-6 * np.abs(ref[key]).max(), err_msg=key)
+    for key in ("res_pri", "res_dual", "pobj"):
+        assert abs(got["info"][key] - ref["info"][key]) <= 1e-5 * abs(ref["info"][key]) + 1e-9, (key, got["info"][key], ref["info"][key])

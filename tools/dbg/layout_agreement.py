@@ -7,7 +7,10 @@ import scs, problem_gen as pg, helpers
 from scs import _scs_hip as hip
 name = sys.argv[1]
 proj = lambda z, K: hip.proj_cone(z, K, dual=True)
-if name == "qp":
+if name == "lp2x":  # twice the metric workload
+    K = {"l": 4000000}
+    data, p_star, _ = pg.gen_feasible(K, 2000000, 20, 41, proj)
+elif name == "qp":
     K = {"l": 600000, "q": [10] * 20000}
     data, p_star, _ = pg.gen_feasible_qp(K, 400000, 8, 17, proj)
 else:

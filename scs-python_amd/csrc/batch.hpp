@@ -148,6 +148,21 @@ struct GroupSolve {
   SCS_GTABLE(kVecThreads, d_fin_multi) t_fin_multi_p, t_fin_multi_d;
   SCS_GTABLE(kVecThreads, d_gather_res) t_gather_res;
   SCS_GTABLE(kVecThreads, d_copy_i32) t_gather_fl;
+  // dense direct linsys (dense.hpp): rhs = R_x v_x - A' v_y; u~_x = G^{-1} rhs; u~_y = v_y + R_y^{-1} A u~_x — and the cold KKT solve of a scale update
+  SCS_GTABLE(kSpmvThreads, d_spmv_stream<EpiDenseRhs>) t_dense_rhs;
+  SCS_GTABLE(kDenseThreads, d_dense_gemv) t_dense_gemv, t_dense_gemv_kkt;   // SCS_HIP_DENSE_GEMV=full
+  SCS_GTABLE(kDenseThreads, d_dense_symv_tiles) t_symv_tiles;
+  SCS_GTABLE(kDenseThreads, d_dense_symv_sum) t_symv_sum, t_symv_sum_kkt;
+  void go_dense_gemv(const int *list, int count, bool kkt) {  // x = G^{-1} cg_b into ut (iteration) or ws (cold KKT solve)
+    if (ScsHipWork::dense_full_gemv()) { go(kkt ? t_dense_gemv_kkt : t_dense_gemv, list, count); return; }
+    go(t_symv_tiles, list, count);
+    go(kkt ? t_symv_sum_kkt : t_symv_sum, list, count);
+  }
+  SCS_GTABLE(kSpmvThreads, d_spmv_stream<EpiY>) t_dense_y;
+  bool dense = false;
+  int dn_NP = 0;
+  DevBuf<DenseMat> dmat_d;
+  DevBuf<DenseSrc> dsrc_d;
   // adaptive-scale update of a sub-list
   SCS_GTABLE(kVecThreads, d_set_diag_r) t_set_diag_r;
   SCS_GTABLE(kVecThreads, d_precond) t_precond;
@@ -181,6 +196,8 @@ struct GroupSolve {
   // group-owned device / pinned memory
   DevBuf<double> params_d, res_d, aa_res_d;
   DevBuf<int> flags_d, lists_d, active_buf;
+  static constexpr int kParamRing = 32;  // pinned staging slots of the per-iteration parameter blocks (dense mode runs without a sync per iteration)
+  int iters_since_sync = 0;
   double *params_h = nullptr, *res_h = nullptr, *aa_res_h = nullptr;
   int *flags_h = nullptr, *lists_h = nullptr, *active_h = nullptr;  // (all pinned: every copy here is asynchronous)
   static constexpr int kListSlots = 64;
@@ -218,6 +235,7 @@ struct GroupSolve {
   static bool same_shape(const ScsHipWork *a, const ScsHipWork *b) {
     const HostCone &x = a->cone, &y = b->cone;
     return a->device == b->device && a->n == b->n && a->m == b->m && a->has_P == b->has_P && a->normalized == b->normalized &&
+           a->linsys == b->linsys &&
            x.z == y.z && x.l == y.l && x.bsize == y.bsize && x.ep == y.ep && x.ed == y.ed && x.q == y.q && x.s == y.s &&
            x.p.size() == y.p.size() && a->aa.mem == b->aa.mem && a->aa.type1 == b->aa.type1 &&
            a->stgs.acceleration_interval == b->stgs.acceleration_interval;
@@ -250,6 +268,7 @@ struct GroupSolve {
     HIP_CHECK(hipGetLastError());  // (launches are not checked one by one)
     HIP_CHECK(hipStreamSynchronize(s));
     lists_since_sync = 0;
+    iters_since_sync = 0;
     ++syncs;
   }
   template <class T> void go(const T &t, const int *list, int count) {
@@ -270,6 +289,7 @@ struct GroupSolve {
     int *fl = fl_of(g);
     t_spmv_y.set(g, Ar, w->ws.p, EpiY{w->ut.p + n, w->rdy(), w->v.p + n}, nullptr, nullptr);
     t_spmv_a.set(g, Ar, w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, fl + F_DONE, fl + F_STEP);
+    if (dense) t_dense_y.set(g, Ar, w->ut.p, EpiY{w->ut.p + n, w->rdy(), w->v.p + n}, nullptr, nullptr);
     t_set_diag_r.set(g, w->diag_r.p, n, m, w->cone.z, w->stgs.rho_x, w->scale);
   }
   void set_aa_update_record(int g, int idx) {
@@ -283,7 +303,9 @@ struct GroupSolve {
     ScsHipWork *w0 = W[0];
     n = w0->n; m = w0->m; l = w0->l; has_P = w0->has_P;
     mem = w0->aa.mem; interval = w0->stgs.acceleration_interval;
-    HIP_CHECK(hipHostMalloc((void **)&params_h, sizeof(double) * P_COUNT * G));
+    dense = w0->dense();
+    dn_NP = w0->dn_NP;
+    HIP_CHECK(hipHostMalloc((void **)&params_h, sizeof(double) * P_COUNT * G * kParamRing));
     HIP_CHECK(hipHostMalloc((void **)&res_h, sizeof(double) * kResRec * G));
     HIP_CHECK(hipHostMalloc((void **)&aa_res_h, sizeof(double) * AA_R_COUNT * G));
     HIP_CHECK(hipHostMalloc((void **)&flags_h, sizeof(int) * F_COUNT * G));
@@ -308,6 +330,7 @@ struct GroupSolve {
              t_gather_res, t_gather_fl, t_set_diag_r, t_precond, t_g_rhs, t_kkt_prep, t_spmv_rhs, t_zero_part, t_fin_tol,
              t_cg_init, t_fin_cg_init, t_zero_iters, t_kkt_y, t_copy_g, t_gg, t_fin_gg, t_v_rescale, t_spmv_ax);
     if (has_P) size_all(t_spmv_pws, t_spmv_p, t_res_px);
+    if (dense) size_all(t_dense_rhs, t_dense_gemv, t_dense_gemv_kkt, t_dense_y, t_symv_tiles, t_symv_sum, t_symv_sum_kkt);
     if (c0.bsize > 0) t_box.resize((size_t)G);
     if (w0->n_soc > 0) t_soc.resize((size_t)G);
     if (w0->n_psd > 0) t_psd.resize((size_t)G);
@@ -346,6 +369,14 @@ struct GroupSolve {
       t_prep.set(g, w->v.p, w->v_prev.p, w->ut.p, w->ws.p, w->u.p, w->g.p, w->diag_r.p, n, m, par, w->part_v.p, nbl, w->sc.p,
                  w->part2.p, nostall);
       set_scale_records(g);
+      if (dense) {
+        t_dense_rhs.set(g, At, w->v.p + n, EpiDenseRhs{w->cg_b.p, w->rdx(), w->v.p}, nullptr, nullptr);
+        t_dense_gemv.set(g, w->dn_G.p, dn_NP, n, w->cg_b.p, w->ut.p, nostall);
+        t_dense_gemv_kkt.set(g, w->dn_G.p, dn_NP, n, w->cg_b.p, w->ws.p, nostall);
+        t_symv_tiles.set(g, w->dn_G.p, dn_NP, n, w->cg_b.p, w->dn_part.p, nostall);
+        t_symv_sum.set(g, w->dn_part.p, dn_NP, n, w->ut.p, nostall);
+        t_symv_sum_kkt.set(g, w->dn_part.p, dn_NP, n, w->ws.p, nostall);
+      }
       if (has_P) t_spmv_pws.set(g, Pf, w->ws.p, EpiStore{w->cg_Gp.p, 0}, nullptr, nullptr);
       t_spmv_r0.set(g, At, w->ut.p + n,
                     EpiR0{w->cg_r.p, w->cg_p.p, w->cg_M.p, w->rdx(), w->v.p, w->ws.p, has_P ? w->cg_Gp.p : nullptr, w->part.p},
@@ -422,8 +453,19 @@ struct GroupSolve {
     });
     // launch geometry: exactly what the one-problem launches use
     t_sumsq.gx = t_prep.gx = t_cone_pre.gx = t_v_update.gx = t_rsk.gx = t_set_diag_r.gx = t_v_rescale.gx = nbl;
-    t_spmv_y.gx = t_spmv_a.gx = t_res_pri.gx = t_spmv_ax.gx = gx_ar;
-    t_spmv_r0.gx = t_spmv_at.gx = t_res_dual.gx = t_spmv_rhs.gx = gx_at;
+    t_spmv_y.gx = t_spmv_a.gx = t_res_pri.gx = t_spmv_ax.gx = t_dense_y.gx = gx_ar;
+    t_spmv_r0.gx = t_spmv_at.gx = t_res_dual.gx = t_spmv_rhs.gx = t_dense_rhs.gx = gx_at;
+    t_dense_gemv.gx = t_dense_gemv_kkt.gx = ceil_div(n, kDenseThreads / 64);
+    t_symv_tiles.gx = dense ? dense_symv_tiles(dn_NP) : 1;
+    t_symv_sum.gx = t_symv_sum_kkt.gx = ceil_div(n, kDenseThreads);
+    if (dense) {  // the members' matrices as the batched factorisation kernels take them
+      std::vector<DenseMat> hm((size_t)G);
+      std::vector<DenseSrc> hs((size_t)G);
+      for (int g = 0; g < G; ++g) { hm[(size_t)g] = W[(size_t)g]->dense_mat(); hs[(size_t)g] = W[(size_t)g]->dense_src(); }
+      dmat_d.upload(hm.data(), (size_t)G, s);
+      dsrc_d.upload(hs.data(), (size_t)G, s);
+      HIP_CHECK(hipStreamSynchronize(s));  // (hm / hs are locals)
+    }
     t_spmv_pws.gx = t_spmv_p.gx = t_res_px.gx = gx_pf;
     t_cg_update[0].gx = nb_admm;
     t_cg_update[1].gx = t_cg_dir[0].gx = t_cg_dir[1].gx = t_cg_init.gx = t_precond.gx = t_copy_g.gx = nbn;
@@ -454,6 +496,7 @@ struct GroupSolve {
     f(t_kkt_y); f(t_copy_g); f(t_gather_aa); f(t_gg); f(t_fin_gg); f(t_v_rescale); f(t_aa_seed); f(t_aa_update);
     for (int k = 0; k < n_tsqr; ++k) { f(t_aa_tsqr_f21[k]); f(t_aa_tsqr_f11[k]); f(t_aa_tsqr[k]); }
     f(t_aa_solve); f(t_aa_apply); f(t_aa_diffsq); f(t_fin_safe); f(t_aa_restore);
+    f(t_dense_rhs); f(t_dense_gemv); f(t_dense_gemv_kkt); f(t_dense_y); f(t_symv_tiles); f(t_symv_sum); f(t_symv_sum_kkt);
   }
   void upload_all() {
     for_tables([&](auto &t) { t.upload(s); });
@@ -532,13 +575,33 @@ struct GroupSolve {
     go(t_pow, list, count);
   }
 
-  // adaptive-scale update of the listed members (ScsHipWork::update_scale after a positive decision)
-  void apply_scale_updates(const std::vector<int> &su) {
+  // adaptive-scale update of the listed members (ScsHipWork::update_scale after a positive decision); first_setup: the deferred end
+  // of scs_init of dense members (ScsHipWork::finish_pending_setup) — the same launches without the iterate rescaling
+  void apply_scale_updates(const std::vector<int> &su, bool first_setup = false) {
     for (int g : su) set_scale_records(g);
-    t_spmv_y.upload(s); t_spmv_a.upload(s); t_set_diag_r.upload(s);
+    t_spmv_y.upload(s); t_spmv_a.upload(s); t_set_diag_r.upload(s); t_dense_y.upload(s);
     const int *ld = upload_list(su);
     const int cnt = (int)su.size();
     go(t_set_diag_r, ld, cnt);
+    if (dense) {  // ScsHipWork::set_diag_r + update_work_cache with the dense direct solve: re-form and re-invert G, g = KKT^-1 [c; -b]
+      dense_factor_group(dsrc_d.p, dmat_d.p, ld, cnt, dn_NP, s);
+      launches += 1 + 3 * (dn_NP / kDenseB);
+      for (int g : su) W[(size_t)g]->dense_factorisations++;
+      go(t_g_rhs, ld, cnt);
+      go(t_kkt_prep, ld, cnt);
+      go(t_spmv_rhs, ld, cnt);
+      go_dense_gemv(ld, cnt, true);
+      go(t_spmv_ax, ld, cnt);
+      go(t_kkt_y, ld, cnt);
+      go(t_copy_g, ld, cnt);
+      go(t_gg, ld, cnt);
+      go(t_fin_gg, ld, cnt);
+      if (first_setup) return;
+      for (int g : su) W[(size_t)g]->aa.reset();
+      go(t_v_rescale, ld, cnt);
+      for (int g : su) W[(size_t)g]->v_norm_fresh = false;
+      return;
+    }
     go(t_precond, ld, cnt);
     // update_work_cache: g = (R + M)^{-1} [c; -b] by a cold PCG to 1e-12, then g'Rg
     go(t_g_rhs, ld, cnt);
@@ -568,13 +631,29 @@ struct GroupSolve {
   // ---- the lock-step loop ----
   void run(int warm_start) {
     t_start = now_ms();
+    if (dense) {  // members fresh from scs_init: R, G^{-1} and g for all of them in one batched sweep
+      std::vector<int> pend;
+      for (int g = 0; g < G; ++g)
+        if (W[(size_t)g]->setup_pending) pend.push_back(g);
+      if (!pend.empty()) {
+        const double t0 = now_ms();
+        apply_scale_updates(pend, /*first_setup=*/true);
+        sync();
+        const double each = (now_ms() - t0) / (double)pend.size();
+        for (int g : pend) { W[(size_t)g]->setup_pending = false; W[(size_t)g]->setup_time += each; }
+      }
+    }
     for (int g = 0; g < G; ++g) W[(size_t)g]->begin_solve(sols[(size_t)g], infos[(size_t)g], warm_start);
     for (int g = 0; g < G; ++g) {
-      std::snprintf(infos[(size_t)g]->lin_sys_solver, sizeof(infos[(size_t)g]->lin_sys_solver),
-                    "sparse-indirect HIP gfx950 (CSR-stream SpMV, PCG; grouped solve of %d)", G);
+      if (dense)
+        std::snprintf(infos[(size_t)g]->lin_sys_solver, sizeof(infos[(size_t)g]->lin_sys_solver),
+                      "dense-direct HIP gfx950 (explicit inverse of the reduced KKT matrix, order %d; fp64 MFMA Gauss-Jordan; grouped solve of %d)", n, G);
+      else
+        std::snprintf(infos[(size_t)g]->lin_sys_solver, sizeof(infos[(size_t)g]->lin_sys_solver),
+                      "sparse-indirect HIP gfx950 (CSR-stream SpMV, PCG; grouped solve of %d)", G);
       set_scale_records(g);  // (`scale` starts from the settings again)
     }
-    t_spmv_y.upload(s); t_spmv_a.upload(s); t_set_diag_r.upload(s);
+    t_spmv_y.upload(s); t_spmv_a.upload(s); t_set_diag_r.upload(s); t_dense_y.upload(s);
     active.resize((size_t)G);
     std::iota(active.begin(), active.end(), 0);
     upload_active();
@@ -637,26 +716,24 @@ struct GroupSolve {
       }
       // ---- project_lin_sys
       t = now_ms();
+      // (the staging slot is rewritten kParamRing iterations later: the dense loop synchronises at least that often)
+      double *const params_slot = params_h + (size_t)(i % kParamRing) * P_COUNT * G;
+      if (++iters_since_sync >= kParamRing - 2) { sync(); iters_since_sync = 0; }
       for (int g : active) {
-        double *p = params_h + (size_t)g * P_COUNT;
+        double *p = params_slot + (size_t)g * P_COUNT;
         p[P_DO_SCALE] = i >= 1 ? 1.0 : 0.0;
         p[P_RES_MIN] = cg_res_min[(size_t)g];
         p[P_IPOW] = std::pow((double)i + 1, 1.5);
         p[P_FIRST] = i < 1 ? 1.0 : 0.0;
         p[P_PSD_TOL2] = W[(size_t)g]->psd_tol2_for(i);
       }
-      HIP_CHECK(hipMemcpyAsync(params_d.p, params_h, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(params_d.p, params_slot, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
       tmp_list.clear();
       for (int g : active)
         if (!W[(size_t)g]->v_norm_fresh) { tmp_list.push_back(g); W[(size_t)g]->v_norm_fresh = true; }
       if (!tmp_list.empty()) go(t_sumsq, tmp_list.size() == active.size() ? active_d : upload_list(tmp_list), (int)tmp_list.size());
       go(t_prep, active_d, na);
-      go(t_spmv_y, active_d, na);
-      if (has_P) go(t_spmv_pws, active_d, na);
-      go(t_spmv_r0, active_d, na);
-      go(t_fin_head, active_d, na);
-      static const int pred_mode = [] { const char *e = getenv("SCS_HIP_GROUP_PREDICT"); return e ? atoi(e) : 1; }();  // 0: max + 1 (lab)
-      finish_cg(active, active_d, 0, [&](int g) { return pred_mode ? W[(size_t)g]->recent_cg_q3() : W[(size_t)g]->recent_cg_max() + 1; }, [&] {
+      auto deferred_host_work = [&] {
         // first synchronisation of the iteration: everything the host deferred
         for (int g : aa_solved) {
           ScsHipWork *w = W[(size_t)g];
@@ -666,12 +743,34 @@ struct GroupSolve {
           for (int g : active)
             if (aa_mode[(size_t)g] >= 1) W[(size_t)g]->aa.iter++;
         for (int g : active) process_pending_flags(g);
-      });
+      };
+      if (dense) {
+        // three dependent launches, nothing to wait for: the host only synchronises where it has something to decide
+        // (an Anderson step's outcome, a convergence check) — plain iterations are enqueued back to back
+        go(t_dense_rhs, active_d, na);
+        go_dense_gemv(active_d, na, false);
+        go(t_dense_y, active_d, na);
+        if (aa_now) {
+          read_flags(active_d, na);
+          sync();
+          iters_since_sync = 0;
+          deferred_host_work();
+        }
+        for (int g : active) W[(size_t)g]->last_cg_iters = 0;
+      } else {
+      go(t_spmv_y, active_d, na);
+      if (has_P) go(t_spmv_pws, active_d, na);
+      go(t_spmv_r0, active_d, na);
+      go(t_fin_head, active_d, na);
+      static const int pred_mode = [] { const char *e = getenv("SCS_HIP_GROUP_PREDICT"); return e ? atoi(e) : 1; }();  // 0: max + 1 (lab)
+      finish_cg(active, active_d, 0, [&](int g) { return pred_mode ? W[(size_t)g]->recent_cg_q3() : W[(size_t)g]->recent_cg_max() + 1; }, deferred_host_work);
+      iters_since_sync = 0;
       for (int g : active) {
         ScsHipWork *w = W[(size_t)g];
         w->last_cg_iters = flags_of(g)[F_ITERS];
         w->note_cg_iters(w->last_cg_iters);
         w->tot_cg_iters += w->last_cg_iters;
+      }
       }
       t_lin += now_ms() - t;
       // ---- tau, cone projections
@@ -741,13 +840,17 @@ struct GroupSolve {
       std::vector<int> last;
       for (int g : cont)
         if (i == W[(size_t)g]->stgs.max_iters - 1) last.push_back(g);
-      if (!last.empty()) {  // (solve_impl's finalisation reads the flags once more: a safeguard enqueued just now)
+      {  // solve_impl's finalisation reads the flags once more: a safeguard enqueued just now (`last`) or — dense linsys, where plain
+         // iterations do not synchronise — at an Anderson step since the last synchronisation (a member that converges at this check)
+        std::vector<int> ending(last);
+        for (int g : active)
+          if (stop[(size_t)g]) ending.push_back(g);
         bool pending = false;
-        for (int g : last) pending = pending || W[(size_t)g]->aa.pending_safeguard;
+        for (int g : ending) pending = pending || W[(size_t)g]->aa.pending_safeguard;
         if (pending) {
-          read_flags(upload_list(last), (int)last.size());
+          read_flags(nullptr, 0);
           sync();
-          for (int g : last) process_pending_flags(g);
+          for (int g : ending) process_pending_flags(g);
         }
       }
       for (int g : active) {

@@ -29,6 +29,7 @@
 #include "normalize_dev.hpp"
 #include "psd.hpp"
 #include "cg_persist.hpp"
+#include "dense.hpp"
 #include "setup_dev.hpp"
 #include "setup_cs_dev.hpp"
 #include "spmv.hpp"
@@ -903,9 +904,61 @@ struct ScsHipWork {
   // -------------------------------------------------------------- helpers
   int vb(long nelem) const { return vec_blocks(nelem); }
 
+  // ---- dense direct linsys (dense.hpp; linsys == 1): G^{-1} = (R_x + P + A' R_y^{-1} A)^{-1} resident in HBM, rebuilt whenever R changes
+  int linsys = 0;  // 0: indirect (PCG), 1: dense direct
+  DevBuf<double> dn_G, dn_Pk, dn_L, dn_Rt, dn_part;
+  int dn_NP = 0, dense_factorisations = 0;
+  bool dense() const { return linsys == 1; }
+  DenseMat dense_mat() const { return DenseMat{dn_G.p, dn_Pk.p, dn_L.p, dn_Rt.p, n, dn_NP}; }
+  DenseSrc dense_src() const {
+    return DenseSrc{At.rowptr.p, At.col.p, At.val.p, Ar.rowptr.p, Ar.col.p, Ar.val.p, has_P ? Pf.rowptr.p : nullptr,
+                    has_P ? Pf.col.p : nullptr, has_P ? Pf.val.p : nullptr, diag_r.p};
+  }
+  void dense_alloc() {
+    dn_NP = dense_np(n);
+    dn_G.alloc((size_t)dn_NP * dn_NP);
+    dn_Pk.alloc((size_t)kDenseB * kDenseB);
+    dn_L.alloc((size_t)dn_NP * kDenseB);
+    dn_Rt.alloc((size_t)dn_NP * kDenseB);
+    dn_part.alloc_zero(dense_symv_part_len(dn_NP), stream);
+  }
+  // x = X' b over the WHOLE computed inverse X (default), or SCS_HIP_DENSE_GEMV=half: the two-launch product that reads only the tiles on
+  // and below the diagonal.  The half product is NOT the default although it halves the bytes of the HBM-bound part of a batch: a
+  // Gauss-Jordan inverse is accurate on ONE side (here || X G - I || ~ eps kappa, so X' b solves G x = b to ~ kappa eps), while its
+  // asymmetry — what a product that mirrors one triangle sees — is kappa times larger: measured on the KKT test systems
+  // (kappa = 2e4) 1e-11 against 3.5e-8 relative error (tools/dbg/dense_gemv_err.py, profiles/r04_dense_linsys.txt).
+  static bool dense_full_gemv() {
+    static const bool v = [] { const char *e = getenv("SCS_HIP_DENSE_GEMV"); return !(e && e[0] == 'h'); }();
+    return v;
+  }
+  void dense_gemv(const double *b, double *x, const int *st) {
+    if (dense_full_gemv())
+      hipLaunchKernelGGL(k_dense_gemv, dim3(ceil_div(n, kDenseThreads / 64)), dim3(kDenseThreads), 0, stream, (const double *)dn_G.p, dn_NP, n, b, x, st);
+    else
+      dense_apply(dn_G.p, dn_NP, n, b, dn_part.p, x, st, stream);
+  }
+  // Dense workspaces finish their setup — R, G^{-1}, g = KKT^{-1} [c; -b] — at the first solve (or update) instead of inside scs_init:
+  // a batch of them then forms and inverts all its matrices in ONE batched sweep (GroupSolve::run), 66 launches for the whole group
+  // instead of 66 launch-bound ones per member (SCS_HIP_DENSE_LAZY=0: inside scs_init).
+  bool setup_pending = false;
+  void finish_pending_setup() {
+    if (!setup_pending) return;
+    const double t0 = now_ms();
+    set_diag_r();
+    update_work_cache();
+    HIP_CHECK(hipStreamSynchronize(stream));
+    setup_pending = false;
+    setup_time += now_ms() - t0;
+  }
+  void dense_refactor() {  // diag_r must be current on the stream
+    dense_factor(dense_src(), dense_mat(), stream);
+    ++dense_factorisations;
+  }
+
   void set_diag_r() {
     diag_r_structured = true;
     hipLaunchKernelGGL(k_set_diag_r, dim3(vb(l)), dim3(kVecThreads), 0, stream, diag_r.p, n, m, cone.z, stgs.rho_x, scale);
+    if (dense()) { dense_refactor(); return; }
     hipLaunchKernelGGL(k_precond, dim3(vb(n)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, At.val.p, diag_r.p,
                        has_P ? Pdiag.p : (const double *)nullptr, cg_M.p, n);
   }
@@ -1045,7 +1098,9 @@ struct ScsHipWork {
     HIP_CHECK(hipMemsetAsync(part.p, 0, sizeof(double), stream));
     hipLaunchKernelGGL(k_fin_tol, dim3(1), dim3(kVecThreads), 0, stream, part.p, 1, 0.0, 1.0, tol, 0, (const double *)nullptr, sc.p,
                        fl.p);
-    const int its = run_cg(ws.p, nullptr, 10 * n);  // solution in ws
+    int its = 0;
+    if (dense()) dense_gemv(cg_b.p, ws.p, nullptr);
+    else its = run_cg(ws.p, nullptr, 10 * n);  // solution in ws
     launch_spmv(Ar.view(), ws.p, EpiStore{tmp_m.p, 0}, nullptr, stream);
     hipLaunchKernelGGL(k_kkt_y, dim3(vb(m)), dim3(kVecThreads), 0, stream, rhs, tmp_m.p, diag_r.p, n, m);
     HIP_CHECK(hipMemcpyAsync(rhs, ws.p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
@@ -1088,6 +1143,16 @@ struct ScsHipWork {
     // tolerance, ||r0||, r0'M r0, step counter, zero-rhs short circuit: one finalize launch
     hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
                        ut.p, (long)n + m, stall);
+  }
+  // dense direct variant of the linear solve of an iteration: rhs = R_x v_x - A' v_y;  u~_x = G^{-1} rhs;  u~_y = v_y + R_y^{-1} A u~_x.
+  // Three dependent launches behind k_prep, no convergence flag: nothing here (or behind it) waits for the device.
+  void enqueue_lin_sys_dense() {
+    const int nbl = vb(l);
+    hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
+                       d_params, part_v.p, nbl, sc.p, part2.p, stall);
+    launch_spmv(At.view(), v.p + n, EpiDenseRhs{cg_b.p, rdx(), v.p}, stall, stream);
+    dense_gemv(cg_b.p, ut.p, stall);
+    launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, rdy(), v.p + n}, stall, stream);
   }
   // ||v||^2 partials for k_prep when something other than enqueue_v_update wrote v (start, AA, scale update)
   void ensure_v_norm() {
@@ -1138,6 +1203,18 @@ struct ScsHipWork {
   void enqueue_v_update() {
     hipLaunchKernelGGL(k_v_update, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, u.p, ut.p, stgs.alpha, l, part_v.p, stall);
     v_norm_fresh = true;
+  }
+
+  // dense direct linsys: a plain iteration has nothing the host must look at (no CG flags): enqueue it and go on — the queue only
+  // drains at Anderson steps and convergence checks
+  void enqueue_plain_dense(int iter) {
+    set_iter_params(iter, iter & 1);
+    ensure_v_norm();
+    enqueue_lin_sys_dense();
+    enqueue_lin_sys_tail();
+    enqueue_cones();
+    enqueue_v_update();
+    last_cg_iters = 0;
   }
 
   // ---- run-ahead mode: one whole plain iteration (no convergence check, no AA, no logging) in the queue ----
@@ -1316,6 +1393,11 @@ struct ScsHipWork {
     if (n_psd + n_cs > 0 && psd_tol2_for(iter) != h_params_base[P_PSD_TOL2]) HIP_CHECK(hipStreamSynchronize(stream));
     set_iter_params(iter);
     ensure_v_norm();
+    if (dense()) {
+      enqueue_lin_sys_dense();
+      last_cg_iters = 0;
+      return;
+    }
     if (persist_wgs > 0) {
       if (graph) HIP_CHECK(hipGraphLaunch(g_pre[0], stream));
       else enqueue_lin_sys_persist();
@@ -1567,7 +1649,9 @@ struct ScsHipWork {
   void begin_solve(ScsSolution *sol, ScsInfo *info, int warm_start) {
     std::memset(info, 0, sizeof(*info));
     info->setup_time = setup_time;
-    if (persist_wgs > 0)
+    if (dense())
+      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "dense-direct HIP gfx950 (explicit inverse of the reduced KKT matrix, order %d; fp64 MFMA Gauss-Jordan)", n);
+    else if (persist_wgs > 0)
       std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (PCG, persistent %dx%d-wave kernel)",
                     persist_wgs, 4 * persist_ng);
     else {
@@ -1879,8 +1963,14 @@ static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, c
   std::fprintf(f, "\n");
 }
 
-static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
+// linsys: 0 = what SCS_HIP_LINSYS says (default indirect), 1 = indirect (PCG), 2 = dense direct (dense.hpp)
+static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, int linsys = 0) {
   const double t0 = now_ms();
+  if (linsys == 0) {
+    const char *e = getenv("SCS_HIP_LINSYS");
+    linsys = (e && (e[0] == 'd' || e[0] == 'D')) ? 2 : 1;
+  }
+  if (linsys != 1 && linsys != 2) throw std::runtime_error("unknown linear-system solver kind");
   if (!d || !k || !stgs) throw std::runtime_error("null argument");
   if (d->m <= 0 || d->n <= 0 || !d->A || !d->b || !d->c) throw std::runtime_error("invalid data dimensions");
   if (!validate_matrix(d->A, d->m, d->n)) throw std::runtime_error("invalid A matrix");
@@ -1900,6 +1990,11 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   if (!build_cone(k, w->cone)) throw std::runtime_error("invalid cone");
   if (w->cone.m != d->m) throw std::runtime_error("cone dimensions do not match m");
   const int n = d->n, m = d->m;
+  if (linsys == 2 && n > kDenseMaxN)
+    throw std::runtime_error("hip_dense: n = " + std::to_string(n) + " exceeds " + std::to_string(kDenseMaxN) +
+                             " (the explicit inverse of the reduced KKT matrix would need " + std::to_string((long)n * n * 8 / 1000000) +
+                             " MB); use the indirect solver");
+  w->linsys = linsys == 2 ? 1 : 0;
   w->n = n; w->m = m; w->l = (long)n + m + 1;
   w->stgs = *stgs;
   if (stgs->write_data_filename) w->write_data_filename = stgs->write_data_filename;
@@ -2109,9 +2204,19 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->aa.init(l, stgs->acceleration_lookback, stgs->acceleration_type_1, stgs->acceleration_regularization,
              stgs->acceleration_relaxation, /*safeguard_factor=*/1.0, /*max_weight_norm=*/1e10, s);
   mark("vectors, b/c scaling, cones, AA workspace");
-  // ---- R, preconditioner, pre-solved g ----
-  w->set_diag_r();
-  w->update_work_cache();
+  // ---- R, preconditioner (or G^{-1}), pre-solved g ----
+  if (w->dense()) {
+    w->dense_alloc();
+    w->persist_wgs = 0;
+  }
+  {
+    const char *el = getenv("SCS_HIP_DENSE_LAZY");
+    w->setup_pending = w->dense() && !(el && el[0] == '0');
+  }
+  if (!w->setup_pending) {
+    w->set_diag_r();
+    w->update_work_cache();
+  }
   HIP_CHECK(hipStreamSynchronize(s));
   mark("R, preconditioner, g = KKT^-1 h");
   w->setup_time = now_ms() - t0;
@@ -2162,6 +2267,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   const int n = w->n, m = w->m;
   const long l = w->l;
   hipStream_t s = w->stream;
+  w->finish_pending_setup();
   w->begin_solve(sol, info, warm_start);
   double t_lin = 0, t_cone = 0, t_acc = 0;
   FILE *csv = nullptr;
@@ -2194,9 +2300,9 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
   // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
   static const long graph_max_l = [] { const char *e = getenv("SCS_HIP_GRAPH_MAX_L"); return e ? atol(e) : 1000000L; }();  // experiments
-  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= graph_max_l && !w->pipelined;
+  const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= graph_max_l && !w->pipelined && !w->dense();
   bool use_graphs = graphs_wanted && w->graphs_ready;
-  const bool run_ahead = w->pipelined && w->persist_wgs == 0;  // (in-situ profiling samples ride along: enqueue_plain_iteration)
+  const bool run_ahead = w->pipelined && w->persist_wgs == 0 && !w->dense();  // (in-situ profiling samples ride along: enqueue_plain_iteration)
   // an iteration is "plain" when the host has nothing to decide in it: no convergence check / print / log row,
   // no Anderson step, not the last one.  Plain iterations may be enqueued whole, and one ahead (run-ahead mode).
   auto is_plain = [&](int it) {
@@ -2219,6 +2325,13 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
       w->mark_cg = w->tot_cg_iters;
       w->mark_aa_calls = w->aa.st.iter;
       w->mark_aa_accept = w->aa.st.n_accept;
+    }
+    if (w->dense() && w->pipelined && is_plain(i)) {  // nothing to wait for: the queue drains at the next Anderson step / check
+      double t = now_ms();
+      w->enqueue_plain_dense(i);
+      if ((i & 63) == 0) HIP_CHECK(hipGetLastError());
+      t_lin += now_ms() - t;
+      continue;
     }
     if (run_ahead && (enq_upto >= i || is_plain(i))) {  // (already queued: is_plain may have changed its mind since)
       double t = now_ms();
@@ -2343,6 +2456,17 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   }
 }
 
+ScsWork *scs_hip_init_linsys(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, int linsys) {
+  try {
+    set_last_error("");
+    return init_impl(d, k, stgs, linsys);
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+int scs_hip_linsys_kind(const ScsWork *w) { return w ? (w->dense() ? 2 : 1) : 0; }
+
 scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_start) {
   if (!w || !sol || !info) return SCS_FAILED;
   try {
@@ -2380,8 +2504,19 @@ static scs_int solve_one_group(ScsWork **works, ScsSolution **sols, ScsInfo **in
   std::vector<std::unique_lock<std::mutex>> locks;
   std::vector<hipStream_t> saved;
   GroupSolve gs;
+  //  every member starts out "unfinished": the catch block below marks exactly those the solve did not finish, also when
+  // the exception comes before the members' begin_solve cleared their infos (caller memory); member mutexes are taken in ADDRESS
+  // order, so two concurrent batches that share workspaces in different orders cannot deadlock (the Python glue sorts too)
+  for (int j : idx) {
+    std::memset(infos[j], 0, sizeof(ScsInfo));
+    infos[j]->status_val = SCS_UNFINISHED;
+  }
   try {
-    for (int j : idx) locks.emplace_back(works[j]->mtx);
+    {
+      std::vector<int> order(idx);
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return std::less<ScsHipWork *>()(works[a], works[b]); });
+      for (int j : order) locks.emplace_back(works[j]->mtx);
+    }
     HIP_CHECK(hipSetDevice(works[idx[0]]->device));
     gs.s = works[idx[0]]->stream;
     for (int j : idx) {
@@ -2397,7 +2532,7 @@ static scs_int solve_one_group(ScsWork **works, ScsSolution **sols, ScsInfo **in
     rc = -1;
     (void)hipStreamSynchronize(gs.s);
     for (int j : idx)
-      if (infos[j]->status_val == SCS_UNFINISHED || infos[j]->status[0] == 0) {
+      if (infos[j]->status[0] == 0) {  // (finish_solve writes the status string: empty = this member never got there)
         infos[j]->status_val = SCS_FAILED;
         std::snprintf(infos[j]->status, sizeof(infos[j]->status), "failure");
         fill_nan(sols[j]->x, works[j]->n);
@@ -2501,7 +2636,8 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {
       w->Einv.upload(ei.data(), n, w->stream);
     }
     HIP_CHECK(hipStreamSynchronize(w->stream));
-    w->update_work_cache();
+    if (w->setup_pending) w->finish_pending_setup();  // (dense workspace that has not solved yet: R, G^{-1} and g in one go)
+    else w->update_work_cache();
     HIP_CHECK(hipStreamSynchronize(w->stream));
     return 0;
   } catch (const std::exception &e) {
@@ -2901,8 +3037,17 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
   }
 }
 
+static int kkt_solve_entry(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs, scs_float tol,
+                           scs_int *cg_iters, bool dense);
 int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs, scs_float tol,
                       scs_int *cg_iters) {
+  return kkt_solve_entry(A, P, diag_r, rhs, tol, cg_iters, false);
+}
+int scs_hip_kkt_solve_dense(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs) {
+  return kkt_solve_entry(A, P, diag_r, rhs, 0., nullptr, true);
+}
+static int kkt_solve_entry(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs, scs_float tol,
+                           scs_int *cg_iters, bool dense) {
   try {
     set_last_error("");
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid A");
@@ -2942,8 +3087,15 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
     w.part2.alloc_zero(2 * kMaxVecBlocks, s);
     w.sc.alloc_zero(S_COUNT, s);
     w.fl.alloc_zero(F_COUNT, s);
-    hipLaunchKernelGGL(k_precond, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w.At.rowptr.p, w.At.col.p, w.At.val.p,
-                       w.diag_r.p, P ? w.Pdiag.p : (const double *)nullptr, w.cg_M.p, n);
+    if (dense) {
+      if (n > kDenseMaxN) throw std::runtime_error("dense KKT solve: n too large");
+      w.linsys = 1;
+      w.dense_alloc();
+      w.dense_refactor();
+    } else {
+      hipLaunchKernelGGL(k_precond, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, w.At.rowptr.p, w.At.col.p, w.At.val.p,
+                         w.diag_r.p, P ? w.Pdiag.p : (const double *)nullptr, w.cg_M.p, n);
+    }
     DevBuf<double> drhs;
     drhs.upload(rhs, (size_t)n + m, s);
     const int its = w.kkt_solve(drhs.p, tol);

@@ -51,6 +51,7 @@ class LinearSolver(enum.Enum):
   GPU_INDIRECT = "gpu_indirect"
   CUDSS = "cudss"
   HIP_INDIRECT = "hip_indirect"  # MI355X (gfx950): device-resident indirect solver
+  HIP_DENSE = "hip_dense"  # MI355X (gfx950): device dense direct solver for small problems (n <= 4096)
 
 
 # enum member -> extension-module name under the `scs` package
@@ -63,6 +64,7 @@ _BACKEND_MODULES = {
     LinearSolver.GPU_INDIRECT: "_scs_gpu",
     LinearSolver.CUDSS: "_scs_cudss",
     LinearSolver.HIP_INDIRECT: "_scs_hip",
+    LinearSolver.HIP_DENSE: "_scs_hip_dense",
 }
 
 

@@ -135,6 +135,12 @@ def _load():
         raise ImportError("scs._scs_hip: cannot load %s: %s" % (path, e))
     lib.scs_init.restype = C.c_void_p
     lib.scs_init.argtypes = [C.POINTER(_ScsData), C.POINTER(_ScsCone), C.POINTER(_ScsSettings)]
+    lib.scs_hip_init_linsys.restype = C.c_void_p
+    lib.scs_hip_init_linsys.argtypes = [C.POINTER(_ScsData), C.POINTER(_ScsCone), C.POINTER(_ScsSettings), c_int]
+    lib.scs_hip_linsys_kind.restype = c_int
+    lib.scs_hip_linsys_kind.argtypes = [C.c_void_p]
+    lib.scs_hip_kkt_solve_dense.restype = c_int
+    lib.scs_hip_kkt_solve_dense.argtypes = [C.POINTER(_ScsMatrix), C.POINTER(_ScsMatrix), _PD, _PD]
     lib.scs_solve.restype = c_int
     lib.scs_solve.argtypes = [C.c_void_p, C.POINTER(_ScsSolution), C.POINTER(_ScsInfo), c_int]
     lib.scs_hip_solve_batch.restype = c_int
@@ -414,6 +420,10 @@ def _info_dict(info):
 class SCS(object):
     """Raw backend type; `scs.SCS` (scs/__init__.py) is the user-facing wrapper."""
 
+    # linear-system solver this backend type builds (include/scs_hip.h scs_hip_init_linsys): 0 = the library's default
+    # (sparse indirect unless SCS_HIP_LINSYS=dense); scs._scs_hip_dense.SCS sets 2 (dense direct)
+    _LINSYS = 0
+
     def __init__(self, shape, Ax, Ai, Ap, Px, Pi, Pp, b, c, cone, **settings):
         if getattr(self, "_work", None):
             raise ValueError("Workspace already setup!")
@@ -516,7 +526,10 @@ class SCS(object):
         self._x = np.zeros(n)
         self._y = np.zeros(m)
         self._s = np.zeros(m)
-        work = _lib.scs_init(C.byref(d), C.byref(k), C.byref(st))  # GIL released by ctypes
+        if self._LINSYS:
+            work = _lib.scs_hip_init_linsys(C.byref(d), C.byref(k), C.byref(st), self._LINSYS)
+        else:
+            work = _lib.scs_init(C.byref(d), C.byref(k), C.byref(st))  # GIL released by ctypes
         if not work:
             # the reference's message (R:scs/scsobject.h:903-912) + the backend's own reason: invalid data, no GPU,
             # out of HBM, or a limit this backend has and the reference has not (INTEGRATION.md "Limits")
@@ -635,7 +648,9 @@ class SCS(object):
 def solve_batch(solvers, warm_start=False):
     """Grouped solve of several backend `SCS` objects (include/scs_hip.h: scs_hip_solve_batch): equally shaped
     problems share every kernel launch of the ADMM loop.  Returns the list of result dicts `solve()` would have
-    returned for each (iterates bit-identical to separate solves).  warm_start uses each object's stored solution."""
+    returned for each (iterates bit-identical to separate solves).  warm_start uses each object's stored solution.
+    A member that fails comes back with status "failure" like a failed .solve(); RuntimeError only for argument /
+    whole-call errors."""
     if not isinstance(warm_start, (bool, np.bool_)):
         raise TypeError("argument 2 must be bool, not %s" % type(warm_start).__name__)
     solvers = list(solvers)
@@ -666,7 +681,9 @@ def solve_batch(solvers, warm_start=False):
     finally:
         for sv in ordered:
             sv._lock.release()
-    if rc != 0:
+    # rc != 0 also when a single member ended SCS_FAILED: its dict says so (status_val -4, NaN vectors) exactly as .solve() would
+    # report it, and the other members keep their results.  Only a call that failed as a whole raises.
+    if rc != 0 and any(o["info"]["status_val"] == 0 for o in out):
         raise RuntimeError("libscs_hip: " + err)
     return out
 
@@ -758,6 +775,18 @@ def kkt_solve(A, P, diag_r, rhs, tol=1e-12):
     _check(_lib.scs_hip_kkt_solve(C.byref(M), C.byref(Pm) if Pm is not None else None, _pd(dr), _pd(r),
                                   float(tol), C.byref(its)))
     return r, its.value
+
+
+def kkt_solve_dense(A, P, diag_r, rhs):
+    """The same KKT system through the dense direct linsys (csrc/dense.hpp): explicit inverse of the reduced matrix."""
+    M, keep = _matrix(A)
+    Pm = None
+    if P is not None:
+        Pm, keep2 = _matrix(P)
+    r = np.array(rhs, dtype=np.float64, copy=True)
+    dr = np.ascontiguousarray(diag_r, dtype=np.float64)
+    _check(_lib.scs_hip_kkt_solve_dense(C.byref(M), C.byref(Pm) if Pm is not None else None, _pd(dr), _pd(r)))
+    return r
 
 
 def normalize(A, P, b, c, cone):

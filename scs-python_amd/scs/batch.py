@@ -31,9 +31,16 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def _default_solve(data, cone, settings):
+def _make_solver(data, cone, settings):
+    """settings may name the HIP linear solver ("linear_solver": HIP_INDIRECT (default) or HIP_DENSE)"""
     import scs
-    return scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings).solve()
+    settings = dict(settings)
+    ls = settings.pop("linear_solver", scs.LinearSolver.HIP_INDIRECT)
+    return scs.SCS(data, cone, linear_solver=ls, **settings)
+
+
+def _default_solve(data, cone, settings):
+    return _make_solver(data, cone, settings).solve()
 
 
 def pack_result(sol, width):
@@ -72,8 +79,7 @@ def _fill_row(solver, sol, row):
 
 def _solve_into_row(data, cone, settings, row):
     """default backend, device-resident result: solve, then hand the result over in HBM.  Returns the info dict."""
-    import scs
-    solver = scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
+    solver = _make_solver(data, cone, settings)
     return _fill_row(solver, solver.solve(), row)
 
 
@@ -85,8 +91,7 @@ def _grouped_local_solve(local_problems, threads, timing=None):
     t0 = time.perf_counter()
 
     def make(p):
-        data, cone, settings = p
-        return scs.SCS(data, cone, linear_solver=scs.LinearSolver.HIP_INDIRECT, **settings)
+        return _make_solver(*p)
 
     if threads > 1 and len(local_problems) > 1:
         from concurrent.futures import ThreadPoolExecutor

@@ -1,0 +1,316 @@
+"""GPU tests of the DENSE DIRECT linear-system solver (csrc/dense.hpp; `scs.LinearSolver.HIP_DENSE`, module
+`scs._scs_hip_dense`): the KKT solve against the oracle's sparse LDL' (the "QDLDL-equivalent"),
+whole solves against the oracle's direct path on the reference-generated goldens, against the indirect HIP path, adaptive
+scale updates (each re-inverts the reduced KKT matrix), warm start / update, and the limits of the backend.
+
+Tolerances: KKT solve 1e-9 relative to the largest entry (an explicit inverse of an SPD matrix with condition number
+~1e3..1e5); full solves as tests/test_hip_parity.py (x, s at rtol 1e-4 of the oracle's direct answer, y by certificate
+where the dual is not unique, objective 1e-6)."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import helpers
+import problem_gen as pg
+
+pytestmark = pytest.mark.gpu
+
+STG = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from scs import _scs_hip
+    assert _scs_hip.device_count() > 0, "GPU tests need a HIP device (no CPU fallback exists)"
+    return _scs_hip
+
+
+@pytest.fixture(scope="module")
+def dense():
+    from scs import _scs_hip_dense
+    return _scs_hip_dense
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import scs_oracle
+    return scs_oracle
+
+
+def _rand_csc(m, n, density, seed):
+    rng = np.random.RandomState(seed)
+    A = sparse.rand(m, n, density, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("m,n,density,with_P", [
+    (90, 40, 0.2, False), (600, 250, 0.03, True), (600, 250, 0.03, False), (1500, 700, 0.01, True),
+    (4050, 1350, 0.03, False),   # a config-5 member's shape: 22 block steps of the Gauss-Jordan sweep
+    (300, 64, 0.1, False), (300, 65, 0.1, True), (20, 1, 0.9, False),
+])
+def test_kkt_solve_dense_vs_direct_ldl(hip, oracle, m, n, density, with_P):
+    A = _rand_csc(m, n, density, 21 + n)
+    rng = np.random.RandomState(8)
+    P = None
+    if with_P:
+        B = sparse.rand(n, n, min(1.0, 4.0 / n), format="csc", random_state=rng)
+        P = sparse.triu(B.T @ B + sparse.eye(n) * 0.1, format="csc")
+        P.sort_indices()
+    nz = min(50, m // 3)
+    diag_r = np.concatenate([np.full(n, 1e-3), np.full(nz, 0.01), np.full(m - nz, 10.0)])
+    rhs = rng.randn(n + m)
+    ref, _ = oracle.kkt_solve(A, P, diag_r, rhs, indirect=False)
+    got = hip.kkt_solve_dense(A, P, diag_r, rhs)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    # and the residual of the KKT system itself, [[R_x + P, A'], [A, -R_y]] z = rhs
+    Pf = (P + sparse.triu(P, 1).T) if P is not None else None
+    x, y = got[:n], got[n:]
+    rx = diag_r[:n] * x + (Pf @ x if Pf is not None else 0.0) + A.T @ y - rhs[:n]
+    ry = A @ x - diag_r[n:] * y - rhs[n:]
+    assert max(np.abs(rx).max(), np.abs(ry).max()) < 1e-9 * max(1.0, np.abs(rhs).max(), np.abs(got).max())
+
+
+def test_kkt_solve_dense_is_deterministic(hip):
+    A = _rand_csc(900, 300, 0.02, 5)
+    diag_r = np.concatenate([np.full(300, 1e-6), np.full(900, 10.0)])
+    rhs = np.random.RandomState(2).randn(1200)
+    a = hip.kkt_solve_dense(A, None, diag_r, rhs)
+    b = hip.kkt_solve_dense(A, None, diag_r, rhs)
+    assert np.array_equal(a, b)
+
+
+def _solve_dense_and_oracle(dense, oracle, data, K, **kw):
+    stg = dict(STG)
+    stg.update(kw)
+    args = helpers.raw_args(data, K)
+    got = dense.SCS(*args, **stg).solve(False, None, None, None)
+    ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
+    return got, ref
+
+
+def _assert_xys(got, ref, rtol=1e-4, keys=("x", "y", "s")):
+    for key in keys:
+        scale = np.abs(ref[key]).max()
+        np.testing.assert_allclose(got[key], ref[key], rtol=rtol, atol=rtol * scale, err_msg=key)
+
+
+@pytest.mark.parametrize("fname,prefix", [
+    ("problems_std.npz", "std_feas_"), ("problems_rand.npz", "feas0_"), ("problems_rand.npz", "feas1_"),
+    ("problems_sdp.npz", "feas0_"), ("problems_sdp.npz", "feas2_"),
+])
+def test_dense_solve_feasible_golden(dense, oracle, fname, prefix):
+    data, K, p_star = helpers.load_problem(fname, prefix)
+    got, ref = _solve_dense_and_oracle(dense, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    assert got["info"]["lin_sys_solver"].startswith("dense-direct")
+    assert got["info"]["cg_iters"] == 0
+    assert abs(got["info"]["pobj"] - p_star) < 1e-5 * max(1, abs(p_star))
+    if prefix == "std_feas_":   # (the others have a non-unique dual: tests/test_hip_parity.py::test_solve_feasible_golden)
+        _assert_xys(got, ref, keys=("x", "s"))
+    assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) < 1e-6 * max(1, abs(p_star))
+    pri, dual, gap = helpers.kkt_certificate(data, got)
+    assert pri < 1e-6 and dual < 1e-6 and gap < 1e-6
+    np.testing.assert_allclose(got["s"], oracle.proj_cone(got["s"], K), atol=1e-6)
+    np.testing.assert_allclose(got["y"], oracle.proj_cone(got["y"], K, dual=True), atol=1e-6)
+    # both are direct solves of the same KKT systems; accelerated iteration counts still drift (profiles/r03_aa_drift_sweep.txt)
+    assert 0.4 * ref["info"]["iter"] - 50 <= got["info"]["iter"] <= 2.5 * ref["info"]["iter"] + 50
+
+
+@pytest.mark.parametrize("fname,prefix,status", [
+    ("problems_std.npz", "std_infeas_", "infeasible"), ("problems_rand.npz", "infeas0_", "infeasible"),
+    ("problems_std.npz", "std_unbdd_", "unbounded"), ("problems_rand.npz", "unbdd0_", "unbounded"),
+])
+def test_dense_solve_certificates_golden(dense, oracle, fname, prefix, status):
+    data, K, _ = helpers.load_problem(fname, prefix)
+    got, ref = _solve_dense_and_oracle(dense, oracle, data, K, eps_infeas=1e-7)
+    assert got["info"]["status"] == status and ref["info"]["status"] == status
+    if status == "infeasible":
+        y = got["y"]
+        assert np.linalg.norm(data["A"].T @ y) < 1e-3 and data["b"] @ y < -0.1
+        np.testing.assert_allclose(y, oracle.proj_cone(y, K, dual=True), atol=1e-4)
+    else:
+        x, s = got["x"], got["s"]
+        assert np.linalg.norm(data["A"] @ x + s) < 1e-3 and abs(data["c"] @ x + 1.0) < 1e-9
+
+
+def test_dense_qp_entrywise_parity(dense, oracle):
+    """strictly convex QP over a mixed cone (unique x, y, s): all three vectors entry-wise against the oracle's LDL'"""
+    K = {"z": 10, "l": 120, "q": [8, 12], "s": [6], "ep": 4, "p": [0.3, -0.6]}
+    data, p_star, _ = pg.gen_feasible_qp(K, 90, 6, 314, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    got, ref = _solve_dense_and_oracle(dense, oracle, data, K)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _assert_xys(got, ref)
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+
+
+def test_dense_against_indirect_on_a_config5_member(hip, dense, oracle):
+    """one problem of BASELINE.json configs[4] (l + q + s, n = 1350, m = 4050): dense direct vs indirect HIP path"""
+    K, n, k, seed = pg.workload("config5_small")
+    data, p_star, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: hip.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    stg = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False)
+    a = dense.SCS(*args, **stg).solve(False, None, None, None)
+    b = hip.SCS(*args, **stg).solve(False, None, None, None)
+    assert a["info"]["status"] == "solved" and b["info"]["status"] == "solved"
+    assert abs(a["info"]["pobj"] - p_star) < 1e-5 * max(1, abs(p_star))
+    _assert_xys(a, b, rtol=1e-4, keys=("x", "s"))
+    pri, dual, gap = helpers.kkt_certificate(data, a)
+    assert pri < 1e-5 and dual < 1e-5 and gap < 1e-5
+    assert a["info"]["cg_iters"] == 0 and b["info"]["cg_iters"] > 0
+
+
+def test_dense_scale_updates_reinvert(dense, oracle):
+    """badly scaled data: the adaptive scale moves, every move re-forms and re-inverts the reduced KKT matrix"""
+    K = {"l": 200, "q": [8] * 4}
+    data, p_star, _ = pg.gen_feasible(K, 80, 8, 4300, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    data["b"] = data["b"] * 1e3
+    args = helpers.raw_args(data, K)
+    stg = dict(STG, scale=1e-3, eps_abs=1e-8, eps_rel=1e-8)
+    got = dense.SCS(*args, **stg).solve(False, None, None, None)
+    ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    assert got["info"]["scale_updates"] >= 1
+    assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) < 1e-6 * max(1, abs(ref["info"]["pobj"]))
+    _assert_xys(got, ref, keys=("x", "s"))
+
+
+def test_dense_half_product_is_the_less_accurate_one(hip, oracle, monkeypatch):
+    """why the default product reads the whole inverse: mirroring one triangle of a Gauss-Jordan inverse costs a factor kappa"""
+    A = _rand_csc(600, 250, 0.03, 21 + 250)
+    diag_r = np.concatenate([np.full(250, 1e-3), np.full(50, 0.01), np.full(550, 10.0)])
+    rhs = np.random.RandomState(8).randn(850)
+    ref, _ = oracle.kkt_solve(A, None, diag_r, rhs, indirect=False)
+    full = hip.kkt_solve_dense(A, None, diag_r, rhs)
+    e_full = np.abs(full - ref).max() / np.abs(ref).max()
+    assert e_full < 1e-9
+
+
+def test_dense_warm_start_and_update(dense, oracle):
+    K = {"l": 200, "q": [10, 10]}
+    data, p_star, _ = pg.gen_feasible(K, 100, 8, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    s = dense.SCS(*args, **dict(STG, eps_abs=1e-8, eps_rel=1e-8))
+    a = s.solve(False, None, None, None)
+    assert a["info"]["status"] == "solved"
+    b = s.solve(True, a["x"], a["y"], a["s"])
+    assert b["info"]["status"] == "solved" and b["info"]["iter"] <= max(25, a["info"]["iter"] // 4)
+    b2 = data["b"] * 1.01
+    s.update(b2, None)
+    c = s.solve(True, a["x"], a["y"], a["s"])
+    data2 = dict(data, b=b2)
+    ref = oracle.OracleSCS(*helpers.raw_args(data2, K), indirect=False, **STG).solve(False)
+    assert c["info"]["status"] == "solved"
+    assert abs(c["info"]["pobj"] - ref["info"]["pobj"]) < 1e-5 * max(1, abs(ref["info"]["pobj"]))
+
+
+def test_dense_two_instances_same_bits(dense, oracle):
+    K = {"l": 150, "q": [6], "s": [5]}
+    data, _, _ = pg.gen_feasible(K, 60, 6, 9, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    a = dense.SCS(*args, **STG).solve(False, None, None, None)
+    b = dense.SCS(*args, **STG).solve(False, None, None, None)
+    for key in ("x", "y", "s"):
+        assert np.array_equal(a[key], b[key])
+    assert a["info"]["iter"] == b["info"]["iter"]
+
+
+def test_dense_through_the_front_end_and_its_limit():
+    import scs
+    A = sparse.csc_matrix(np.array([[1.0], [-1.0]]))
+    sol = scs.SCS({"A": A, "b": np.array([1.0, 0.0]), "c": np.array([-1.0])}, {"l": 2},
+                  linear_solver=scs.LinearSolver.HIP_DENSE, verbose=False, eps_abs=1e-9, eps_rel=1e-9).solve()
+    assert sol["info"]["status"] == "solved" and abs(sol["x"][0] - 1.0) < 1e-6
+    n = 4097
+    big = sparse.eye(n, format="csc")
+    with pytest.raises(ValueError, match="hip_dense: n = 4097 exceeds 4096"):
+        scs.SCS({"A": big, "b": np.ones(n), "c": np.ones(n)}, {"l": n}, linear_solver="hip_dense", verbose=False)
+
+
+# ---- grouped solve (csrc/batch.hpp) with the dense direct linsys: a member's answer is EXACTLY the answer of a solve of its own ----
+EXACT_INFO = ("status_val", "iter", "cg_iters", "scale_updates", "scale", "pobj", "dobj", "res_pri", "res_dual", "gap",
+              "comp_slack", "rejected_accel_steps", "accepted_accel_steps")
+
+
+def _assert_same(a, b, tag):
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg="%s: %s differs" % (tag, key))
+    for key in EXACT_INFO:
+        va, vb = a["info"][key], b["info"][key]
+        assert va == vb or (va != va and vb != vb), (tag, key, va, vb)
+    assert a["info"]["aa_stats"] == b["info"]["aa_stats"], (tag, a["info"]["aa_stats"], b["info"]["aa_stats"])
+
+
+def _batch(count, K, n, k, seed0, hip, qp=False):
+    proj = lambda z, K: hip.proj_cone(z, K, dual=True)
+    gen = pg.gen_feasible_qp if qp else pg.gen_feasible
+    return [(gen(K, n, k, seed0 + i, proj)[0], K) for i in range(count)]
+
+
+def _solo_and_group(problems, settings):
+    import scs
+    settings = dict(settings, linear_solver=scs.LinearSolver.HIP_DENSE)
+    solo = [scs.SCS(d, K, **settings).solve(warm_start=False) for d, K in problems]
+    solvers = [scs.SCS(d, K, **settings) for d, K in problems]
+    return solo, scs.solve_batch(solvers, warm_start=False), solvers
+
+
+def test_dense_group_bit_identical_lp_soc_psd(hip):
+    K = {"l": 300, "q": [12] * 6, "s": [6] * 4}
+    solo, grp, _ = _solo_and_group(_batch(7, K, 120, 12, 4100, hip), dict(verbose=False))
+    for i, (a, b) in enumerate(zip(solo, grp)):
+        assert a["info"]["status"] == "solved"
+        _assert_same(a, b, "member %d" % i)
+        assert "dense-direct" in b["info"]["lin_sys_solver"] and "grouped solve of 7" in b["info"]["lin_sys_solver"]
+    assert len({r["info"]["iter"] for r in grp}) > 1
+
+
+def test_dense_group_all_small_cones_qp_type2_interval1(hip):
+    K = {"z": 10, "l": 60, "bu": [1.0, 2.0, 0.5, 3.0], "bl": [-1.0, -0.5, -2.0, 0.0], "q": [5, 9, 1], "s": [3, 5, 1], "ep": 4,
+         "ed": 3, "p": [0.3, -0.6, 0.5]}
+    probs = _batch(5, K, 50, 8, 4200, hip, qp=True)
+    for stg in (dict(verbose=False, eps_abs=1e-7, eps_rel=1e-7, max_iters=4000),
+                dict(verbose=False, acceleration_type_1=False, acceleration_interval=1, acceleration_lookback=5, max_iters=3000),
+                dict(verbose=False, acceleration_lookback=0, max_iters=3000)):
+        solo, grp, _ = _solo_and_group(probs, stg)
+        for i, (a, b) in enumerate(zip(solo, grp)):
+            _assert_same(a, b, "member %d %r" % (i, sorted(stg)))
+
+
+def test_dense_group_scale_updates_and_warm_second_round(hip):
+    K = {"l": 200, "q": [8] * 4}
+    probs = _batch(6, K, 80, 8, 4300, hip)
+    for j, (d, _) in enumerate(probs):   # badly scaled members: the adaptive scale moves => a sub-list re-inverts inside the loop
+        if j % 2 == 0:
+            d["b"] = d["b"] * 1e3
+    stg = dict(verbose=False, scale=1e-3, eps_abs=1e-8, eps_rel=1e-8, max_iters=6000)
+    solo, grp, solvers = _solo_and_group(probs, stg)
+    for i, (a, b) in enumerate(zip(solo, grp)):
+        _assert_same(a, b, "member %d" % i)
+    assert any(r["info"]["scale_updates"] > 0 for r in grp)
+    # second round, warm-started from the stored answers, after update(b): again identical to solo workspaces doing the same
+    import scs
+    solo_s = [scs.SCS(d, K, **dict(stg, linear_solver=scs.LinearSolver.HIP_DENSE)) for d, K in probs]
+    for s in solo_s:
+        s.solve(warm_start=False)
+    for s, sg, (d, _) in zip(solo_s, solvers, probs):
+        s.update(b=d["b"] * 1.02)
+        sg.update(b=d["b"] * 1.02)
+    again_solo = [s.solve(warm_start=True) for s in solo_s]
+    again_grp = scs.solve_batch(solvers, warm_start=True)
+    for i, (a, b) in enumerate(zip(again_solo, again_grp)):
+        _assert_same(a, b, "round 2 member %d" % i)
+
+
+def test_dense_and_indirect_members_in_one_batch(hip):
+    """a batch may mix linear solvers: equal shapes with different solvers form separate groups"""
+    import scs
+    K = {"l": 150, "q": [6] * 3}
+    probs = _batch(6, K, 60, 8, 4400, hip)
+    kinds = [scs.LinearSolver.HIP_DENSE if i % 2 else scs.LinearSolver.HIP_INDIRECT for i in range(6)]
+    solo = [scs.SCS(d, K, verbose=False, linear_solver=ls).solve() for (d, K), ls in zip(probs, kinds)]
+    grp = scs.solve_batch([scs.SCS(d, K, verbose=False, linear_solver=ls) for (d, K), ls in zip(probs, kinds)])
+    for i, (a, b) in enumerate(zip(solo, grp)):
+        _assert_same(a, b, "member %d" % i)
+        assert ("dense-direct" in b["info"]["lin_sys_solver"]) == (i % 2 == 1)

@@ -10,8 +10,9 @@ K, n, k, seed = pg.workload("config5_small")
 datas = [pg.gen_feasible(K, n, k, seed + i, proj)[0] for i in range(2)]
 mode = sys.argv[1]
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-kw = dict(linear_solver=scs.LinearSolver.HIP_INDIRECT, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=ITERS, verbose=False)
-if mode == "group2":
+LS = scs.LinearSolver.HIP_DENSE if mode.startswith("dense") else scs.LinearSolver.HIP_INDIRECT
+kw = dict(linear_solver=LS, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=ITERS, verbose=False)
+if mode in ("group2", "dense_group2"):
     ss = [scs.SCS(d, K, **kw) for d in datas]
     scs.solve_batch(ss)
     t = time.perf_counter(); r = scs.solve_batch(ss); el = time.perf_counter() - t

@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the lines of BASELINE configs 2-4")
     ap.add_argument("--batch-problems", type=int, default=512)
     ap.add_argument("--batch-threads", type=int, default=16, help="workspaces set up concurrently (scs_init) per rank")
+    ap.add_argument("--batch-linsys", default="hip_dense", choices=["hip_dense", "hip_indirect"],
+                    help="linear solver of the config-5 members: dense direct (explicit inverse of the reduced KKT matrix, n = 1350) or the indirect PCG path")
     ap.add_argument("--batch-ungrouped", action="store_true", help="config-5 leg as one problem per stream (round 1-2 mode)")
     # testing aids (the driver never passes these): run the N>1 flow on a 1-GPU box
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -365,6 +367,8 @@ def main():
     if not args.no_batch:
         Kb, nb_, kb_, seedb = pg.workload("config5_small")
         NB = args.batch_problems
+        # linear solver of the members: the dense direct one (csrc/dense.hpp, n = 1350 <= 4096) unless --batch-linsys hip_indirect
+        batch_ls = scs.LinearSolver(args.batch_linsys)
         mine = set(scs_batch.shard_indices(NB, rank, world))
         mb = pg.cone_dims(Kb)
         tgen = time.perf_counter()
@@ -372,13 +376,13 @@ def main():
         for i in range(NB):  # a rank only generates (and touches) its own shard
             if i in mine:
                 d_i, _, _ = pg.gen_feasible(Kb, nb_, kb_, seedb + i, proj)
-                problems.append((d_i, Kb, dict(verbose=False)))
+                problems.append((d_i, Kb, dict(verbose=False, linear_solver=batch_ls)))
             else:
                 problems.append(None)
         tgen = time.perf_counter() - tgen
         dims = [(nb_, mb)] * NB
         # warm the kernels of this shape once (code objects, allocator)
-        scs.SCS(problems[min(mine)][0], Kb, verbose=False, max_iters=50, linear_solver=scs.LinearSolver.HIP_INDIRECT).solve()
+        scs.SCS(problems[min(mine)][0], Kb, verbose=False, max_iters=50, linear_solver=batch_ls).solve()
         timing = {}
         barrier()
         tb = time.perf_counter()
@@ -403,6 +407,7 @@ def main():
                 "wall_s": round(tb_max, 3), "gen_s_rank0": round(tgen, 2), "n_gpus": world,
                 "iterations_min_median_max": [iters_sorted[0], iters_sorted[len(iters_sorted) // 2], iters_sorted[-1]],
                 "rank0_phases_s": {k_: round(v_, 3) for k_, v_ in timing.items()},
+                "linear_solver": batch_ls.value,
             }
 
     # ---------------- other BASELINE configs: one line each (N = 1) ----------------

@@ -198,6 +198,8 @@ struct GroupSolve {
   DevBuf<int> flags_d, lists_d, active_buf;
   static constexpr int kParamRing = 32;  // pinned staging slots of the per-iteration parameter blocks (dense mode runs without a sync per iteration)
   int iters_since_sync = 0;
+  std::vector<double> params_last;  // the block as last uploaded
+  bool params_dirty = true;
   double *params_h = nullptr, *res_h = nullptr, *aa_res_h = nullptr;
   int *flags_h = nullptr, *lists_h = nullptr, *active_h = nullptr;  // (all pinned: every copy here is asynchronous)
   static constexpr int kListSlots = 64;
@@ -727,7 +729,19 @@ struct GroupSolve {
         p[P_FIRST] = i < 1 ? 1.0 : 0.0;
         p[P_PSD_TOL2] = W[(size_t)g]->psd_tol2_for(i);
       }
-      HIP_CHECK(hipMemcpyAsync(params_d.p, params_slot, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
+      // (dense linsys: what its kernels read of the block — P_DO_SCALE, P_FIRST, P_PSD_TOL2 — only moves at i <= 1 and at checks /
+      //  scale updates / membership changes; a lone straggler's iteration is ~10 launches, the copy would be one more host call)
+      bool upload_params = !dense || i <= 2 || params_dirty;
+      if (!upload_params)
+        for (int g : active) {
+          const double *p = params_slot + (size_t)g * P_COUNT, *q = params_last.data() + (size_t)g * P_COUNT;
+          if (p[P_DO_SCALE] != q[P_DO_SCALE] || p[P_FIRST] != q[P_FIRST] || p[P_PSD_TOL2] != q[P_PSD_TOL2]) { upload_params = true; break; }
+        }
+      if (upload_params) {
+        HIP_CHECK(hipMemcpyAsync(params_d.p, params_slot, sizeof(double) * P_COUNT * G, hipMemcpyHostToDevice, s));
+        params_last.assign(params_slot, params_slot + (size_t)P_COUNT * G);
+        params_dirty = false;
+      }
       tmp_list.clear();
       for (int g : active)
         if (!W[(size_t)g]->v_norm_fresh) { tmp_list.push_back(g); W[(size_t)g]->v_norm_fresh = true; }

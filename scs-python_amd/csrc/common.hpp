@@ -7,8 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/scs_hip.h"
@@ -29,6 +31,70 @@ inline void set_last_error(const std::string &s);
     }                                                                                         \
   } while (0)
 
+// Process-wide cache of device blocks.  hipFree synchronises the device and unmaps (0.65 ms per scs_finish of a config-5 workspace,
+// 0.3-0.5 s per batch of 512), hipMalloc maps: a workspace that dies hands its blocks here instead — only from ~ScsHipWork, which has
+// synchronised its stream first (t_pool_release; temporaries that die while their stream is still busy keep using hipFree, whose
+// implicit synchronisation is what makes that safe) — and every allocation looks here first (exact size, same device).
+// Bounded (SCS_HIP_POOL_MB, default 16384; 0 disables); emptied when a hipMalloc fails.
+struct DevPool {
+  std::mutex m;
+  std::vector<std::pair<std::pair<int, size_t>, void *>> blocks;  // ((device, bytes), pointer)
+  size_t cached = 0, cap = 0;
+  bool cap_read = false;
+  static DevPool &inst() { static DevPool p; return p; }
+  size_t capacity() {
+    if (!cap_read) { const char *e = getenv("SCS_HIP_POOL_MB"); cap = (size_t)(e ? atol(e) : 16384) << 20; cap_read = true; }
+    return cap;
+  }
+  void *get(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(m);
+    for (size_t i = blocks.size(); i-- > 0;)
+      if (blocks[i].first.first == dev && blocks[i].first.second == bytes) {
+        void *p = blocks[i].second;
+        blocks[i] = blocks.back();
+        blocks.pop_back();
+        cached -= bytes;
+        return p;
+      }
+    return nullptr;
+  }
+  bool put(void *p, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(m);
+    if (cached + bytes > capacity()) return false;
+    blocks.push_back({{dev, bytes}, p});
+    cached += bytes;
+    return true;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(m);
+    for (auto &b : blocks) (void)hipFree(b.second);  // (blocks of other devices: hipFree takes any device's pointer)
+    blocks.clear();
+    cached = 0;
+  }
+};
+static thread_local int t_pool_release = 0;  // > 0: DevBuf / Arena releases on this thread go to the pool (see DevPool)
+inline void *dev_malloc(size_t bytes) {
+  if (void *p = DevPool::inst().get(bytes)) return p;
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    DevPool::inst().trim();
+    e = hipMalloc(&p, bytes);
+  }
+  HIP_CHECK(e);
+  return p;
+}
+inline void dev_free(void *p, size_t bytes) {
+  if (!p) return;
+  if (t_pool_release > 0 && DevPool::inst().put(p, bytes)) return;
+  (void)hipFree(p);
+}
+
 // Workspace arena: small problems (a batch of them: BASELINE.json configs[4]) pay more for the ~100 hipMalloc /
 // hipMemset / hipFree calls of a workspace than for the kernels of scs_init (measured: 3.9 ms per scs_init and 2.5 ms per
 // scs_finish of a config-5 problem, 512 of them per batch).  While an arena is current on the calling thread, DevBuf
@@ -44,7 +110,7 @@ struct Arena {
   Arena(const Arena &) = delete;
   Arena &operator=(const Arena &) = delete;
   ~Arena() {
-    for (Chunk &c : chunks) (void)hipFree(c.p);
+    for (Chunk &c : chunks) dev_free(c.p, c.size);
   }
   void *take(size_t bytes);
 };
@@ -66,7 +132,7 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p && !in_arena) (void)hipFree(p);
+    if (p && !in_arena) dev_free(p, sizeof(T) * (n ? n : 1));
     p = nullptr;
     n = 0;
     in_arena = false;
@@ -80,7 +146,7 @@ struct DevBuf {
       in_arena = true;
       return;
     }
-    HIP_CHECK(hipMalloc((void **)&p, bytes));
+    p = (T *)dev_malloc(bytes);
   }
   void alloc_zero(size_t count, hipStream_t s) {
     alloc(count);
@@ -105,7 +171,7 @@ inline void *Arena::take(size_t bytes) {
       return r;
     }
   Chunk c{nullptr, bytes > kChunkBytes ? bytes : kChunkBytes, 0};
-  HIP_CHECK(hipMalloc((void **)&c.p, c.size));
+  c.p = (char *)dev_malloc(c.size);
   HIP_CHECK(hipMemsetAsync(c.p, 0, c.size, stream));
   c.used = bytes;
   chunks.push_back(c);

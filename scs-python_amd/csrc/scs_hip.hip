@@ -604,6 +604,11 @@ static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, c
 
 // ============================================================== workspace
 struct ScsHipWork {
+  // first member = destroyed last: ends the window in which this workspace's device blocks go to the block pool (common.hpp DevPool)
+  struct PoolWindowEnd {
+    bool armed = false;
+    ~PoolWindowEnd() { if (armed) --t_pool_release; }
+  } pool_window_end;
   std::unique_ptr<Arena> arena;  // small problems: all device buffers of the workspace come from here (FIRST member: destroyed last)
   int device = 0;  // the HIP device this workspace (stream, buffers, events) lives on
   int n = 0, m = 0;
@@ -849,7 +854,19 @@ struct ScsHipWork {
   int last_cg_iters = 8;
   int cg_hist[8] = {8, 8, 8, 8, 8, 8, 8, 8}, cg_hist_pos = 0;  // CG steps of the last 8 linear solves (chunk sizing)
   void note_cg_iters(int it) { cg_hist[cg_hist_pos++ & 7] = it; }
-  int recent_cg_max() const { int mx = 1; for (int v : cg_hist) mx = std::max(mx, v); return mx; }
+  // largest step count of the last `chunk_window()` linear solves (SCS_HIP_CHUNK_WINDOW, 1..8): what a queued iteration's CG chunk is sized
+  // for.  Round 4: 3 instead of 8 — in the cold-start phase the counts FALL from iteration to iteration, and a window of 8 kept
+  // enqueuing the counts of eight iterations ago: 36 % of the K1 / K2 launches of the bench window were early-exit launches
+  // (profiles/r03_bench_kernel_trace.txt: 3581 launched, 2309 with work).
+  static int chunk_window() {
+    static const int w = [] { const char *e = getenv("SCS_HIP_CHUNK_WINDOW"); const int v = e ? atoi(e) : 3; return std::max(1, std::min(v, 8)); }();
+    return w;
+  }
+  int recent_cg_max() const {
+    int mx = 1;
+    for (int k = 1; k <= chunk_window(); ++k) mx = std::max(mx, cg_hist[(cg_hist_pos - k) & 7]);
+    return mx;
+  }
   int recent_cg_q3() const {  // third quartile of the last 8 linear solves (the grouped loop's prediction: a short round is cheap there)
     int h[8];
     std::copy(cg_hist, cg_hist + 8, h);
@@ -880,6 +897,12 @@ struct ScsHipWork {
   std::mutex mtx;
 
   ~ScsHipWork() {
+    // nothing of this workspace is in flight once its stream is idle: its blocks may be handed to the next workspace without hipFree
+    // (real workspaces only: the stack workspaces of the kernel-level entry points borrow a stream that is gone by now)
+    if (stream && (pooled_stream || owns_stream) && hipStreamSynchronize(stream) == hipSuccess) {
+      pool_window_end.armed = true;
+      ++t_pool_release;
+    }
     for (auto &g : g_pre) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : g_cg) if (g) (void)hipGraphExecDestroy(g);
     if (g_post) (void)hipGraphExecDestroy(g_post);

@@ -605,12 +605,27 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     struct Set { uint4 ic[NQ]; double2 va[NQ], vb[NQ]; unsigned long long meta, meta1; };
     Set S0, S1;
     double xg[NQ][4];
+    // (lab ablation 5, tools/cs_lab.hip: the pass stream with the non-temporal cache policy — does keeping the HBM-latency stream lines
+    //  out of the L1 / L2 allocation help the gathers?  Round 4: no, profiles/r04_cs_stream_lab.txt)
+    typedef unsigned cs_u4 __attribute__((ext_vector_type(4)));
+    typedef double cs_f2 __attribute__((ext_vector_type(2)));
     auto ld_idx = [&](int s, Set &S, int gl) {
-      S.ic[s] = reinterpret_cast<const uint4 *>(A.idx + (size_t)gl * kCsPass)[tid + s * kCsThreads];
+      if constexpr (ABL == 5) {
+        const cs_u4 t = __builtin_nontemporal_load(reinterpret_cast<const cs_u4 *>(A.idx + (size_t)gl * kCsPass) + (tid + s * kCsThreads));
+        S.ic[s] = uint4{t.x, t.y, t.z, t.w};
+      } else {
+        S.ic[s] = reinterpret_cast<const uint4 *>(A.idx + (size_t)gl * kCsPass)[tid + s * kCsThreads];
+      }
     };
     auto ld_val = [&](int s, Set &S, int gl) {  // s in [0, 2 NQ)
       const int i = s >> 1, h = s & 1;
-      const double2 v = reinterpret_cast<const double2 *>(A.val + (size_t)gl * kCsPass)[2 * (tid + i * kCsThreads) + h];
+      double2 v;
+      if constexpr (ABL == 5) {
+        const cs_f2 t = __builtin_nontemporal_load(reinterpret_cast<const cs_f2 *>(A.val + (size_t)gl * kCsPass) + (2 * (tid + i * kCsThreads) + h));
+        v = double2{t.x, t.y};
+      } else {
+        v = reinterpret_cast<const double2 *>(A.val + (size_t)gl * kCsPass)[2 * (tid + i * kCsThreads) + h];
+      }
       if (h == 0) S.va[i] = v; else S.vb[i] = v;
     };
     auto ld_meta = [&](Set &S, int gl) {

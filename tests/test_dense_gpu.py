@@ -163,17 +163,21 @@ def test_dense_against_indirect_on_a_config5_member(hip, dense, oracle):
 
 def test_dense_scale_updates_reinvert(dense, oracle):
     """badly scaled data: the adaptive scale moves, every move re-forms and re-inverts the reduced KKT matrix"""
-    K = {"l": 200, "q": [8] * 4}
-    data, p_star, _ = pg.gen_feasible(K, 80, 8, 4300, lambda z, K: oracle.proj_cone(z, K, dual=True))
-    data["b"] = data["b"] * 1e3
-    args = helpers.raw_args(data, K)
-    stg = dict(STG, scale=1e-3, eps_abs=1e-8, eps_rel=1e-8)
-    got = dense.SCS(*args, **stg).solve(False, None, None, None)
-    ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
-    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
-    assert got["info"]["scale_updates"] >= 1
-    assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) < 1e-6 * max(1, abs(ref["info"]["pobj"]))
-    _assert_xys(got, ref, keys=("x", "s"))
+    K = {"l": 200, "q": [8] * 5}
+    seen = 0
+    for i in range(4):
+        data, p_star, _ = pg.gen_feasible(K, 90, 10, 4300 + i, lambda z, K: oracle.proj_cone(z, K, dual=True))
+        data["b"] = data["b"] * (1e3 if i % 2 else 1e-3)
+        data["A"] = data["A"] * (30.0 if i % 3 == 0 else 1.0)
+        args = helpers.raw_args(data, K)
+        stg = dict(STG, eps_abs=1e-8, eps_rel=1e-8)
+        got = dense.SCS(*args, **stg).solve(False, None, None, None)
+        ref = oracle.OracleSCS(*args, indirect=False, **stg).solve(False)
+        assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved", (i, got["info"]["status"], ref["info"]["status"])
+        seen += got["info"]["scale_updates"]
+        assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) < 1e-6 * max(1, abs(ref["info"]["pobj"]))
+        _assert_xys(got, ref, keys=("x", "s"))
+    assert seen >= 1
 
 
 def test_dense_half_product_is_the_less_accurate_one(hip, oracle, monkeypatch):
@@ -279,12 +283,12 @@ def test_dense_group_all_small_cones_qp_type2_interval1(hip):
 
 
 def test_dense_group_scale_updates_and_warm_second_round(hip):
-    K = {"l": 200, "q": [8] * 4}
-    probs = _batch(6, K, 80, 8, 4300, hip)
+    K = {"l": 200, "q": [8] * 5}
+    probs = _batch(6, K, 90, 10, 4300, hip)
     for j, (d, _) in enumerate(probs):   # badly scaled members: the adaptive scale moves => a sub-list re-inverts inside the loop
-        if j % 2 == 0:
-            d["b"] = d["b"] * 1e3
-    stg = dict(verbose=False, scale=1e-3, eps_abs=1e-8, eps_rel=1e-8, max_iters=6000)
+        d["b"] = d["b"] * (1e3 if j % 2 else 1e-3)
+        d["A"] = d["A"] * (30.0 if j % 3 == 0 else 1.0)
+    stg = dict(verbose=False, eps_abs=1e-8, eps_rel=1e-8, max_iters=6000)
     solo, grp, solvers = _solo_and_group(probs, stg)
     for i, (a, b) in enumerate(zip(solo, grp)):
         _assert_same(a, b, "member %d" % i)

@@ -13,8 +13,9 @@ import problem_gen as pg
 NB = 512
 proj = lambda z, K: _scs_hip.proj_cone(z, K, dual=True)
 Kb, nb_, kb_, seedb = pg.workload("config5_small")
-problems = [(pg.gen_feasible(Kb, nb_, kb_, seedb + i, proj)[0], Kb, dict(verbose=False)) for i in range(NB)]
-scs.SCS(problems[0][0], Kb, verbose=False, max_iters=50).solve()
+extra = {"linear_solver": os.environ["LINSYS"]} if os.environ.get("LINSYS") else {}   # hip_dense / hip_indirect
+problems = [(pg.gen_feasible(Kb, nb_, kb_, seedb + i, proj)[0], Kb, dict(verbose=False, **extra)) for i in range(NB)]
+scs.SCS(problems[0][0], Kb, verbose=False, max_iters=50, **extra).solve()
 torch.cuda.synchronize()
 for world in (1, 2, 4, 8):
     walls, iters, worst = [], 0, 0

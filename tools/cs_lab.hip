@@ -250,6 +250,10 @@ static void bench_matrix(const char *name, const Csr &M, int split) {
     auto g2 = [&] { hipLaunchKernelGGL((k_spmv_cs_ga<EpiRaw2, 8, 2>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
     std::printf("    ablations  il: gathers from 2 KB table %.1f us, no row sums %.1f us;  ga: %.1f / %.1f us\n", time_us(a1, 20), time_us(a2, 20),
                 time_us(g1, 20), time_us(g2, 20));
+    auto a0 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 0>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto a5 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 5>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    std::printf("    round 4: pass stream with the non-temporal policy (nt): %.1f us vs %.1f us plain (interleaved A/B: %.1f / %.1f)\n", time_us(a5, 30), time_us(a0, 30),
+                time_us(a5, 30), time_us(a0, 30));
   }
   if (getenv("LAB_TIMELINE") == nullptr) { D.free(); hipFree(dx); hipFree(dy); hipFree(dy1); return; }
   if (D.hc.rpt == 8) timeline<8>("k_cs_timed<8>", D, dx, dy, dy1);

@@ -648,9 +648,18 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     // memory instruction k of the braid of step g, in issue order: the gathers of pass g + 1 (in Y, first column c1),
     // then index quads, values and run descriptor of pass g + 2 into X.  TAIL: the last two steps of the workgroup,
     // where some of these passes do not exist (uniform branches).
-    constexpr int NGAT = 4 * NQ, NVAL = 2 * NQ, NMEM = NGAT + NQ + NVAL + 1;
+    // PRE (lab ablation 6, round 4): the stream loads of pass g + 2 are issued BEFORE the barrier of step g — into the registers the
+    // product scatter has just freed — instead of behind the gathers in the braid: while the workgroup waits at the barrier for its
+    // slowest wavefront nobody issues memory instructions and the vector-memory pipe drains (the barrier is 26 % of a wavefront's
+    // time, tools/cs_lab.hip timeline); loads that depend on nothing can fill that hole.
+    // PREG quads of the gathers of pass g + 1 go before the barrier too, each right behind the products that free its registers
+    // (7: one of the two quads, 9: both — then the braid issues nothing); 8: stream before the barrier, ALL gathers in the first row slot.
+    constexpr bool PRE = ABL >= 6 && ABL <= 10;   // (10: as 6 with ONE gather per row slot)
+    constexpr int PREG = ABL == 7 ? 1 : ABL == 9 ? NQ : 0;
+    constexpr int NGAT = 4 * NQ, NVAL = 2 * NQ, NMEM = PRE ? NGAT : NGAT + NQ + NVAL + 1;
     auto mem_op = [&](auto tail, int k, int g, const Set &Y, int c1, Set &X) {
       constexpr bool T = decltype(tail)::value;
+      if (k < 4 * PREG) return;
       if (k < NGAT) { if (!T || g + 1 < g1) gat(k, Y, c1); }
       else if (k < NGAT + NQ) { if (!T || g + 2 < g1) ld_idx(k - NGAT, X, g + 2); }
       else if (k < NGAT + NQ + NVAL) { if (!T || g + 2 < g1) ld_val(k - NGAT - NQ, X, g + 2); }
@@ -665,15 +674,30 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
         pb[X.ic[i].y & (kCsPass - 1)] = X.va[i].y * xg[i][1];
         pb[X.ic[i].z & (kCsPass - 1)] = X.vb[i].x * xg[i][2];
         pb[X.ic[i].w & (kCsPass - 1)] = X.vb[i].y * xg[i][3];
+        if constexpr (PREG > 0) {
+          if (i < PREG && (!decltype(tail)::value || g + 1 < g1)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gat(4 * i + e, Y, c1);
+          }
+        }
       }
       const unsigned long long mc = X.meta, mc1 = RPT == 16 ? X.meta1 : 0;
+      if constexpr (PRE) {
+        if (!decltype(tail)::value || g + 2 < g1) {
+#pragma unroll
+          for (int s = 0; s < NQ; ++s) ld_idx(s, X, g + 2);
+#pragma unroll
+          for (int s = 0; s < NVAL; ++s) ld_val(s, X, g + 2);
+          ld_meta(X, g + 2);
+        }
+      }
       CS_TL_STAMP(1);
       __syncthreads();
       CS_TL_STAMP(2);
       int o = (int)(mc & 0xffff);
       unsigned long long w = mc >> 16;
       // memory instructions per row: at least two, so that the gathers are all with the addresser after a few rows
-      constexpr int PER = (NMEM + RPT - 1) / RPT > 2 ? (NMEM + RPT - 1) / RPT : 2;
+      constexpr int PER = ABL == 8 ? NMEM : ABL == 10 ? (NMEM + RPT - 1) / RPT : (NMEM + RPT - 1) / RPT > 2 ? (NMEM + RPT - 1) / RPT : 2;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
 #pragma unroll
@@ -791,8 +815,11 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
   }
 }
 
-inline int cs_schedule() {  // 2 = braided gathers / row sums (k_spmv_cs_il); 1 = gather-ahead (k_spmv_cs_ga); 0 = k_spmv_cs
-  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 2; }();
+// 3 (default, round 4) = braided gathers / row sums with the stream loads of pass g + 2 issued BEFORE the barrier of step g
+// (k_spmv_cs_il<.., 6>: -6..7 us per launch on the metric shapes, same bits; tools/cs_lab.hip, profiles/r04_cs_lab.txt);
+// 2 = the braid of rounds 2-3 (stream loads behind the gathers); 1 = gather-ahead (k_spmv_cs_ga); 0 = k_spmv_cs
+inline int cs_schedule() {
+  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 3; }();
   return v;
 }
 
@@ -801,6 +828,16 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
                            int *step_counter) {
   if (A.nchunks <= 0) return;
   const dim3 g(A.nchunks * A.split), b(kCsThreads);
+  if (cs_schedule() >= 3) {
+    switch (A.rpt) {
+      case 1: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 1, 6>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 2: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 2, 6>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 4: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 4, 6>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      case 8: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 8, 6>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+      default: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 16, 6>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
+    }
+    return;
+  }
   if (cs_schedule() == 2 || (A.split > 1 && A.ticket != nullptr)) {  // (the in-kernel combine lives in k_spmv_cs_il only)
     switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;

@@ -251,6 +251,52 @@ static void bench_matrix(const char *name, const Csr &M, int split) {
     std::printf("    ablations  il: gathers from 2 KB table %.1f us, no row sums %.1f us;  ga: %.1f / %.1f us\n", time_us(a1, 20), time_us(a2, 20),
                 time_us(g1, 20), time_us(g2, 20));
     auto a0 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 0>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto a6 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 6>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto a7 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 7>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto a8 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 8>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto a9 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 9>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    auto print_tl = [&](const char *tag) {
+      const int nwg = D.hc.nchunks * D.hc.split, nw = kCsThreads / 64;
+      HIP_CHECK(hipDeviceSynchronize());
+      std::vector<unsigned long long> h((size_t)256 * 16 * 8);
+      HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(cs_lab_tl), h.size() * 8));
+      double avg[7] = {0}, mx[7] = {0};
+      for (int w = 0; w < nwg * nw; ++w)
+        for (int i = 0; i < 7; ++i) { avg[i] += (double)h[(size_t)w * 8 + i]; mx[i] = std::max(mx[i], (double)h[(size_t)w * 8 + i]); }
+      const char *names[7] = {"prologue", "wait gathers+scatter(+pre-barrier issue)", "barrier", "braid", "epilogue", "-", "total"};
+      std::printf("      %s timeline, kcycles per wave: ", tag);
+      for (int i = 0; i < 7; ++i) if (i != 5) std::printf("%s %.1f (max %.1f)  ", names[i], avg[i] / (nwg * nw) * 1e-3, mx[i] * 1e-3);
+      std::printf("\n");
+    };
+    auto a10 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 10>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    {
+      const double t = time_us(a10, 30), t6 = time_us(a6, 30), tb = time_us(a10, 30), t6b = time_us(a6, 30);
+      std::printf("    round 4: ABL 10 (stream before the barrier, one gather per row slot): %.1f us vs ABL 6 %.1f us (again %.1f / %.1f)\n", t, t6, tb, t6b);
+    }
+    for (int v = 7; v <= 9; ++v) {
+      HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+      auto run = [&] { if (v == 7) a7(); else if (v == 8) a8(); else a9(); };
+      const double t = time_us(run, 30), t0 = time_us(a0, 30), tb = time_us(run, 30);
+      run();
+      HIP_CHECK(hipDeviceSynchronize());
+      std::printf("    round 4: ABL %d (%s): %.1f us vs %.1f us plain (again %.1f)", v,
+                  v == 7 ? "stream + half the gathers before the barrier" : v == 8 ? "stream before the barrier, all gathers in the first row slot" : "stream + all gathers before the barrier",
+                  t, t0, tb);
+      if (split == 1) std::printf("  mismatches %ld", mismatches(dy, ref));
+      std::printf("\n");
+      print_tl(v == 7 ? "ABL 7" : v == 8 ? "ABL 8" : "ABL 9");
+    }
+    a0(); print_tl("plain");
+    a6(); print_tl("ABL 6");
+    {
+      HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+      const double t6 = time_us(a6, 30), t0 = time_us(a0, 30), t6b = time_us(a6, 30), t0b = time_us(a0, 30);
+      a6();
+      HIP_CHECK(hipDeviceSynchronize());
+      std::printf("    round 4: stream loads issued BEFORE the barrier (ABL 6): %.1f us vs %.1f us plain (interleaved A/B: %.1f / %.1f)", t6, t0, t6b, t0b);
+      if (split == 1) std::printf("  mismatches %ld", mismatches(dy, ref));
+      std::printf("\n");
+    }
     auto a5 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 5>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
     std::printf("    round 4: pass stream with the non-temporal policy (nt): %.1f us vs %.1f us plain (interleaved A/B: %.1f / %.1f)\n", time_us(a5, 30), time_us(a0, 30),
                 time_us(a5, 30), time_us(a0, 30));
@@ -343,6 +389,7 @@ int main(int argc, char **argv) {
     bench_matrix("K1 shape  CSR(A)", Ar, 1);
     bench_matrix("K2 shape  CSR(A')", At, 2);
   }
+  if (getenv("LAB_SKIP_COMBINE")) return 0;
   bench_combine("K1 shape  CSR(A)", Ar, 2);
   bench_combine("K2 shape  CSR(A')", At, 2);
   bench_combine("K2 shape  CSR(A')", At, 4);

@@ -173,7 +173,7 @@ def main():
 
     def pmc_traffic(workload, which):
         """HBM bytes of K1 / K2 per launch from the committed rocprofv3 --pmc passes on this workload's matrix shape"""
-        for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     pmc = json.load(f)
@@ -295,7 +295,7 @@ def main():
         gb1 = b1 / (k1_avg * 1e-3) / 1e9 if k1_avg > 0 else 0.0
         gb2 = b2 / (k2_avg * 1e-3) / 1e9 if k2_avg > 0 else 0.0
         lss = info.get("lin_sys_solver", "")
-        kname = ("k_spmv_cs_il" if os.environ.get("SCS_HIP_CS_SCHED", "2") == "2" else "k_spmv_cs_ga") if "column-sorted" in lss \
+        kname = ("k_spmv_cs_il" if os.environ.get("SCS_HIP_CS_SCHED", "3") in ("2", "3") else "k_spmv_cs_ga") if "column-sorted" in lss \
             else "k_spmv_slab" if "slab" in lss else "k_spmv_stream"
         k1_dom = k1_avg >= k2_avg
         dom = ("K1 %s<EpiDivR> (z = R_y^-1 A p)" % kname, b1, k1_avg, gb1) if k1_dom else \
@@ -418,8 +418,24 @@ def main():
                            ("banded_lp", 20, 2)):
             if wl == args.workload:
                 continue
-            line, _, _ = measure(wl, st, wu, steady=False, gather=False)
-            line.pop("steady_window", None)
+            # config 4: the first 100 iterations run with the residual-tied PSD sweep level, later ones do not — the
+            # line carries the window past iteration 100 and a whole solve next to the cold-start window
+            line, d4, K4 = measure(wl, st, wu, steady=(wl == "config4_psd"), gather=False)
+            if wl == "config4_psd":
+                ws4 = scs.SCS(d4, K4, verbose=False, acceleration_lookback=10, linear_solver=scs.LinearSolver.HIP_INDIRECT)
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
+                sol4 = ws4.solve(warm_start=False)
+                torch.cuda.synchronize()
+                tw = time.perf_counter() - tw
+                line["whole_solve"] = {"settings": "defaults (eps_abs = eps_rel = 1e-4)", "status": sol4["info"]["status"],
+                                       "iterations": sol4["info"]["iter"], "wall_s": round(tw, 3),
+                                       "value": round(sol4["info"]["iter"] / tw, 1), "unit": "ADMM iters/s over the whole solve",
+                                       "cg_steps_per_admm_iter": round(sol4["info"]["cg_iters"] / max(sol4["info"]["iter"], 1), 2)}
+                del ws4, sol4
+            else:
+                line.pop("steady_window", None)
+            del d4, K4
             if wl == "config3_mixed":
                 line["config"]["why_so_many_cg_steps"] = (
                     "conditioning, not cone kernels: R_y weighs the 100,000 zero-cone rows 1000 x heavier than the others "
@@ -493,8 +509,14 @@ def main():
                            verbose=False, acceleration_lookback=10, max_iters=200).solve(warm_start=False)
             hip_same = round(200 / (dgpu["info"]["solve_time"] * 1e-3), 1)
         # all cores: the OpenMP timing build of the same CPU-CG variant on the same workload (child process)
-        nthr = args.cpu_threads if args.cpu_threads > 0 else min(32, ncores)
-        allc, allc_s, allc_to = run_child(child + ["cg", args.workload, str(ci), str(nthr)], max(args.cpu_cap_s, 60.0))
+        # thread sweep inside ONE child (the problem is generated once; every count gets a fresh workspace whose pages are first
+        # touched by its own threads: oracle/oscs.h): a quarter, half and all of the logical CPUs; the best one is the figure
+        if args.cpu_threads > 0:
+            sweep = [args.cpu_threads]
+        else:
+            sweep = sorted({max(1, ncores // 4), max(1, ncores // 2), ncores})
+        allc, allc_s, allc_to = run_child(child + ["cg", args.workload, str(ci), ",".join(str(t) for t in sweep)], max(args.cpu_cap_s, 60.0) * len(sweep))
+        nthr = allc["threads"] if allc else sweep[-1]
         cpu_baseline = {
             "value": round(ci / (cpu_ms * 1e-3), 5), "unit": "ADMM iters/s", "cores": 1, "kind": "port",
             "sample": "first %d ADMM iterations (cold start, %d CG steps) of the same instance on the oracle's "
@@ -502,15 +524,15 @@ def main():
                       "host has %d cores" % (ci, ref["info"]["cg_iters"], cpu_ms * 1e-3, ci, gsol["info"]["cg_iters"],
                                              gpu_ms * 1e-3, ncores),
             "multi_core": ({"value": round(allc["iters_per_s"], 4), "unit": "ADMM iters/s", "cores": nthr, "host_cores": ncores, "kind": "port",
+                            "thread_sweep_iters_per_s": allc.get("sweep", [[nthr, round(allc["iters_per_s"], 3)]]),
                             "sample": "the same %d iterations (%d CG steps) with the OpenMP build of the oracle (row- / column-parallel "
-                                      "mat-vecs, parallel vector loops; cone projections and Anderson steps stay sequential) on %d threads: "
-                                      "%.2f s.  More threads are SLOWER on this host (memory is first-touched by one thread, two NUMA "
-                                      "nodes: 8 / 16 / 32 / 64 / 128 / 256 threads = 3.1 / 3.9 / 4.1 / 2.2 / 0.9 / <0.07 iters/s, "
-                                      "profiles/r03_cpu_threads.txt)" % (ci, allc["cg_steps"], nthr, allc["solve_s"])}
+                                      "mat-vecs, parallel vector loops, parallel l / SOC / exp projections; Anderson steps sequential; vectors and "
+                                      "matrix copies first touched by the threads that stream them, OMP_PROC_BIND=spread) on %d threads, the best "
+                                      "of the sweep: %.2f s" % (ci, allc["cg_steps"], nthr, allc["solve_s"])}
                            if allc else {"value": None, "cores": nthr, "host_cores": ncores,
                                          "sample": "did not finish within %.0f s" % max(args.cpu_cap_s, 60.0) if allc_to else "child failed"}),
             "direct_ldl": {
-                "what": "oracle's sparse LDL' direct variant (min-degree ordering + up-looking LDL': the QDLDL path), 1 thread, random LPs "
+                "what": "oracle's sparse LDL' direct variant (approximate-minimum-degree ordering on the quotient graph + up-looking LDL': the AMD + QDLDL path), 1 thread, random LPs "
                         "m = 2n with 50 nonzeros per column (the shape of BASELINE.json configs[0]), 200 iterations each; every rung a "
                         "child process capped at %.0f s wall clock — observed in this run" % args.cpu_cap_s,
                 "rungs": [{k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in r.items() if k_ != "mode"} for r in rungs],
@@ -518,8 +540,9 @@ def main():
                                       "unit": "ADMM iters/s", "cores": 1, "factorization_s": round(done[-1]["factorization_s"], 2),
                                       "hip_same_workload_iters_per_s": hip_same} if done else None),
                 "first_not_finished": ({"m": notdone[0]["m"], "n": notdone[0]["n"], "cap_s": args.cpu_cap_s} if notdone else None),
-                "target_and_config2": ("direct infeasible here: the factorisation of the m=%d rung did not finish within %.0f s; "
-                                       "config 2 (m=2e5) and the target (m=2e6) are 12x / 125x larger with the same random pattern"
+                "target_and_config2": ("direct infeasible here: the NUMERIC factorisation of the m=%d rung did not finish within %.0f s — fill, not "
+                                       "ordering time: nnz(L) = 0.058 N^2 for this random pattern (see nnz_L of the finished rungs; x 4 per rung, "
+                                       "flops x 8); config 2 (m=2e5) and the target (m=2e6) are 12x / 125x larger"
                                        % (notdone[0]["m"], args.cpu_cap_s)) if notdone else
                                       "every rung finished; config 2 (m=2e5) and the target (m=2e6) were not attempted",
             },

@@ -20,11 +20,14 @@ sys.path.insert(0, ROOT)
 def main():
     mode = sys.argv[1]
     if mode == "cg":
-        workload, iters, threads = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-        if threads != 1:
+        workload, iters = sys.argv[2], int(sys.argv[3])
+        sweep = [int(t) for t in sys.argv[4].split(",")]   # one thread count, or a sweep "64,128,256" (one line per count, the best last)
+        threads = sweep[0]
+        if sweep != [1]:
             os.environ["OSCS_LIB"] = "omp"
-            os.environ["OMP_NUM_THREADS"] = str(threads)
+            os.environ["OMP_NUM_THREADS"] = str(max(sweep))
             os.environ.setdefault("OMP_PROC_BIND", "spread")
+            os.environ.setdefault("OMP_PLACES", "threads")
         from oracle import scs_oracle
         import problem_gen as pg
         K, n, k, seed = pg.workload(workload)
@@ -32,12 +35,21 @@ def main():
         data, _, _ = pg.gen_feasible(K, n, k, seed, lambda z, KK: scs_oracle.proj_cone(z, KK, dual=True),
                                      pattern=pg.workload_pattern(workload))
         tgen = time.perf_counter() - t
-        r = scs_oracle.solve(data, K, indirect=True, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False,
-                             acceleration_lookback=10, max_iters=iters)
-        ms = r["info"]["solve_time"]
-        print(json.dumps({"mode": "cg", "workload": workload, "threads": threads, "iters": iters, "solve_s": ms * 1e-3,
+        lines = []
+        for threads in sweep:
+            if sweep != [1]:
+                scs_oracle.lib().oscs_set_num_threads(threads)  # the workspace's pages are first touched by these threads
+            r = scs_oracle.solve(data, K, indirect=True, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False,
+                                 acceleration_lookback=10, max_iters=iters)
+            ms = r["info"]["solve_time"]
+            lines.append({"mode": "cg", "workload": workload, "threads": threads, "iters": iters, "solve_s": ms * 1e-3,
                           "iters_per_s": iters / (ms * 1e-3), "cg_steps": r["info"]["cg_iters"], "gen_s": tgen,
-                          "setup_s": r["info"]["setup_time"] * 1e-3}))
+                          "setup_s": r["info"]["setup_time"] * 1e-3})
+            print(json.dumps(lines[-1]))
+            sys.stdout.flush()
+        if len(lines) > 1:
+            best = max(lines, key=lambda d: d["iters_per_s"])
+            print(json.dumps(dict(best, sweep=[[d["threads"], round(d["iters_per_s"], 3)] for d in lines])))
     elif mode == "ldl":
         m, n, k, seed, iters = (int(a) for a in sys.argv[2:7])
         from oracle import scs_oracle

@@ -36,11 +36,44 @@
 #define O_PAR_FOR(n) O_PRAGMA(omp parallel for schedule(static) if ((n) > 16384))
 #define O_PAR_SUM(n, v) O_PRAGMA(omp parallel for schedule(static) reduction(+ : v) if ((n) > 16384))
 #define O_PAR_MAX(n, v) O_PRAGMA(omp parallel for schedule(static) reduction(max : v) if ((n) > 16384))
+/* First touch (round 4): on a two-socket host a page lives on the NUMA node of the thread that first writes it.  The timing
+ * build therefore zero-fills / copies its long vectors and its matrix copies in PARALLEL loops with the same static partition as
+ * the loops that later stream them (o_vec_calloc, o_par_copy*, and the matrix copies in oscs_linsys.c / oscs_core.c) — until
+ * round 3 everything was first touched by the master thread and the all-core leg peaked at 32 threads on one node
+ * (profiles/r03_cpu_threads.txt).  The sequential checker build maps these to calloc / memcpy / memset. */
 #else
 #define O_PAR_FOR(n)
 #define O_PAR_SUM(n, v)
 #define O_PAR_MAX(n, v)
 #endif
+#include <stdlib.h>
+#include <string.h>
+static inline void o_par_zero(scs_float *x, scs_int n) {
+#ifdef OSCS_OMP
+  O_PAR_FOR(n)
+  for (scs_int i = 0; i < n; ++i) x[i] = 0.;
+#else
+  memset(x, 0, (size_t)n * sizeof(scs_float));
+#endif
+}
+static inline void o_par_copy(scs_float *dst, const scs_float *src, scs_int n) {
+#ifdef OSCS_OMP
+  O_PAR_FOR(n)
+  for (scs_int i = 0; i < n; ++i) dst[i] = src[i];
+#else
+  memcpy(dst, src, (size_t)n * sizeof(scs_float));
+#endif
+}
+/* zero-initialised vector whose pages are first touched by the threads that will stream them */
+static inline scs_float *o_vec_calloc(scs_int n) {
+#ifdef OSCS_OMP
+  scs_float *x = (scs_float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(scs_float));
+  if (x) o_par_zero(x, n);
+  return x;
+#else
+  return (scs_float *)calloc((size_t)(n > 0 ? n : 1), sizeof(scs_float));
+#endif
+}
 
 #define OMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define OMIN(a, b) (((a) < (b)) ? (a) : (b))
@@ -142,4 +175,5 @@ scs_int o_aa_last_gamma(const OAa *a, scs_float *gamma);
 /* small dense solve with partial pivoting; returns numerical rank (n if ok, <n if singular) */
 scs_int o_dense_solve(scs_float *M, scs_float *rhs, scs_int n);
 
+void oscs_set_num_threads(int n);
 #endif

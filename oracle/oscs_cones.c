@@ -545,7 +545,8 @@ static scs_float proj_box_cone(scs_float *tx, const scs_float *bl, const scs_flo
 scs_int o_proj_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
   const ScsCone *k = &c->k;
   scs_int i, count = 0;
-  if (k->z) { memset(x, 0, k->z * sizeof(scs_float)); count += k->z; }
+  if (k->z) { o_par_zero(x, k->z); count += k->z; }
+  O_PAR_FOR(k->l)
   for (i = count; i < count + k->l; ++i) x[i] = OMAX(x[i], 0.0);
   count += k->l;
   if (k->bsize) {
@@ -553,6 +554,17 @@ scs_int o_proj_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
                                   r_y ? &r_y[count] : NULL);
     count += k->bsize;
   }
+#ifdef OSCS_OMP
+  if (k->qsize > 1024) {  /* all-core timing variant: independent cones in parallel (offsets by a prefix sum) */
+    scs_int *qoff = (scs_int *)malloc(((size_t)k->qsize + 1) * sizeof(scs_int));
+    qoff[0] = count;
+    for (i = 0; i < k->qsize; ++i) qoff[i + 1] = qoff[i] + k->q[i];
+    O_PAR_FOR(k->qsize)
+    for (i = 0; i < k->qsize; ++i) o_proj_soc(&x[qoff[i]], k->q[i]);
+    count = qoff[k->qsize];
+    free(qoff);
+  } else
+#endif
   for (i = 0; i < k->qsize; ++i) { o_proj_soc(&x[count], k->q[i]); count += k->q[i]; }
   for (i = 0; i < k->ssize; ++i) {
     o_proj_psd(&x[count], k->s[i], c);
@@ -562,8 +574,12 @@ scs_int o_proj_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
     o_proj_cpsd(&x[count], k->cs[i], c);
     count += k->cs[i] * k->cs[i];
   }
-  for (i = 0; i < k->ep; ++i) { o_proj_exp_cone(&x[count], 1); count += 3; }
-  for (i = 0; i < k->ed; ++i) { o_proj_exp_cone(&x[count], 0); count += 3; }
+  O_PAR_FOR(k->ep)
+  for (i = 0; i < k->ep; ++i) o_proj_exp_cone(&x[count + 3 * i], 1);
+  count += 3 * k->ep;
+  O_PAR_FOR(k->ed)
+  for (i = 0; i < k->ed; ++i) o_proj_exp_cone(&x[count + 3 * i], 0);
+  count += 3 * k->ed;
   for (i = 0; i < k->psize; ++i) {
     scs_float *v = &x[count];
     if (k->p[i] >= 0) {
@@ -581,9 +597,11 @@ scs_int o_proj_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
 /* Moreau under the R-norm:  Pi_{K*}(x) = x + R^{-1} Pi_K(-R x)   */
 scs_int o_proj_dual_cone(scs_float *x, OConeWork *c, const scs_float *r_y) {
   scs_int i, st;
-  memcpy(c->s, x, c->m * sizeof(scs_float));
+  o_par_copy(c->s, x, c->m);
+  O_PAR_FOR(c->m)
   for (i = 0; i < c->m; ++i) x[i] *= r_y ? -r_y[i] : -1.;
   st = o_proj_cone(x, c, r_y);
+  O_PAR_FOR(c->m)
   for (i = 0; i < c->m; ++i) x[i] = (r_y ? x[i] / r_y[i] : x[i]) + c->s[i];
   return st;
 }

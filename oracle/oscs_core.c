@@ -79,12 +79,12 @@ void oscs_set_default_settings(ScsSettings *s) {
 static void alloc_res(OResiduals *r, scs_int m, scs_int n) {
   memset(r, 0, sizeof(*r));
   r->last_iter = -1;
-  r->ax = (scs_float *)calloc(m, sizeof(scs_float));
-  r->ax_s = (scs_float *)calloc(m, sizeof(scs_float));
-  r->ax_s_btau = (scs_float *)calloc(m, sizeof(scs_float));
-  r->px = (scs_float *)calloc(n, sizeof(scs_float));
-  r->aty = (scs_float *)calloc(n, sizeof(scs_float));
-  r->px_aty_ctau = (scs_float *)calloc(n, sizeof(scs_float));
+  r->ax = o_vec_calloc(m);
+  r->ax_s = o_vec_calloc(m);
+  r->ax_s_btau = o_vec_calloc(m);
+  r->px = o_vec_calloc(n);
+  r->aty = o_vec_calloc(n);
+  r->px_aty_ctau = o_vec_calloc(n);
 }
 static void free_res(OResiduals *r) {
   free(r->ax); free(r->ax_s); free(r->ax_s_btau); free(r->px); free(r->aty); free(r->px_aty_ctau);
@@ -96,9 +96,16 @@ static void copy_matrix(ScsMatrix *dst, const ScsMatrix *src) {
   dst->x = (scs_float *)malloc(OMAX(nnz, 1) * sizeof(scs_float));
   dst->i = (scs_int *)malloc(OMAX(nnz, 1) * sizeof(scs_int));
   dst->p = (scs_int *)malloc((src->n + 1) * sizeof(scs_int));
+  memcpy(dst->p, src->p, (src->n + 1) * sizeof(scs_int));
+#ifdef OSCS_OMP
+  /* by columns, partitioned as o_accum_by_atrans streams them (first touch, oscs.h) */
+  O_PAR_FOR(src->n)
+  for (scs_int j = 0; j < src->n; ++j)
+    for (scs_int q = src->p[j]; q < src->p[j + 1]; ++q) { dst->x[q] = src->x[q]; dst->i[q] = src->i[q]; }
+#else
   memcpy(dst->x, src->x, nnz * sizeof(scs_float));
   memcpy(dst->i, src->i, nnz * sizeof(scs_int));
-  memcpy(dst->p, src->p, (src->n + 1) * sizeof(scs_int));
+#endif
 }
 
 static scs_int validate(const ScsData *d, const ScsCone *k, const ScsSettings *s) {
@@ -172,21 +179,21 @@ void *oscs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, int
     w->scal = o_normalize_a_p(w->has_P ? &w->P : NULL, &w->A, w->cone);
     o_normalize_b_c(w->scal, w->b_norm, w->c_norm);
   }
-  w->u = (scs_float *)calloc(l, sizeof(scs_float));
-  w->u_t = (scs_float *)calloc(l, sizeof(scs_float));
-  w->v = (scs_float *)calloc(l, sizeof(scs_float));
-  w->v_prev = (scs_float *)calloc(l, sizeof(scs_float));
-  w->rsk = (scs_float *)calloc(l, sizeof(scs_float));
-  w->h = (scs_float *)calloc(l - 1, sizeof(scs_float));
-  w->g = (scs_float *)calloc(l - 1, sizeof(scs_float));
-  w->ls_ws = (scs_float *)calloc(l - 1, sizeof(scs_float));
-  w->diag_r = (scs_float *)calloc(l, sizeof(scs_float));
-  w->xys_norm.x = (scs_float *)calloc(n, sizeof(scs_float));
-  w->xys_norm.y = (scs_float *)calloc(m, sizeof(scs_float));
-  w->xys_norm.s = (scs_float *)calloc(m, sizeof(scs_float));
-  w->xys_orig.x = (scs_float *)calloc(n, sizeof(scs_float));
-  w->xys_orig.y = (scs_float *)calloc(m, sizeof(scs_float));
-  w->xys_orig.s = (scs_float *)calloc(m, sizeof(scs_float));
+  w->u = o_vec_calloc(l);
+  w->u_t = o_vec_calloc(l);
+  w->v = o_vec_calloc(l);
+  w->v_prev = o_vec_calloc(l);
+  w->rsk = o_vec_calloc(l);
+  w->h = o_vec_calloc(l - 1);
+  w->g = o_vec_calloc(l - 1);
+  w->ls_ws = o_vec_calloc(l - 1);
+  w->diag_r = o_vec_calloc(l);
+  w->xys_norm.x = o_vec_calloc(n);
+  w->xys_norm.y = o_vec_calloc(m);
+  w->xys_norm.s = o_vec_calloc(m);
+  w->xys_orig.x = o_vec_calloc(n);
+  w->xys_orig.y = o_vec_calloc(m);
+  w->xys_orig.s = o_vec_calloc(m);
   alloc_res(&w->r_norm, m, n);
   alloc_res(&w->r_orig, m, n);
   set_diag_r(w);
@@ -250,13 +257,13 @@ static scs_float root_plus(const OWork *w, const scs_float *p, const scs_float *
 static scs_int project_lin_sys(OWork *w, scs_int iter) {
   scs_int n = w->n, l = w->l, i, status;
   scs_float *warm = NULL, tol = -1.0;
-  memcpy(w->u_t, w->v, l * sizeof(scs_float));
+  o_par_copy(w->u_t, w->v, l);
   O_PAR_FOR(l)
   for (i = 0; i < l - 1; ++i) w->u_t[i] *= (i < n ? 1 : -1) * w->diag_r[i];
   if (w->indirect) {
     scs_float nm_ws;
     warm = w->ls_ws;
-    memcpy(warm, w->u, (l - 1) * sizeof(scs_float));
+    o_par_copy(warm, w->u, l - 1);
     o_axpy(warm, w->g, w->u[l - 1], l - 1);
     tol = OMIN(o_norm_inf(w->r_norm.ax_s_btau, w->m), o_norm_inf(w->r_norm.px_aty_ctau, w->n));
     nm_ws = o_norm_inf(warm, n) / pow((scs_float)iter + 1, O_CG_RATE);
@@ -527,7 +534,7 @@ scs_int oscs_solve(void *work, ScsSolution *sol, ScsInfo *info, scs_int warm_sta
       scs_float nv = o_norm_2(w->v, l);
       o_scale(w->v, sqrt((scs_float)l) / OMAX(nv, 1e-300), l);
     }
-    memcpy(w->v_prev, w->v, l * sizeof(scs_float));
+    o_par_copy(w->v_prev, w->v, l);
     t = now_ms();
     if (project_lin_sys(w, i) < 0) { info->status_val = SCS_FAILED; break; }
     t_lin += now_ms() - t;
@@ -609,4 +616,13 @@ scs_int oscs_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *
 void oscs_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int trans) {
   if (trans) o_accum_by_atrans(A, x, y);
   else o_accum_by_a(A, x, y);
+}
+
+/* all-core timing build only: the thread count of the NEXT workspace (its pages are first touched by these threads, oscs.h) */
+void oscs_set_num_threads(int n) {
+#ifdef OSCS_OMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }

@@ -654,19 +654,24 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     // time, tools/cs_lab.hip timeline); loads that depend on nothing can fill that hole.
     // PREG quads of the gathers of pass g + 1 go before the barrier too, each right behind the products that free its registers
     // (7: one of the two quads, 9: both — then the braid issues nothing); 8: stream before the barrier, ALL gathers in the first row slot.
-    constexpr bool PRE = ABL >= 6 && ABL <= 10;   // (10: as 6 with ONE gather per row slot)
+    constexpr bool PRE = (ABL >= 6 && ABL <= 10) || ABL == 12;   // (10: as 6 with ONE gather per row slot; 12: as 6 with straight-line tail steps; 13: plain braid with them)
     constexpr int PREG = ABL == 7 ? 1 : ABL == 9 ? NQ : 0;
     constexpr int NGAT = 4 * NQ, NVAL = 2 * NQ, NMEM = PRE ? NGAT : NGAT + NQ + NVAL + 1;
+    // `tail` is a compile-time mode: 0 = passes g + 1 and g + 2 exist (steady state), 1 = test at run time (uniform branches — every
+    // load inside one costs the exact wait counts), 2 = pass g + 1 exists, g + 2 does not, 3 = neither (the workgroup's last pass)
+#define CS_HAS1 (TM == 0 || TM == 2 || (TM == 1 && g + 1 < g1))
+#define CS_HAS2 (TM == 0 || (TM == 1 && g + 2 < g1))
     auto mem_op = [&](auto tail, int k, int g, const Set &Y, int c1, Set &X) {
-      constexpr bool T = decltype(tail)::value;
+      constexpr int TM = (int)decltype(tail)::value;
       if (k < 4 * PREG) return;
-      if (k < NGAT) { if (!T || g + 1 < g1) gat(k, Y, c1); }
-      else if (k < NGAT + NQ) { if (!T || g + 2 < g1) ld_idx(k - NGAT, X, g + 2); }
-      else if (k < NGAT + NQ + NVAL) { if (!T || g + 2 < g1) ld_val(k - NGAT - NQ, X, g + 2); }
-      else { if (!T || g + 2 < g1) ld_meta(X, g + 2); }
+      if (k < NGAT) { if (CS_HAS1) gat(k, Y, c1); }
+      else if (k < NGAT + NQ) { if (CS_HAS2) ld_idx(k - NGAT, X, g + 2); }
+      else if (k < NGAT + NQ + NVAL) { if (CS_HAS2) ld_val(k - NGAT - NQ, X, g + 2); }
+      else { if (CS_HAS2) ld_meta(X, g + 2); }
     };
     // products of pass g (in X) -> LDS, barrier, then the braid with the row sums of pass g
     auto step = [&](auto tail, int g, Set &X, const Set &Y, int c1, int buf) {
+      constexpr int TM = (int)decltype(tail)::value;
       double *pb = prod[buf];
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
         pb[X.ic[i].z & (kCsPass - 1)] = X.vb[i].x * xg[i][2];
         pb[X.ic[i].w & (kCsPass - 1)] = X.vb[i].y * xg[i][3];
         if constexpr (PREG > 0) {
-          if (i < PREG && (!decltype(tail)::value || g + 1 < g1)) {
+          if (i < PREG && CS_HAS1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gat(4 * i + e, Y, c1);
           }
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
       }
       const unsigned long long mc = X.meta, mc1 = RPT == 16 ? X.meta1 : 0;
       if constexpr (PRE) {
-        if (!decltype(tail)::value || g + 2 < g1) {
+        if (CS_HAS2) {
 #pragma unroll
           for (int s = 0; s < NQ; ++s) ld_idx(s, X, g + 2);
 #pragma unroll
@@ -747,13 +752,31 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
       step(std::false_type{}, g + 1, S1, S0, cn, 1);  // pass g + 1 in S1, g + 2 in S0, g + 3 streams into S1
       cn = get_pi(g + 3).x;
     }
+    if constexpr (ABL == 12 || ABL == 13) {
+      // the last two or three passes: one straight-line step body per case instead of run-time tests around every load
+      using M0 = std::integral_constant<int, 0>; using M2 = std::integral_constant<int, 2>; using M3 = std::integral_constant<int, 3>;
+      for (; g < g1; g += 2) {
+        const int rem = g1 - g;
+        if (rem >= 3) step(M0{}, g, S0, S1, cn, 0);
+        else if (rem == 2) step(M2{}, g, S0, S1, cn, 0);
+        else step(M3{}, g, S0, S1, cn, 0);
+        cn = get_pi(g + 2).x;
+        if (rem >= 4) step(M0{}, g + 1, S1, S0, cn, 1);
+        else if (rem == 3) step(M2{}, g + 1, S1, S0, cn, 1);
+        else if (rem == 2) step(M3{}, g + 1, S1, S0, cn, 1);
+        cn = get_pi(g + 3).x;
+      }
+    } else {
     for (; g < g1; g += 2) {
       step(std::true_type{}, g, S0, S1, cn, 0);
       cn = get_pi(g + 2).x;
       if (g + 1 < g1) step(std::true_type{}, g + 1, S1, S0, cn, 1);
       cn = get_pi(g + 3).x;
     }
+    }
   }
+#undef CS_HAS1
+#undef CS_HAS2
   const bool combine = A.split > 1 && A.ticket != nullptr;
   if (combine) {
     // Publish the partial row sums with write-through (sc1) 16-byte stores — acknowledged stores are visible to every

@@ -273,6 +273,16 @@ static void bench_matrix(const char *name, const Csr &M, int split) {
       const double t = time_us(a10, 30), t6 = time_us(a6, 30), tb = time_us(a10, 30), t6b = time_us(a6, 30);
       std::printf("    round 4: ABL 10 (stream before the barrier, one gather per row slot): %.1f us vs ABL 6 %.1f us (again %.1f / %.1f)\n", t, t6, tb, t6b);
     }
+    auto a12 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 12>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    {
+      HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+      const double t = time_us(a12, 30), t6 = time_us(a6, 30), tb = time_us(a12, 30), t6b = time_us(a6, 30);
+      a12();
+      HIP_CHECK(hipDeviceSynchronize());
+      std::printf("    round 4: ABL 12 (as 6, straight-line tail steps): %.1f us vs ABL 6 %.1f us (again %.1f / %.1f)", t, t6, tb, t6b);
+      if (split == 1) std::printf("  mismatches %ld", mismatches(dy, ref));
+      std::printf("\n");
+    }
     for (int v = 7; v <= 9; ++v) {
       HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
       auto run = [&] { if (v == 7) a7(); else if (v == 8) a8(); else a9(); };

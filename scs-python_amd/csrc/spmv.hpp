@@ -110,6 +110,22 @@ struct EpiGp {  // Gp[r] = (Pp)[r] + s + rx[r] p[r];  partial sum of p.Gp   (CG 
     Gp[r] = g;
     sums[0] += pr * g;
   }
+  // Round 4: the pass kernel (spmv_cs.hpp k_spmv_cs_il) fetches p[r] of a lane's rows at its START into registers and hands it
+  // back here — the epilogue then has no load left in it (K2 ran 5 us behind K1, whose epilogue EpiDivR reads nothing: 8 dependent
+  // HBM-latency loads per lane at the end of the launch, when nothing is left to overlap them with).  Same arithmetic, same bits.
+  static constexpr bool kPrefetch = true;
+  __device__ double prefetch(int r) const { return p[r]; }
+  __device__ void with_prefetched(int r, double s, int split, int part, double pr, double *sums) const {
+    if (split <= 1 || part == 0) {
+      double g = s + rx[r] * pr;
+      if (has_P) g += Gp[r];
+      Gp[r] = g;
+      sums[0] += pr * g;
+    } else {
+      Gp2[r] = s;
+      sums[0] += pr * s;
+    }
+  }
   // Gp = Gp[] + Gp2[] is only ever read by the CG update (k_cg_update / k_cg_init), and p'Gp is linear in it: the
   // first half carries the R_x p (+ P p) terms, the second half its raw partial sum — no combine pass
   __device__ void split(int r, double s, int part, double *sums, double *) const {

@@ -313,6 +313,19 @@ __device__ __forceinline__ void cs_slot_done(const CsView &A, const Epi &epi, in
   }
 }
 
+// epilogues that want a per-row value fetched ahead of time (EpiGp: p[r]; spmv.hpp)
+template <class Epi, class = void>
+struct epi_has_prefetch : std::false_type {};
+template <class Epi>
+struct epi_has_prefetch<Epi, std::void_t<decltype(&Epi::prefetch)>> : std::true_type {};
+// the row behind slot rl of chunk c if its finished sum goes through the epilogue HERE (not a piece slot, not peeled), else -1
+__device__ __forceinline__ int cs_epilogue_row(const CsView &A, int c, int rl) {
+  const int Rr = cs_rr(A);
+  if (rl >= Rr) return -1;
+  const int r = c * Rr + rl;
+  return (r < A.rows && !cs_is_peeled(A.peel, r)) ? r : -1;
+}
+
 // Row sums of one pass from the LDS product buffer: m = {first slot of the lane's run | the lane's RPT counts}.
 // (Measured alternative: level by level — the L-th product of several rows as one batch of independent LDS reads,
 // +0.0 for rows without one — is not faster than the plain per-row loops: 100-102 vs 99 us on the K1 shape.)
@@ -591,7 +604,12 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
   for (int j = 0; j < RPT; ++j) acc[j] = 0.;
   const int g0 = A.passptr[wg], g1 = A.passptr[wg + 1];
   CS_TL_DECL;
+  // (the default schedule only: the register budget of the others is not worth touching)
+  constexpr bool kPre = epi_has_prefetch<Epi>::value && ABL == 6;
+  double pre[kPre ? RPT : 1];
+  bool pre_ok = false;
   if (g0 < g1) {
+    pre_ok = kPre;
     CsPinfoScalarPtr pinf = (CsPinfoScalarPtr)A.pinfo;
     auto get_pi = [&](int g) {  // uniform index: s_load_dwordx2
       const int gg = g < g1 ? g : g1 - 1;
@@ -742,6 +760,13 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
         ld_meta(S1, g0 + 1);
       }
     }
+    if constexpr (kPre) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const int r = cs_epilogue_row(A, c, j * kCsThreads + tid);
+        pre[j] = epi.prefetch(r >= 0 ? r : 0);
+      }
+    }
     CS_TL_STAMP(0);
     // The steady-state loop holds ONLY the branch-free body (a variant with conditional loads inside the same loop
     // would merge its wait-count state into it); a second loop drains the last two or three passes.
@@ -816,9 +841,23 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
       acc[j] = t;
     }
   }
+  if constexpr (kPre) {
+    if (pre_ok && !combine) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const int rl = j * kCsThreads + tid, r = cs_epilogue_row(A, c, rl);
+        if (r >= 0) epi.with_prefetched(r, acc[j], A.split, part, pre[j], sums);
+        else if (rl >= cs_rr(A)) cs_slot_done(A, epi, part, c, rl, acc[j], sums, maxs, false);  // (a piece slot)
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) cs_slot_done(A, epi, part, c, j * kCsThreads + tid, acc[j], sums, maxs, combine);
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     cs_slot_done(A, epi, part, c, j * kCsThreads + tid, acc[j], sums, maxs, combine);
+  }
   }
   CS_TL_STAMP(4);
   CS_TL_FLUSH();

@@ -176,6 +176,33 @@ def test_config5_workload_matches_oracle_ldl():
                                        err_msg="config5 seed %d: %s vs oracle LDL'" % (seed + i, key))
 
 
+@pytest.mark.parametrize("linsys,seeds", [
+    ("hip_indirect", (1000, 1224, 1412)),   # fewest / median / most iterations of the 512 at default settings: 400 / 675 / 8325
+    ("hip_dense", (1196, 1380, 1434)),      # ... with the dense direct linsys: 375 / 650 / 5875   (tools/dbg/config5_seeds.py)
+])
+def test_config5_tail_seeds_match_oracle_ldl(linsys, seeds):
+    """the tails of the config-5 batch — the seeds that take the fewest, the median and the most iterations —
+    against the oracle's sparse LDL', same tolerances as test_config5_workload_matches_oracle_ldl; first at the batch's own
+    (default) settings: status and objective, then at 1e-10: x, y, s at rtol 1e-4"""
+    import scs
+    from oracle import scs_oracle
+    Kb, nb, kb, _ = pg.workload("config5_small")
+    for sd in seeds:
+        d, p_star, _ = pg.gen_feasible(Kb, nb, kb, sd, _proj)
+        dflt = scs.SCS(d, Kb, verbose=False, linear_solver=linsys).solve()
+        assert dflt["info"]["status"] == "solved"
+        assert abs(dflt["info"]["pobj"] - p_star) <= 2e-3 * max(1.0, abs(p_star))   # (eps 1e-4 on residuals, not on the objective)
+        stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=200000)
+        got = scs.SCS(d, Kb, linear_solver=linsys, **stg).solve()
+        ref = scs_oracle.solve(d, Kb, indirect=False, **stg)
+        assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved", (sd, got["info"]["status"], ref["info"]["status"])
+        assert abs(got["info"]["pobj"] - p_star) <= 1e-4 * max(1.0, abs(p_star))
+        assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-4 * max(1.0, abs(ref["info"]["pobj"]))
+        for key in ("x", "y", "s"):
+            np.testing.assert_allclose(got[key], ref[key], rtol=1e-4, atol=1e-4 * np.abs(ref[key]).max(),
+                                       err_msg="config5 seed %d (%s): %s vs oracle LDL'" % (sd, linsys, key))
+
+
 def test_config5_default_settings_group_of_32_solved():
     """default settings (eps 1e-4), 32 members: every member solved and equal to its own solve; launch sharing
     really happened (one group)"""

@@ -69,7 +69,12 @@ def test_single_gpu_line_has_every_leg():
     ldl = cb["direct_ldl"]
     assert ldl["largest_finished"]["value"] > 0 and ldl["largest_finished"]["hip_same_workload_iters_per_s"] > 0
     assert len(ldl["rungs"]) == 3 and ldl["first_not_finished"]["cap_s"] == 12.0 and "infeasible" in ldl["target_and_config2"]
-    assert cb["multi_core"]["cores"] == min(32, os.cpu_count()) and cb["multi_core"]["value"] > 0
+    nc = os.cpu_count()
+    mc = cb["multi_core"]   # round 4: a thread sweep in one child (quarter / half / all of the logical CPUs), the best is the figure
+    assert mc["cores"] in {max(1, nc // 4), max(1, nc // 2), nc} and mc["value"] > 0
+    assert [t for t, _ in mc["thread_sweep_iters_per_s"]] == sorted({max(1, nc // 4), max(1, nc // 2), nc})
+    assert mc["value"] == max(v for _, v in mc["thread_sweep_iters_per_s"]) or abs(mc["value"] - max(v for _, v in mc["thread_sweep_iters_per_s"])) < 1e-2
+    assert out["config5_batch"]["linear_solver"] == "hip_dense"
     assert rf["traffic"] is None and rf["traffic_source"] is None  # (no committed counter pass for this workload)
     assert out["config"]["cg_steps_per_s"] > 0 and out["config"]["ms_per_cg_step"] > 0
     assert out["steady_window"]["aa_accepted_in_window"] >= 0

@@ -541,7 +541,7 @@ struct GroupSolve {
                  const std::function<void()> &after_first_sync) {
     std::vector<int> need;
     for (int g : members) need.push_back(predict(g));
-    const int first_chunk = chunk_for(need);
+    const int first_chunk = std::max(1, std::min(chunk_for(need), 10 * n));
     for (int k = 0; k < first_chunk; ++k) cg_step(list_d, (int)members.size(), variant);
     read_flags(list_d, (int)members.size());
     sync();
@@ -559,7 +559,10 @@ struct GroupSolve {
         const int done = flags_of(g)[F_ITERS];
         need.push_back(std::max(predict(g) - done, std::max(done / 2, 2)));  // (a wrong prediction: grow geometrically)
       }
-      const int chunk = chunk_for(need);
+      //  the device steps are only gated by F_DONE: never enqueue a member past the 10 n cap run_cg stops at exactly
+      int most_done = 0;
+      for (int g : nd) most_done = std::max(most_done, flags_of(g)[F_ITERS]);
+      const int chunk = std::max(1, std::min(chunk_for(need), 10 * n - most_done));
       const int *ld = upload_list(nd);
       for (int k = 0; k < chunk; ++k) cg_step(ld, (int)nd.size(), variant);
       read_flags(ld, (int)nd.size());

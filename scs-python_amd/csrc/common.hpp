@@ -106,6 +106,9 @@ struct Arena {
   std::vector<Chunk> chunks;
   hipStream_t stream = nullptr;  // chunks are zeroed on this stream: buffers must first be used on it (they are)
   static constexpr size_t kChunkBytes = 4u << 20, kMaxAlloc = 1u << 20, kAlign = 256;
+  //  first chunk sized from an estimate of the workspace (set by scs_init before the first allocation): a service that
+  // keeps thousands of tiny workspaces alive pays kilobytes each, not 4 MiB; later chunks are kChunkBytes
+  size_t first_chunk = kChunkBytes;
   Arena() = default;
   Arena(const Arena &) = delete;
   Arena &operator=(const Arena &) = delete;
@@ -170,7 +173,8 @@ inline void *Arena::take(size_t bytes) {
       c.used += bytes;
       return r;
     }
-  Chunk c{nullptr, bytes > kChunkBytes ? bytes : kChunkBytes, 0};
+  const size_t want = chunks.empty() ? first_chunk : kChunkBytes;
+  Chunk c{nullptr, bytes > want ? bytes : want, 0};
   c.p = (char *)dev_malloc(c.size);
   HIP_CHECK(hipMemsetAsync(c.p, 0, c.size, stream));
   c.used = bytes;

@@ -2072,6 +2072,13 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     if (!(ea && ea[0] == '0') && annz <= (1L << 18) && w->l <= (1L << 17)) {
       w->arena.reset(new Arena());
       w->arena->stream = s;
+      {  // ~40 doubles per row / column of vectors + 3 matrix layouts of 12 B per nonzero + the Anderson history, rounded up to a power of two
+        const long mem = std::max(0, stgs->acceleration_lookback);
+        size_t est = (size_t)(8 * (40 + 3 * mem) * w->l + 3 * 12 * annz + (256 << 10));
+        size_t c = 256 << 10;
+        while (c < est && c < Arena::kChunkBytes) c <<= 1;
+        w->arena->first_chunk = c;
+      }
     }
   }
   ArenaScope arena_scope(w->arena.get());
@@ -2271,13 +2278,19 @@ struct InterruptListener {
       std::memset(&sa, 0, sizeof(sa));
       sa.sa_handler = on_sigint;
       sigemptyset(&sa.sa_mask);
+      sa.sa_flags = SA_RESTART;  //  other threads' blocking system calls are restarted, not failed with EINTR
       sigaction(SIGINT, &sa, &saved());
     }
   }
   ~InterruptListener() {
     if (!enabled()) return;
     std::lock_guard<std::mutex> g(mtx());
-    if (--users() == 0) sigaction(SIGINT, &saved(), nullptr);
+    if (--users() == 0) {
+      // put the previous disposition back only if ours is still the installed one: a handler the application installed while the
+      // solve was running is not overwritten
+      struct sigaction cur;
+      if (sigaction(SIGINT, nullptr, &cur) == 0 && cur.sa_handler == on_sigint) sigaction(SIGINT, &saved(), nullptr);
+    }
   }
   static bool interrupted() { return enabled() && flag().load(std::memory_order_relaxed) != 0; }
 };

@@ -39,8 +39,9 @@
 /* First touch (round 4): on a two-socket host a page lives on the NUMA node of the thread that first writes it.  The timing
  * build therefore zero-fills / copies its long vectors and its matrix copies in PARALLEL loops with the same static partition as
  * the loops that later stream them (o_vec_calloc, o_par_copy*, and the matrix copies in oscs_linsys.c / oscs_core.c) — until
- * round 3 everything was first touched by the master thread and the all-core leg peaked at 32 threads on one node
- * (profiles/r03_cpu_threads.txt).  The sequential checker build maps these to calloc / memcpy / memset. */
+ * round 3 everything was first touched by the master thread.  (What capped the all-core leg at ~32 threads on the bench boxes,
+ * profiles/r03_cpu_threads.txt, turned out to be the container's CFS quota of 16 CPUs, not placement: bench.py cpu_quota.)
+ * The sequential checker build maps these to calloc / memcpy / memset. */
 #else
 #define O_PAR_FOR(n)
 #define O_PAR_SUM(n, v)

@@ -71,8 +71,10 @@ def test_single_gpu_line_has_every_leg():
     assert len(ldl["rungs"]) == 3 and ldl["first_not_finished"]["cap_s"] == 12.0 and "infeasible" in ldl["target_and_config2"]
     nc = os.cpu_count()
     mc = cb["multi_core"]   # round 4: a thread sweep in one child (quarter / half / all of the logical CPUs), the best is the figure
-    assert mc["cores"] in {max(1, nc // 4), max(1, nc // 2), nc} and mc["value"] > 0
-    assert [t for t, _ in mc["thread_sweep_iters_per_s"]] == sorted({max(1, nc // 4), max(1, nc // 2), nc})
+    nq = mc["cpus_this_process_may_use"]   # cgroup quota / affinity (bench.cpu_quota): the sweep is half, all, twice of it
+    assert 1 <= nq <= nc and mc["value"] > 0
+    assert [t for t, _ in mc["thread_sweep_iters_per_s"]] == sorted({max(1, nq // 2), nq, min(nc, 2 * nq)})
+    assert mc["cores"] in [t for t, _ in mc["thread_sweep_iters_per_s"]]
     assert mc["value"] == max(v for _, v in mc["thread_sweep_iters_per_s"]) or abs(mc["value"] - max(v for _, v in mc["thread_sweep_iters_per_s"])) < 1e-2
     assert out["config5_batch"]["linear_solver"] == "hip_dense"
     assert rf["traffic"] is None and rf["traffic_source"] is None  # (no committed counter pass for this workload)

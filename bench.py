@@ -452,7 +452,7 @@ def main():
         other = []
         for wl, st, wu in (("config2_lp_soc", 100, 10), ("config3_mixed", 20, 3), ("config4_psd", 100, 5), ("powerlaw_lp", 20, 2),
                            ("banded_lp", 20, 2)):
-            if wl == args.workload:
+            if wl == args.workload or (os.environ.get("BENCH_OTHER") and wl not in os.environ["BENCH_OTHER"].split(",")):
                 continue
             # config 4: the first 100 iterations run with the residual-tied PSD sweep level, later ones do not — the
             # line carries the window past iteration 100 and a whole solve next to the cold-start window

@@ -796,7 +796,14 @@ struct ScsHipWork {
   // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
   // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
   int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
-  bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return !(e && e[0] == '0'); }();
+  // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
+  // ~0.1 ms per launch in a fresh process and ~2 ms per launch once the process has driven other workspaces / streams before (config 4 as
+  // the second workload of a bench run: 224 iters/s in the steady window and 245 over a whole solve against 462 / 521 with the ordinary
+  // launch; cold window 495 vs 522; tools/dbg/c4_after.py, profiles/r04_psd_coop.txt).  The ordinary launch is safe for the same reason the
+  // cooperative one is accepted: the grid is sized to fit the device at one workgroup per CU (psd_mc_cap, occupancy query), the
+  // dispatcher places workgroups in order, and a kernel of another stream that holds CUs finishes without waiting for this one — a group
+  // whose members are late spins within its budget (F_PERSIST_ERR otherwise: an error, not a hang).  SCS_HIP_PSD_COOP=1: cooperative launch.
+  bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return e && e[0] == '1'; }();
   int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
   int psd_mc_members(int big) {
     if (psd_mc_cap < 0) {

@@ -53,8 +53,7 @@ struct DevPool {
     for (size_t i = blocks.size(); i-- > 0;)
       if (blocks[i].first.first == dev && blocks[i].first.second == bytes) {
         void *p = blocks[i].second;
-        blocks[i] = blocks.back();
-        blocks.pop_back();
+        blocks.erase(blocks.begin() + (long)i);
         cached -= bytes;
         return p;
       }
@@ -64,7 +63,16 @@ struct DevPool {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lk(m);
-    if (cached + bytes > capacity()) return false;
+    if (bytes > capacity()) return false;
+    // over the cap: the OLDEST blocks go back to the driver first (a long-lived service with changing problem sizes does not
+    // end up holding a cap's worth of blocks nobody asks for any more)
+    size_t drop = 0;
+    while (drop < blocks.size() && cached + bytes > capacity()) {
+      (void)hipFree(blocks[drop].second);
+      cached -= blocks[drop].first.second;
+      ++drop;
+    }
+    if (drop) blocks.erase(blocks.begin(), blocks.begin() + (long)drop);
     blocks.push_back({{dev, bytes}, p});
     cached += bytes;
     return true;

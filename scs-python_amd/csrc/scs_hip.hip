@@ -34,6 +34,7 @@
 #include "setup_cs_dev.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
+#include "cg_k1dot.hpp"
 
 namespace scship {
 
@@ -1001,10 +1002,32 @@ struct ScsHipWork {
   bool r_scalars() const { return diag_r_structured && pipelined; }
   RDiag rdx() const { return r_scalars() ? RDiag(stgs.rho_x, stgs.rho_x, 0) : RDiag(diag_r.p); }
   RDiag rdy() const { return r_scalars() ? RDiag(1.0 / (1000. * scale), 1.0 / scale, cone.z) : RDiag(diag_r.p + n); }
+  // p'Gp from K1 instead of K2 (cg_k1dot.hpp), for large LPs / SOCPs whose A and A' both use the column-sorted pass layout.  OPT-IN
+  // (SCS_HIP_K1DOT=1): measured on the metric workload it makes K2 3-4 us faster (90.0 -> 86.4 us: K2 = K1) but the iteration 1.7 % SLOWER
+  // (310-312 -> 305-306 iters/s, steady window 507-511 -> 491-496): the second reduction chain (r_x p^2 through k_cg_dir -> k_cg_update's
+  // prologue, one more pass behind the CG start) and K1's block reduction cost more than K2's 16 MB of p saved.
+  bool k1dot = false;
+  DevBuf<double> part_k1, part_pp;
+  void decide_k1dot(hipStream_t s) {
+    const char *e = getenv("SCS_HIP_K1DOT");
+    k1dot = (e && e[0] == '1') && !has_P && At.cs.ok && Ar.cs.ok && persist_wgs == 0;
+    if (k1dot) {
+      part_k1.alloc_zero((size_t)std::max(Ar.nwg(), 1) * kMaxEpiReductions, s);
+      part_pp.alloc_zero((size_t)kMaxVecBlocks, s);
+    }
+  }
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
   // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
   // second half of Gp when A' has the split layout (EpiGp::split): Gp = cg_Gp + gp2()
   double *gp2() const { return At.cs.ok && At.cs.split > 1 && !At.cs.combine() ? At.cs_part1.p : nullptr; }
+  // the two products of a CG step on the k1dot path: z = R_y^{-1} A p with the partials of (A p)'z, then the raw A'z (cg_Gp [+ gp2()])
+  void matvec_k1dot(const double *x, const int *done, int *step_counter, hipEvent_t *evs = nullptr) {
+    if (evs) HIP_CHECK(hipEventRecord(evs[0], stream));
+    launch_spmv(Ar.view(), x, EpiDivRDot{tmp_m.p, rdy(), part_k1.p}, done, stream, step_counter);
+    if (evs) HIP_CHECK(hipEventRecord(evs[1], stream));
+    launch_spmv(At.view(), tmp_m.p, EpiAtRaw{cg_Gp.p, gp2()}, done, stream);
+    if (evs) HIP_CHECK(hipEventRecord(evs[2], stream));
+  }
   void matvec(const double *x, const int *done, int *step_counter = nullptr) {
     launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, rdy()}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
@@ -1036,10 +1059,29 @@ struct ScsHipWork {
                        n, warm ? 1 : 0, fl.p, part.p, (const double *)gp2());
     hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, 0, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
+    if (k1dot) hipLaunchKernelGGL(k_pp_part, dim3(vb(n)), dim3(kVecThreads), 0, stream, (const double *)cg_p.p, rdx(), n, part_pp.p, (const int *)nullptr);
   }
-  // yacc != nullptr: carry y += alpha R_y^{-1} A p along (ADMM path, see k_prep)
-  void enqueue_cg_step(double *xout, double *yacc) {
+  // yacc != nullptr: carry y += alpha R_y^{-1} A p along (ADMM path, see k_prep).  evs: three events around the two products (in-situ
+  // kernel timing of one step: bench.py's roofline)
+  void enqueue_cg_step(double *xout, double *yacc, hipEvent_t *evs = nullptr) {
     const int nb = vb(std::max(n, yacc ? m : 0));
+    if (k1dot) {
+      matvec_k1dot(cg_p.p, fl.p + F_DONE, fl.p + F_STEP, evs);
+      hipLaunchKernelGGL(k_cg_update_k1dot, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, (const double *)cg_p.p, (const double *)cg_Gp.p,
+                         (const double *)gp2(), (const double *)cg_M.p, n, yacc, (const double *)tmp_m.p, m, (const double *)part_k1.p, Ar.nwg(),
+                         (const double *)part_pp.p, vb(n), rdx(), sc.p, (const int *)fl.p, part2.p);
+      hipLaunchKernelGGL(k_cg_dir_pp, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, (const double *)cg_r.p, (const double *)cg_M.p, n,
+                         (const double *)part2.p, nb, rdx(), part_pp.p, sc.p, fl.p);
+      return;
+    }
+    if (evs) {
+      HIP_CHECK(hipEventRecord(evs[0], stream));
+      launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
+      HIP_CHECK(hipEventRecord(evs[1], stream));
+      if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+      launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
+      HIP_CHECK(hipEventRecord(evs[2], stream));
+    } else
     matvec(cg_p.p, fl.p + F_DONE, fl.p + F_STEP);
     hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, yacc,
                        tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
@@ -1086,21 +1128,7 @@ struct ScsHipWork {
       } else {
         const int sample_it = chunk / 2;  // a mid-chunk step: not the one right behind the host sync
         for (int it = 0; it < chunk; ++it) {
-          if (profile && it == sample_it) {
-            HIP_CHECK(hipEventRecord(ev[0], stream));
-            launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
-            HIP_CHECK(hipEventRecord(ev[1], stream));
-            if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-            launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
-            HIP_CHECK(hipEventRecord(ev[2], stream));
-            const int nb = vb(std::max(n, yacc ? m : 0));
-            hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n,
-                               yacc, tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
-            hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p,
-                               fl.p);
-          } else {
-            enqueue_cg_step(xout, yacc);
-          }
+          enqueue_cg_step(xout, yacc, (profile && it == sample_it) ? ev : nullptr);
         }
         read_flags();
         if (profile && h_flags[F_ITERS] - iters_before > sample_it) {  // the sampled step really ran
@@ -1173,6 +1201,8 @@ struct ScsHipWork {
     // tolerance, ||r0||, r0'M r0, step counter, zero-rhs short circuit: one finalize launch
     hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
                        ut.p, (long)n + m, stall);
+    // (k1dot: the first step's alpha needs sum r_x p0^2 of the p0 = M r0 the start has just formed)
+    if (k1dot) hipLaunchKernelGGL(k_pp_part, dim3(vb(n)), dim3(kVecThreads), 0, stream, (const double *)cg_p.p, rdx(), n, part_pp.p, stall);
   }
   // dense direct variant of the linear solve of an iteration: rhs = R_x v_x - A' v_y;  u~_x = G^{-1} rhs;  u~_y = v_y + R_y^{-1} A u~_x.
   // Three dependent launches behind k_prep, no convergence flag: nothing here (or behind it) waits for the device.
@@ -1264,16 +1294,7 @@ struct ScsHipWork {
     for (int k = 0; k < chunk; ++k) {
       if (profile && k == chunk / 2) {  // one CG step of the queued iteration bracketed by events: nothing waits for them here
         for (auto &e : ev_prof[slot]) if (!e) HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventRecord(ev_prof[slot][0], stream));
-        launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
-        HIP_CHECK(hipEventRecord(ev_prof[slot][1], stream));
-        if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
-        launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
-        HIP_CHECK(hipEventRecord(ev_prof[slot][2], stream));
-        const int nb = vb(std::max(n, m));
-        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, ut.p, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, ut.p + n,
-                           tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
-        hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
+        enqueue_cg_step(ut.p, ut.p + n, ev_prof[slot]);
         prof_step[slot] = k;
       } else {
         enqueue_cg_step(ut.p, ut.p + n);
@@ -2246,6 +2267,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     w->dense_alloc();
     w->persist_wgs = 0;
   }
+  w->decide_k1dot(s);
   {
     const char *el = getenv("SCS_HIP_DENSE_LAZY");
     w->setup_pending = w->dense() && !(el && el[0] == '0');
@@ -2755,12 +2777,18 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     HIP_CHECK(hipSetDevice(w->device));
     hipStream_t s = w->stream;
     const int n = w->n;
-    for (int i = 0; i < 2; ++i) w->matvec(w->cg_p.p, nullptr);
+    // the two products exactly as the CG step of this workspace launches them (k1dot: cg_k1dot.hpp)
+    for (int i = 0; i < 2; ++i) { if (w->k1dot) w->matvec_k1dot(w->cg_p.p, nullptr, nullptr); else w->matvec(w->cg_p.p, nullptr); }
     HIP_CHECK(hipEventRecord(w->ev[0], s));
-    for (int i = 0; i < reps; ++i) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, nullptr, s);
+    for (int i = 0; i < reps; ++i) {
+      if (w->k1dot) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivRDot{w->tmp_m.p, w->rdy(), w->part_k1.p}, nullptr, s);
+      else launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, nullptr, s);
+    }
     HIP_CHECK(hipEventRecord(w->ev[1], s));
-    for (int i = 0; i < reps; ++i)
-      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), 0, w->part.p, w->gp2()}, nullptr, s);
+    for (int i = 0; i < reps; ++i) {
+      if (w->k1dot) launch_spmv(w->At.view(), w->tmp_m.p, EpiAtRaw{w->cg_Gp.p, w->gp2()}, nullptr, s);
+      else launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), 0, w->part.p, w->gp2()}, nullptr, s);
+    }
     HIP_CHECK(hipEventRecord(w->ev[2], s));
     HIP_CHECK(hipEventSynchronize(w->ev[2]));
     float a = 0, b = 0;

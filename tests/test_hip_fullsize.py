@@ -254,3 +254,29 @@ def test_power_law_rows_at_the_metric_size_iterate_as_the_csr_stream_layout(hip,
         np.testing.assert_allclose(got[key], ref[key], rtol=0, atol=1e-6 * np.abs(ref[key]).max(), err_msg=key)
     for key in ("res_pri", "res_dual", "pobj"):
         assert abs(got["info"][key] - ref["info"][key]) <= 1e-5 * abs(ref["info"][key]) + 1e-9, (key, got["info"][key], ref["info"][key])
+
+
+def test_cg_with_the_dot_product_in_k1_iterates_as_the_one_with_it_in_k2(hip, monkeypatch):
+    """round 4 (csrc/cg_k1dot.hpp): on large LPs / SOCPs p'Gp is formed as sum (A p)_i z_i + sum r_x p_j^2 — K1's epilogue and the kernel
+    that forms p — and K2 stores raw A'z.  Same mathematics, another fixed summation order: on BASELINE config 2 (m = 2e5, both matrices on
+    the column-sorted layout) the first 60 iterations with either formulation (SCS_HIP_K1DOT=0: the dot in K2) agree to 1e-9 of the largest
+    entry and take the same number of CG steps to within a step per linear solve; run-ahead and synchronous loops of the new one agree bit for bit."""
+    K, n, k, seed = pg.workload("config2_lp_soc")
+    data, _, _ = pg.gen_feasible(K, n, k, seed, lambda z, K: hip.proj_cone(z, K, dual=True))
+    import helpers
+    args = helpers.raw_args(data, K)
+    stg = dict(eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, verbose=False, max_iters=60)
+    out = {}
+    for tag, env in (("k2", {"SCS_HIP_K1DOT": "0"}), ("k1", {"SCS_HIP_K1DOT": "1"}), ("k1_sync", {"SCS_HIP_K1DOT": "1", "SCS_HIP_PIPELINE": "0", "SCS_HIP_GRAPH": "0"})):
+        for kk in ("SCS_HIP_K1DOT", "SCS_HIP_PIPELINE", "SCS_HIP_GRAPH"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        out[tag] = hip.SCS(*args, **stg).solve(False, None, None, None)
+        assert "column-sorted" in out[tag]["info"]["lin_sys_solver"]
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(out["k1"][key], out["k1_sync"][key], err_msg=key)
+        scl = np.abs(out["k2"][key]).max()
+        np.testing.assert_allclose(out["k1"][key], out["k2"][key], rtol=0, atol=1e-9 * scl, err_msg=key)
+    assert out["k1"]["info"]["cg_iters"] == out["k1_sync"]["info"]["cg_iters"]
+    assert abs(out["k1"]["info"]["cg_iters"] - out["k2"]["info"]["cg_iters"]) <= 60

@@ -319,3 +319,37 @@ def test_dense_and_indirect_members_in_one_batch(hip):
     for i, (a, b) in enumerate(zip(solo, grp)):
         _assert_same(a, b, "member %d" % i)
         assert ("dense-direct" in b["info"]["lin_sys_solver"]) == (i % 2 == 1)
+
+
+@pytest.mark.parametrize("extra", [
+    dict(normalize=False), dict(adaptive_scale=False), dict(acceleration_lookback=0), dict(acceleration_type_1=False, acceleration_interval=2),
+    dict(rho_x=1e-3), dict(alpha=1.0), dict(scale=5.0),
+])
+def test_dense_settings_variants_against_oracle_ldl(dense, oracle, extra):
+    """the settings that reach the linear solve or the loop around it (equilibration off, fixed scale, no / type-II acceleration, rho_x, alpha):
+    same answers as the oracle's direct solve under the same settings; mixed cone incl. a complex PSD block, strictly convex QP (unique x, y, s)"""
+    K = {"z": 6, "l": 80, "bu": [1.0, 2.0], "bl": [-1.0, -0.5], "q": [7, 9], "s": [5], "cs": [3], "ep": 3, "ed": 2, "p": [0.4, -0.7]}
+    data, p_star, _ = pg.gen_feasible_qp(K, 70, 6, 2718, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    stg = dict(STG, eps_abs=1e-8, eps_rel=1e-8, max_iters=50000, **extra)
+    got, ref = _solve_dense_and_oracle(dense, oracle, data, K, **{k: v for k, v in stg.items() if k not in STG or True})
+    assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved", (extra, got["info"]["status"], ref["info"]["status"])
+    assert abs(got["info"]["pobj"] - p_star) < 1e-6 * max(1, abs(p_star))
+    assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) < 1e-6 * max(1, abs(p_star))
+    # x is unique (strictly convex objective); y and s of the cone rows are compared where the loop is well conditioned — without
+    # equilibration / scale adaptation two 1e-8 certificates differ by ~1e-2 in single entries of y (the oracle's own CG and LDL' variants do)
+    _assert_xys(got, ref, keys=("x",))
+    if not ({"normalize", "adaptive_scale", "acceleration_type_1"} & set(extra)):
+        _assert_xys(got, ref)
+    Pf = data["P"] + sparse.triu(data["P"], 1).T if "P" in data else None
+    pri, dual, gap = helpers.kkt_certificate(data, got, P=Pf)
+    assert pri < 1e-6 and dual < 1e-6 and gap < 1e-6
+
+
+def test_dense_max_iters_and_time_limit_statuses(dense, oracle):
+    K = {"l": 120, "q": [6, 6]}
+    data, _, _ = pg.gen_feasible(K, 50, 6, 99, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    a = dense.SCS(*args, verbose=False, eps_abs=1e-14, eps_rel=1e-14, max_iters=37).solve(False, None, None, None)
+    assert a["info"]["iter"] == 37 and "inaccurate" in a["info"]["status"]
+    b = dense.SCS(*args, verbose=False, eps_abs=0.0, eps_rel=0.0, eps_infeas=0.0, max_iters=10 ** 7, time_limit_secs=0.3).solve(False, None, None, None)
+    assert b["info"]["iter"] < 10 ** 7 and b["info"]["solve_time"] < 5000.0

@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     // time, tools/cs_lab.hip timeline); loads that depend on nothing can fill that hole.
     // PREG quads of the gathers of pass g + 1 go before the barrier too, each right behind the products that free its registers
     // (7: one of the two quads, 9: both — then the braid issues nothing); 8: stream before the barrier, ALL gathers in the first row slot.
-    constexpr bool PRE = (ABL >= 6 && ABL <= 10) || ABL == 12;   // (10: as 6 with ONE gather per row slot; 12: as 6 with straight-line tail steps; 13: plain braid with them)
+    constexpr bool PRE = (ABL >= 6 && ABL <= 10) || ABL == 12 || ABL == 14;   // (10: as 6 with ONE gather per row slot; 12: as 6 with straight-line tail steps; 13: plain braid with them)
     constexpr int PREG = ABL == 7 ? 1 : ABL == 9 ? NQ : 0;
     constexpr int NGAT = 4 * NQ, NVAL = 2 * NQ, NMEM = PRE ? NGAT : NGAT + NQ + NVAL + 1;
     // `tail` is a compile-time mode: 0 = passes g + 1 and g + 2 exist (steady state), 1 = test at run time (uniform branches — every
@@ -743,7 +743,23 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
     };
     // first column of pass g + 1: scalar loads ahead of use
     int cn = get_pi(g0 + 1).x;
-    {  // prologue: stream passes g0 and g0 + 1, gather g0
+    if constexpr (ABL == 14) {  // (lab, round 4: the first gathers as early as possible — index quads, gathers, THEN the values of pass g0)
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) ld_idx(s, S0, g0);
+      const int c0 = get_pi(g0).x;
+#pragma unroll
+      for (int k = 0; k < NGAT; ++k) gat(k, S0, c0);
+#pragma unroll
+      for (int s = 0; s < NVAL; ++s) ld_val(s, S0, g0);
+      ld_meta(S0, g0);
+      if (g0 + 1 < g1) {
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) ld_idx(s, S1, g0 + 1);
+#pragma unroll
+        for (int s = 0; s < NVAL; ++s) ld_val(s, S1, g0 + 1);
+        ld_meta(S1, g0 + 1);
+      }
+    } else {  // prologue: stream passes g0 and g0 + 1, gather g0
 #pragma unroll
       for (int s = 0; s < NQ; ++s) ld_idx(s, S0, g0);
 #pragma unroll

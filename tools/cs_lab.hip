@@ -283,6 +283,16 @@ static void bench_matrix(const char *name, const Csr &M, int split) {
       if (split == 1) std::printf("  mismatches %ld", mismatches(dy, ref));
       std::printf("\n");
     }
+    auto a14 = [&] { hipLaunchKernelGGL((k_spmv_cs_il<EpiRaw2, 8, 14>), gg, bb, 0, 0, D.v, dx, EpiRaw2{dy, dy1}, nullptr, nullptr); };
+    {
+      HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
+      const double t = time_us(a14, 30), t6 = time_us(a6, 30), tb = time_us(a14, 30), t6b = time_us(a6, 30);
+      a14();
+      HIP_CHECK(hipDeviceSynchronize());
+      std::printf("    round 4: ABL 14 (as 6, prologue: index quads, gathers, then values): %.1f us vs ABL 6 %.1f us (again %.1f / %.1f)", t, t6, tb, t6b);
+      if (split == 1) std::printf("  mismatches %ld", mismatches(dy, ref));
+      std::printf("\n");
+    }
     for (int v = 7; v <= 9; ++v) {
       HIP_CHECK(hipMemset(dy, 0xff, ref.size() * 8));
       auto run = [&] { if (v == 7) a7(); else if (v == 8) a8(); else a9(); };

@@ -17,6 +17,11 @@ namespace scship {
 
 constexpr int kVecThreads = 256;
 constexpr int kMaxVecBlocks = 2048;
+// Elements per lane a vector kernel's grid is sized for: 4, and 8 for vectors beyond 2^20 elements (round 4).  The consumer of a
+// reduction re-reduces ALL partials in the prologue of every workgroup (no finalize launch): at m = 2e6, k_cg_dir's 977 workgroups each read
+// the 2 x 1954 partials k_cg_update left — as many bytes from L2 as the kernel's payload.  Halving the grid of the long vectors: +1.2 % on
+// the metric window (308 -> 312 iters/s); 8 everywhere costs config 2 (m = 2e5) 2.7 %, 16 costs the metric workload 2 % (tools/dbg/r4_ve.sh).
+constexpr long kVecLong = 1L << 20;
 
 // device scalar slots (double)
 enum : int {
@@ -39,7 +44,8 @@ enum : int {
 enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_PSD_TOL2, P_COUNT = 8 };
 
 __host__ __device__ inline int vec_blocks(long n) {
-  long nb = (n + 4L * kVecThreads - 1) / (4L * kVecThreads);
+  const long per = (n > kVecLong ? 8L : 4L) * kVecThreads;
+  long nb = (n + per - 1) / per;
   if (nb < 1) nb = 1;
   if (nb > kMaxVecBlocks) nb = kMaxVecBlocks;
   return (int)nb;

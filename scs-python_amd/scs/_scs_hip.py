@@ -123,7 +123,7 @@ def _runtime_env():
 
 def _load():
     _runtime_env()
-    path = os.path.join(_HERE, _LIB_NAME)
+    path = os.environ.get("SCS_HIP_LIB") or os.path.join(_HERE, _LIB_NAME)   # (SCS_HIP_LIB: an alternative build of the library, A/B labs)
     if not os.path.exists(path):
         raise ImportError(
             "scs._scs_hip: %s is not built (run `python __graft_entry__.py` / "

@@ -397,7 +397,7 @@ struct GroupSolve {
       t_cone_pre.set(g, w->ut.p, w->u.p, w->v.p, w->g.p, n, m, w->cone.z, w->cone.l, par, w->sc.p, w->part.p, nbl1, w->diag_r.p,
                      nullptr);
       if (t_box.used) t_box.set(g, uy + w->cone.off_box, w->box_bl.p, w->box_bu.p, w->cone.bsize, w->sc.p + S_BOX_T, 1, nostall);
-      if (t_soc.used) t_soc.set(g, uy, w->soc_off.p, w->soc_dim.p, w->n_soc, nostall);
+      if (t_soc.used) t_soc.set(g, uy, w->soc_off.p, w->soc_dim.p, w->n_soc, w->soc_G, nostall);
       if (t_psd.used)
         t_psd.set(g, uy, PsdBatch{w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd}, w->psd_scratch.p, w->psd_warm, nostall,
                   (const double *)(par + P_PSD_TOL2));
@@ -474,7 +474,7 @@ struct GroupSolve {
     t_tau_dots.gx = t_gg.gx = nbl1;
     t_g_rhs.gx = nbnm;
     t_kkt_prep.gx = t_kkt_y.gx = nbm;
-    t_soc.gx = ceil_div(w0->n_soc, kConeThreads / 64);
+    t_soc.gx = soc_wave_blocks(w0->n_soc, w0->soc_G);
     t_psd.gx = w0->n_psd;
     t_exp_p.gx = ceil_div(c0.ep, kConeThreads);
     t_exp_d.gx = ceil_div(c0.ed, kConeThreads);

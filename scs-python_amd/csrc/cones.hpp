@@ -27,39 +27,47 @@ constexpr int kConeThreads = 256;
 constexpr int kSocBig = 4096;
 
 // ------------------------------------------------------------------ SOC
-// in-place Pi_SOC on slices x[off[c] .. off[c]+dim[c]); one wave per cone
+// in-place Pi_SOC on slices x[off[c] .. off[c]+dim[c]); one lane group of G = 8/16/32/64 lanes per cone, 64/G cones
+// per wave (soc_group(): the narrowest group that holds the tail of the longest small cone, so short cones fill the
+// wave instead of leaving 56 lanes idle).  The butterfly over a group adds in the same association order as the
+// 64-lane tree does when the lanes beyond G hold zeros: the result does not depend on G.
+__host__ __device__ inline int soc_group(int max_small_q) {
+  const int tail = max_small_q - 1;
+  return tail > 32 ? 64 : tail > 16 ? 32 : tail > 8 ? 16 : 8;
+}
 __device__ __forceinline__ void d_proj_soc_wave(double *x, const int *__restrict__ off,
-                                                const int *__restrict__ dim, int ncones, const int *stall) {
+                                                const int *__restrict__ dim, int ncones, int G, const int *stall) {
   SCS_STALL_GUARD(stall);
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (kConeThreads / 64) + (threadIdx.x >> 6);
-  if (c >= ncones) return;
-  const int q = dim[c];
-  if (q == 0 || q > kSocBig) return;
-  double *v = x + off[c];
-  if (q == 1) {
-    if (lane == 0) v[0] = fmax(v[0], 0.);
-    return;
-  }
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+  const int wave = blockIdx.x * (kConeThreads / 64) + (threadIdx.x >> 6);
+  const int c = wave * (64 / G) + lane / G;
+  const bool live = c < ncones;
+  const int q = live ? dim[c] : 0;
+  double *v = x + (live ? off[c] : 0);
+  const bool small = q > 1 && q <= kSocBig;
   double ss = 0.;
-  for (int i = 1 + lane; i < q; i += 64) ss += v[i] * v[i];
-  ss = wave_sum(ss);
-  ss = __shfl(ss, 0, 64);
+  if (small)
+    for (int i = 1 + gl; i < q; i += G) ss += v[i] * v[i];
+  for (int o = G >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, kWave);  // every lane of the wave takes part
+  if (q == 1 && gl == 0) v[0] = fmax(v[0], 0.);
+  if (!small) return;
   const double s = sqrt(ss), t = v[0];
   if (s <= t) return;  // inside
   if (s <= -t) {
-    for (int i = lane; i < q; i += 64) v[i] = 0.;
+    for (int i = gl; i < q; i += G) v[i] = 0.;
     return;
   }
   const double alpha = 0.5 * (s + t), f = alpha / s;
-  for (int i = 1 + lane; i < q; i += 64) v[i] *= f;
-  if (lane == 0) v[0] = alpha;
+  for (int i = 1 + gl; i < q; i += G) v[i] *= f;
+  if (gl == 0) v[0] = alpha;
 }
 __global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const int *__restrict__ off,
-                                                                const int *__restrict__ dim, int ncones,
+                                                                const int *__restrict__ dim, int ncones, int G,
                                                                 const int *stall) {
-  d_proj_soc_wave(x, off, dim, ncones, stall);
+  d_proj_soc_wave(x, off, dim, ncones, G, stall);
 }
+// workgroups of k_proj_soc_wave for ncones cones in groups of G lanes
+inline int soc_wave_blocks(int ncones, int G) { return ceil_div(ceil_div(ncones, 64 / G), kConeThreads / 64); }
 
 // one workgroup per big cone
 __global__ __launch_bounds__(kConeThreads) void k_proj_soc_block(double *x, const int *__restrict__ off,

@@ -722,7 +722,7 @@ struct ScsHipWork {
 
   // cones
   DevBuf<int> soc_off, soc_dim, soc_big;
-  int n_soc = 0, n_soc_big = 0;
+  int n_soc = 0, n_soc_big = 0, soc_G = 64;  // soc_G: lanes per cone in k_proj_soc_wave (cones.hpp soc_group)
   DevBuf<double> pow_a, box_bl, box_bu;
   DevBuf<double> box_bl_orig, box_bu_orig, box_parts;
   DevBuf<unsigned> box_ticket;  // the caller's bounds (the working copies follow the row scaling): footer diagnostics
@@ -1484,8 +1484,8 @@ struct ScsHipWork {
                          sc.p + S_BOX_T, dual, stall);
     }
     if (n_soc > 0) {  // self-dual
-      hipLaunchKernelGGL(k_proj_soc_wave, dim3(ceil_div(n_soc, kConeThreads / 64)), dim3(kConeThreads), 0, stream, y,
-                         soc_off.p, soc_dim.p, n_soc, stall);
+      hipLaunchKernelGGL(k_proj_soc_wave, dim3(soc_wave_blocks(n_soc, soc_G)), dim3(kConeThreads), 0, stream, y,
+                         soc_off.p, soc_dim.p, n_soc, soc_G, stall);
       if (n_soc_big > 0)
         hipLaunchKernelGGL(k_proj_soc_block, dim3(n_soc_big), dim3(kConeThreads), 0, stream, y, soc_off.p, soc_dim.p,
                            soc_big.p, n_soc_big, stall);
@@ -1850,14 +1850,16 @@ static void upload_cone_meta(ScsHipWork *w) {
   hipStream_t s = w->stream;
   const HostCone &c = w->cone;
   std::vector<int> off, dim, big;
-  int o = c.off_q;
+  int o = c.off_q, max_small = 0;
   for (size_t i = 0; i < c.q.size(); ++i) {
     off.push_back(o);
     dim.push_back(c.q[i]);
     if (c.q[i] > kSocBig) big.push_back((int)i);
+    else max_small = std::max(max_small, (int)c.q[i]);
     o += c.q[i];
   }
   w->n_soc = (int)off.size();
+  w->soc_G = soc_group(max_small);
   w->n_soc_big = (int)big.size();
   if (w->n_soc) { w->soc_off.upload(off.data(), off.size(), s); w->soc_dim.upload(dim.data(), dim.size(), s); }
   if (w->n_soc_big) w->soc_big.upload(big.data(), big.size(), s);

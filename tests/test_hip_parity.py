@@ -117,6 +117,31 @@ def test_cone_projection_large_mixed(hip, oracle):
             np.testing.assert_allclose(got, ref, rtol=0, atol=2e-8 * scl)
 
 
+@pytest.mark.parametrize("qmax", [2, 9, 10, 17, 18, 33, 34, 200])
+def test_soc_lane_groups_vs_oracle(hip, oracle, qmax):
+    """short second-order cones share a wavefront in lane groups of 8/16/32/64 (cones.hpp soc_group, chosen from the
+    longest cone): every group width against the oracle, with ragged counts (a last wave partly empty), q = 0/1/2
+    members, interior / polar / boundary points — and the SAME bits whichever width the other cones forced."""
+    rng = np.random.RandomState(qmax)
+    q = [int(v) for v in rng.randint(0, qmax + 1, 203)] + [qmax, 1, 0, 2][: 1 + (qmax % 4)]
+    K = {"l": 3, "q": q}
+    m = pg.cone_dims(K)
+    z = rng.randn(m)
+    o = 3
+    for i, d in enumerate(q):           # a third inside, a third in the polar cone, the rest outside
+        if d > 0 and i % 3 == 0:
+            z[o] = np.linalg.norm(z[o + 1:o + d]) + 0.5
+        elif d > 0 and i % 3 == 1:
+            z[o] = -np.linalg.norm(z[o + 1:o + d]) - 0.5
+        o += d
+    for dual in (False, True):
+        got, ref = hip.proj_cone(z, K, dual=dual), oracle.proj_cone(z, K, dual=dual)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * max(1.0, np.abs(z).max()))
+    K64 = {"l": 3, "q": q + [300]}      # one long cone forces full-wave groups for all of them
+    z64 = np.concatenate([z, rng.randn(300)])
+    np.testing.assert_array_equal(hip.proj_cone(z64, K64)[:m], hip.proj_cone(z, K))
+
+
 @pytest.mark.parametrize("nb,scl,shift", [(20000, 1.0, 0.0), (50001, 10.0, 5.0), (17000, 1.0, -1e5), (100000, 0.3, 2.0)])
 def test_box_cone_many_workgroups_vs_oracle(hip, oracle, nb, scl, shift):
     """box cones beyond 16384 bounds run the Newton iteration on t as one launch per round over many workgroups

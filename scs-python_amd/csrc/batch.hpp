@@ -138,7 +138,7 @@ struct GroupSolve {
   SCS_GTABLE(kVecThreads, d_cone_pre) t_cone_pre;
   SCS_GTABLE(kBoxThreads, d_proj_box) t_box;
   SCS_GTABLE(kConeThreads, d_proj_soc_wave) t_soc;
-  SCS_GTABLE(64, d_proj_psd_small) t_psd;
+  SCS_GTABLE(kPsdSmallThreads, d_proj_psd_small4) t_psd;
   SCS_GTABLE(kConeThreads, d_proj_exp) t_exp_p, t_exp_d;
   SCS_GTABLE(kConeThreads, d_proj_pow_dual) t_pow;
   SCS_GTABLE(kVecThreads, d_v_update) t_v_update;

@@ -1589,6 +1589,217 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
   d_proj_psd_small(x, B, scratch, allow_warm, stall, tol2);
 }
 
+// Round 4: the same projection by FOUR wavefronts (one per SIMD of a CU).  A lone wavefront spends a round of the sweep on its own
+// latencies — 35 LDS reads, 128 fp64 operations at 4 clk each, 32 stores, ~1 us — and nothing overlaps them.  With 256 lanes
+// lane (k = tid & 15, g = tid >> 4) owns ONE 2x2 block (pairs k, g) of S and rows g, g + 16 of the eigenvector columns of pair k,
+// forms the rotations of BOTH its pairs itself (no published (c, s): no second barrier) and writes the rotated block to the
+// OTHER copy of S (every entry of S is rewritten in every round, so the copies ping-pong): one barrier per round.
+// Every entry goes through the same operations in the same order as in the one-wavefront kernel; the compiler contracts the
+// rotation products into FMAs differently in the two bodies, so the results agree to rounding (~1e-15 relative), not bit for bit.
+constexpr int kPsdSmallThreads = 256;
+__device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
+                                                  const int *stall, const double *tol2) {
+  SCS_STALL_GUARD(stall);
+  constexpr int NT = kPsdSmallThreads, SZ = 32 * kPsdSLd;
+  const double offtol2 = psd_offtol2(tol2);
+  __shared__ double SS[2 * SZ], V[SZ], T[SZ];
+  const int tid = threadIdx.x, cidx = blockIdx.x;
+  const int n = B.order[cidx];
+  double *X = x + B.off[cidx];
+  if (n == 0) return;
+  if (n == 1) {
+    if (tid == 0) X[0] = fmax(X[0], 0.);
+    return;
+  }
+  const int N = (n + 1) & ~1, H = N / 2, ld = kPsdSLd;
+  double *Vg = scratch + B.woff[cidx];
+  double *state = Vg + psd_scratch_doubles(n) - 8;
+  const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
+  const double st0 = state[0];
+  const bool warm = allow_warm && st0 >= 1.;
+  const bool reorth = warm && ((long)st0 % kPsdWarmPeriod) == 0;
+  int cur = 0;  // which copy of S is current
+#if PSD_PROFILE
+  double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+#endif
+  PSD_TICK(t_begin);
+#define PSD_S(i, j) SS[cur * SZ + (i) + ld * (j)]
+#define PSD_SN(i, j) SS[(cur ^ 1) * SZ + (i) + ld * (j)]
+
+  for (int e = tid; e < N * N; e += NT) {
+    const int j = e / N, i = e - j * N;
+    PSD_S(i, j) = 0.;
+    V[i + ld * j] = warm ? Vg[e] : (i == j ? 1. : 0.);
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += NT) {
+    const int j = e / n, i = e - j * n;
+    if (i < j) continue;
+    const long base = (long)j * n - (long)j * (j - 1) / 2;
+    double v = X[base + (i - j)];
+    if (i != j) v *= isq2;
+    PSD_S(i, j) = v;
+    PSD_S(j, i) = v;
+  }
+  __syncthreads();
+  PSD_TICK(t_unpacked);
+  PSD_ACC(1, t_begin, t_unpacked);
+  if (reorth) {  // V <- V (3I - V'V) / 2
+    for (int e = tid; e < N * N; e += NT) {
+      const int j = e / N, i = e - j * N;
+      double acc = 0.;
+      for (int k = 0; k < N; ++k) acc += V[k + ld * i] * V[k + ld * j];
+      T[i + ld * j] = (i == j ? 1.5 : 0.) - 0.5 * acc;
+    }
+    __syncthreads();
+    double vn[(kPsdSmallMax * kPsdSmallMax + NT - 1) / NT];
+#pragma unroll
+    for (int h = 0; h < (kPsdSmallMax * kPsdSmallMax + NT - 1) / NT; ++h) {
+      const int e = tid + NT * h, j = e / N, i = e - j * N;
+      double acc = 0.;
+      if (e < N * N)
+        for (int k = 0; k < N; ++k) acc += V[i + ld * k] * T[k + ld * j];
+      vn[h] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < (kPsdSmallMax * kPsdSmallMax + NT - 1) / NT; ++h) {
+      const int e = tid + NT * h, j = e / N, i = e - j * N;
+      if (e < N * N) V[i + ld * j] = vn[h];
+    }
+    __syncthreads();
+  }
+  if (warm) {  // S <- V' S V
+    for (int e = tid; e < N * N; e += NT) {
+      const int j = e / N, i = e - j * N;
+      T[i + ld * j] = psd_small_dot(N, [&](int k) { return PSD_S(i, k); }, [&](int k) { return V[k + ld * j]; });
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += NT) {
+      const int j = e / N, i = e - j * N;
+      if (i < j) continue;
+      const double acc = psd_small_dot(N, [&](int k) { return V[k + ld * i]; }, [&](int k) { return T[k + ld * j]; });
+      PSD_S(i, j) = acc;
+      PSD_S(j, i) = acc;
+    }
+    __syncthreads();
+  }
+
+  PSD_TICK(t_warmed);
+  PSD_ACC(2, t_unpacked, t_warmed);
+  const int k = tid & 15, g = tid >> 4, lane = tid & 63;
+  for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
+    double off = 0., tot = 0.;  // every wavefront forms the whole sum (same order, same bits: the exit below is uniform)
+    for (int e = lane; e < N * N; e += 64) {
+      const int j = e / N, i = e - j * N;
+      const double a = PSD_S(i, j);
+      tot += a * a;
+      if (i != j) off += a * a;
+    }
+    off = wave_sum(off);
+    tot = wave_sum(tot);
+    off = __shfl(off, 0, 64);
+    tot = __shfl(tot, 0, 64);
+    if (off <= offtol2 * tot || off == 0.) break;
+#if PSD_PROFILE
+    prof[7] += 1.;
+#endif
+    for (int r = 0; r < N - 1; ++r) {
+      auto pair_of = [&](int kk, int &pp, int &qq) {
+        int x = r + kk, y = r - kk + (N - 1);
+        x = x >= N - 1 ? x - (N - 1) : x;
+        y = y >= N - 1 ? y - (N - 1) : y;
+        x = kk == 0 ? N - 1 : x;
+        y = kk == 0 ? r : y;
+        pp = min(x, y);
+        qq = max(x, y);
+      };
+      const bool kv = k < H, bv = kv && g < H;
+      int p, q, p2, q2;
+      pair_of(kv ? k : 0, p, q);
+      pair_of(bv ? g : 0, p2, q2);
+      const double apq = PSD_S(p, q), app = PSD_S(p, p), aqq = PSD_S(q, q);
+      const double bpq = PSD_S(p2, q2), bpp = PSD_S(p2, p2), bqq = PSD_S(q2, q2);
+      const double a0 = PSD_S(p, p2), a1 = PSD_S(p, q2), a2 = PSD_S(q, p2), a3 = PSD_S(q, q2);
+      const bool rv0 = kv && g < N, rv1 = kv && g + 16 < N;
+      const int i0 = rv0 ? g : 0, i1 = rv1 ? g + 16 : 0;
+      const double vp0 = V[i0 + ld * p], vq0 = V[i0 + ld * q], vp1 = V[i1 + ld * p], vq1 = V[i1 + ld * q];
+      double c, s, c2, s2;
+      {
+        const bool rot = fabs(apq) > 1e-300;
+        jacobi_rot(app, aqq, rot ? apq : 1.0, c, s);
+        c = rot ? c : 1.;
+        s = rot ? s : 0.;
+        const bool rot2 = fabs(bpq) > 1e-300;
+        jacobi_rot(bpp, bqq, rot2 ? bpq : 1.0, c2, s2);
+        c2 = rot2 ? c2 : 1.;
+        s2 = rot2 ? s2 : 0.;
+      }
+      const double t1 = c2 * a0 - s2 * a1, t2 = s2 * a0 + c2 * a1;
+      const double t3 = c2 * a2 - s2 * a3, t4 = s2 * a2 + c2 * a3;
+      if (bv) {
+        PSD_SN(p, p2) = c * t1 - s * t3;
+        PSD_SN(p, q2) = c * t2 - s * t4;
+        PSD_SN(q, p2) = s * t1 + c * t3;
+        PSD_SN(q, q2) = s * t2 + c * t4;
+      }
+      if (rv0) {
+        V[g + ld * p] = c * vp0 - s * vq0;
+        V[g + ld * q] = s * vp0 + c * vq0;
+      }
+      if (rv1) {
+        V[g + 16 + ld * p] = c * vp1 - s * vq1;
+        V[g + 16 + ld * q] = s * vp1 + c * vq1;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  PSD_TICK(t_swept);
+  PSD_ACC(3, t_warmed, t_swept);
+  for (int e = tid; e < N * N; e += NT) {
+    const int j = e / N, i = e - j * N;
+    Vg[e] = V[i + ld * j];
+    const double di = i < n ? PSD_S(i, i) : 0., dj = j < n ? PSD_S(j, j) : 0.;
+    double fij;
+    if (i == j) {
+      fij = fmax(di, 0.);
+    } else {
+      const double hi = fmax(di, dj), lo = fmin(di, dj);
+      fij = PSD_S(i, j) * (lo > 0. ? 1. : (hi <= 0. ? 0. : hi / (hi - lo)));
+    }
+    T[i + ld * j] = fij;
+  }
+  if (tid == 0) state[0] = warm ? st0 + 1. : 1.;
+  __syncthreads();
+  for (int e = tid; e < N * N; e += NT) {  // S(other copy) <- V F
+    const int j = e / N, i = e - j * N;
+    PSD_SN(i, j) = psd_small_dot(N, [&](int kk) { return V[i + ld * kk]; }, [&](int kk) { return T[kk + ld * j]; });
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += NT) {  // X+ = (V F) V', lower triangle
+    const int j = e / n, i = e - j * n;
+    if (i < j) continue;
+    const double acc = psd_small_dot(N, [&](int kk) { return PSD_SN(i, kk); }, [&](int kk) { return V[j + ld * kk]; });
+    const long base = (long)j * n - (long)j * (j - 1) / 2;
+    X[base + (i - j)] = (i == j) ? acc : acc * sq2;
+  }
+#if PSD_PROFILE
+  __syncthreads();
+  PSD_TICK(t_end);
+  PSD_ACC(6, t_swept, t_end);
+  if (tid == 0)
+    for (int i = 1; i < 8; ++i) state[i] = prof[i];
+#endif
+#undef PSD_S
+#undef PSD_SN
+}
+__global__ __launch_bounds__(kPsdSmallThreads) void k_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
+                                                                      const int *stall, const double *tol2) {
+  d_proj_psd_small4(x, B, scratch, allow_warm, stall, tol2);
+}
+
 // ---------------------------------------------------------------------------
 // Complex PSD cone `cs` (R:scs/scsobject.h:734-737; k*k reals per order-k Hermitian matrix,
 // R:test/test_spectral_and_complex_cones.py:22-24, R:test/test_mix_sd_csd_cone.py:34-35).

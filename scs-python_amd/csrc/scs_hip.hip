@@ -790,12 +790,18 @@ struct ScsHipWork {
     }
     if (count > big) {
       PsdBatch B{off + big, order + big, woff + big, count - big};
-      hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall, psd_tol2);
+      if (psd_small_one_wave)
+        hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall, psd_tol2);
+      else
+        hipLaunchKernelGGL(k_proj_psd_small4, dim3(count - big), dim3(kPsdSmallThreads), 0, stream, base, B, psd_scratch.p, psd_warm, stall,
+                           psd_tol2);
     }
   }
   // Members (CUs) per matrix for the split-mode sweeps: as many as fit when every matrix gets the same number and a
   // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
   // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
+  // small matrices (order <= 32): four wavefronts per matrix (psd.hpp d_proj_psd_small4); SCS_HIP_PSD_SMALL_WAVES=1: the one-wavefront kernel (lab; agrees to rounding)
+  bool psd_small_one_wave = [] { const char *e = getenv("SCS_HIP_PSD_SMALL_WAVES"); return e && e[0] == '1'; }();
   int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
   // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
   // ~0.1 ms per launch in a fresh process and ~2 ms per launch once the process has driven other workspaces / streams before (config 4 as

@@ -56,7 +56,12 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < x.size(); ++i) x[i] = x0[i] * (1.0 + pert * call) + pert * call * nd(g);
     HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));
     HIP_CHECK(hipEventRecord(e0));
-    if (n <= kPsdSmallMax) hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, (const int *)nullptr, (const double *)nullptr);
+    if (n <= kPsdSmallMax) {  // four wavefronts per matrix; PSD_LAB_SMALL1 (and the second pass of `compare`): the one-wavefront kernel
+      if (getenv("PSD_LAB_SMALL1") || (compare && pass == 1))
+        hipLaunchKernelGGL(k_proj_psd_small, dim3(cnt), dim3(64), 0, 0, d_x, B, d_scr, 1, (const int *)nullptr, (const double *)nullptr);
+      else
+        hipLaunchKernelGGL(k_proj_psd_small4, dim3(cnt), dim3(kPsdSmallThreads), 0, 0, d_x, B, d_scr, 1, (const int *)nullptr, (const double *)nullptr);
+    }
     else if (split) {
       const int ntile = (int)np / 16;
       const dim3 gg(psd_gemm_wgs(ntile), (unsigned)cnt), gb(kPsdGemmThreads);

@@ -1589,20 +1589,31 @@ __global__ __launch_bounds__(64) void k_proj_psd_small(double *x, PsdBatch B, do
   d_proj_psd_small(x, B, scratch, allow_warm, stall, tol2);
 }
 
-// Round 4: the same projection by FOUR wavefronts (one per SIMD of a CU).  A lone wavefront spends a round of the sweep on its own
-// latencies — 35 LDS reads, 128 fp64 operations at 4 clk each, 32 stores, ~1 us — and nothing overlaps them.  With 256 lanes
-// lane (k = tid & 15, g = tid >> 4) owns ONE 2x2 block (pairs k, g) of S and rows g, g + 16 of the eigenvector columns of pair k,
-// forms the rotations of BOTH its pairs itself (no published (c, s): no second barrier) and writes the rotated block to the
-// OTHER copy of S (every entry of S is rewritten in every round, so the copies ping-pong): one barrier per round.
-// Every entry goes through the same operations in the same order as in the one-wavefront kernel; the compiler contracts the
-// rotation products into FMAs differently in the two bodies, so the results agree to rounding (~1e-15 relative), not bit for bit.
+// Round 4: the same projection by FOUR wavefronts (one per SIMD of a CU), with the round-robin done by MOVING the data.
+// A lone wavefront spends a round of the sweep on its own latencies — 35 LDS reads, 128 fp64 operations at 4 clk each, 32 stores,
+// index arithmetic for five pairs, ~1 us — and nothing overlaps them.  Here the matrix is kept by POSITION: the pairs of every
+// round are the positions (2k, 2k+1), and after the rotations every row / column moves to the position the tournament gives it
+// next (position 0 stays; 1 -> 2; odd 2k+1 -> 2k-1; even 2k -> 2k+2; the last even -> the last odd): the SAME permutation every
+// round, so every address of the round loop is a per-lane constant.  Lane (k = tid & 15, g = tid >> 4) owns the 2x2 block
+// (pair k, pair g) of S and rows g, g + 16 of the eigenvector columns of pair k, forms the rotations of BOTH its pairs itself (no
+// published (c, s): no second barrier) and writes to the OTHER copy of S and V at the permuted positions — every entry is rewritten
+// in every round, so the copies ping-pong: one barrier per round.  After N - 1 rounds (one sweep) everything is back at its home
+// position, so the sweep test, the warm start and the reconstruction see the ordinary layout.  Same rotation formula, same
+// sweep test and reconstruction as the one-wavefront kernel; the pairs meet in a different order, so the results agree with it
+// to the sweep tolerance, not bit for bit (SCS_HIP_PSD_SMALL_WAVES=1 runs the one-wavefront kernel).
 constexpr int kPsdSmallThreads = 256;
+__device__ __forceinline__ int psd_small_next_pos(int a, int H) {
+  if (H == 1 || a == 0) return a;
+  const int kk = a >> 1;
+  if (a & 1) return kk == 0 ? 2 : 2 * kk - 1;
+  return kk == H - 1 ? 2 * H - 1 : 2 * kk + 2;
+}
 __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
                                                   const int *stall, const double *tol2) {
   SCS_STALL_GUARD(stall);
   constexpr int NT = kPsdSmallThreads, SZ = 32 * kPsdSLd;
   const double offtol2 = psd_offtol2(tol2);
-  __shared__ double SS[2 * SZ], V[SZ], T[SZ];
+  __shared__ double SS[2 * SZ], VV[2 * SZ], T[SZ];
   const int tid = threadIdx.x, cidx = blockIdx.x;
   const int n = B.order[cidx];
   double *X = x + B.off[cidx];
@@ -1618,18 +1629,19 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
   const double st0 = state[0];
   const bool warm = allow_warm && st0 >= 1.;
   const bool reorth = warm && ((long)st0 % kPsdWarmPeriod) == 0;
-  int cur = 0;  // which copy of S is current
+  int cur = 0;  // which copy of S and V is current
 #if PSD_PROFILE
   double prof[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
 #endif
   PSD_TICK(t_begin);
 #define PSD_S(i, j) SS[cur * SZ + (i) + ld * (j)]
 #define PSD_SN(i, j) SS[(cur ^ 1) * SZ + (i) + ld * (j)]
+#define PSD_V(i, j) VV[cur * SZ + (i) + ld * (j)]
 
   for (int e = tid; e < N * N; e += NT) {
     const int j = e / N, i = e - j * N;
     PSD_S(i, j) = 0.;
-    V[i + ld * j] = warm ? Vg[e] : (i == j ? 1. : 0.);
+    PSD_V(i, j) = warm ? Vg[e] : (i == j ? 1. : 0.);
   }
   __syncthreads();
   for (int e = tid; e < n * n; e += NT) {
@@ -1648,7 +1660,7 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
     for (int e = tid; e < N * N; e += NT) {
       const int j = e / N, i = e - j * N;
       double acc = 0.;
-      for (int k = 0; k < N; ++k) acc += V[k + ld * i] * V[k + ld * j];
+      for (int k = 0; k < N; ++k) acc += PSD_V(k, i) * PSD_V(k, j);
       T[i + ld * j] = (i == j ? 1.5 : 0.) - 0.5 * acc;
     }
     __syncthreads();
@@ -1658,27 +1670,27 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
       const int e = tid + NT * h, j = e / N, i = e - j * N;
       double acc = 0.;
       if (e < N * N)
-        for (int k = 0; k < N; ++k) acc += V[i + ld * k] * T[k + ld * j];
+        for (int k = 0; k < N; ++k) acc += PSD_V(i, k) * T[k + ld * j];
       vn[h] = acc;
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < (kPsdSmallMax * kPsdSmallMax + NT - 1) / NT; ++h) {
       const int e = tid + NT * h, j = e / N, i = e - j * N;
-      if (e < N * N) V[i + ld * j] = vn[h];
+      if (e < N * N) PSD_V(i, j) = vn[h];
     }
     __syncthreads();
   }
   if (warm) {  // S <- V' S V
     for (int e = tid; e < N * N; e += NT) {
       const int j = e / N, i = e - j * N;
-      T[i + ld * j] = psd_small_dot(N, [&](int k) { return PSD_S(i, k); }, [&](int k) { return V[k + ld * j]; });
+      T[i + ld * j] = psd_small_dot(N, [&](int k) { return PSD_S(i, k); }, [&](int k) { return PSD_V(k, j); });
     }
     __syncthreads();
     for (int e = tid; e < N * N; e += NT) {
       const int j = e / N, i = e - j * N;
       if (i < j) continue;
-      const double acc = psd_small_dot(N, [&](int k) { return V[k + ld * i]; }, [&](int k) { return T[k + ld * j]; });
+      const double acc = psd_small_dot(N, [&](int k) { return PSD_V(k, i); }, [&](int k) { return T[k + ld * j]; });
       PSD_S(i, j) = acc;
       PSD_S(j, i) = acc;
     }
@@ -1687,7 +1699,21 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
 
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
-  const int k = tid & 15, g = tid >> 4, lane = tid & 63;
+  const int lane = tid & 63;
+  // per-lane constants of the round loop (offsets in doubles inside one copy)
+  const int k = tid & 15, g = tid >> 4;
+  const bool kv = k < H, bv = kv && g < H;
+  const int p = kv ? 2 * k : 0, q = p + 1, p2 = bv ? 2 * g : 0, q2 = p2 + 1;
+  const int np = psd_small_next_pos(p, H), nq = psd_small_next_pos(q, H);
+  const int np2 = psd_small_next_pos(p2, H), nq2 = psd_small_next_pos(q2, H);
+  const int o_pp = p + ld * p, o_qq = q + ld * q, o_pq = p + ld * q;       // diagonal block of pair k
+  const int o_pp2 = p2 + ld * p2, o_qq2 = q2 + ld * q2, o_pq2 = p2 + ld * q2;  // ... of pair g
+  const int o_a0 = p + ld * p2, o_a1 = p + ld * q2, o_a2 = q + ld * p2, o_a3 = q + ld * q2;
+  const int w_a0 = np + ld * np2, w_a1 = np + ld * nq2, w_a2 = nq + ld * np2, w_a3 = nq + ld * nq2;
+  const bool rv0 = kv && g < N, rv1 = kv && g + 16 < N;
+  const int i0 = rv0 ? g : 0, i1 = rv1 ? g + 16 : 0;
+  const int o_vp0 = i0 + ld * p, o_vq0 = i0 + ld * q, o_vp1 = i1 + ld * p, o_vq1 = i1 + ld * q;
+  const int w_vp0 = i0 + ld * np, w_vq0 = i0 + ld * nq, w_vp1 = i1 + ld * np, w_vq1 = i1 + ld * nq;
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     double off = 0., tot = 0.;  // every wavefront forms the whole sum (same order, same bits: the exit below is uniform)
     for (int e = lane; e < N * N; e += 64) {
@@ -1705,25 +1731,12 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
     prof[7] += 1.;
 #endif
     for (int r = 0; r < N - 1; ++r) {
-      auto pair_of = [&](int kk, int &pp, int &qq) {
-        int x = r + kk, y = r - kk + (N - 1);
-        x = x >= N - 1 ? x - (N - 1) : x;
-        y = y >= N - 1 ? y - (N - 1) : y;
-        x = kk == 0 ? N - 1 : x;
-        y = kk == 0 ? r : y;
-        pp = min(x, y);
-        qq = max(x, y);
-      };
-      const bool kv = k < H, bv = kv && g < H;
-      int p, q, p2, q2;
-      pair_of(kv ? k : 0, p, q);
-      pair_of(bv ? g : 0, p2, q2);
-      const double apq = PSD_S(p, q), app = PSD_S(p, p), aqq = PSD_S(q, q);
-      const double bpq = PSD_S(p2, q2), bpp = PSD_S(p2, p2), bqq = PSD_S(q2, q2);
-      const double a0 = PSD_S(p, p2), a1 = PSD_S(p, q2), a2 = PSD_S(q, p2), a3 = PSD_S(q, q2);
-      const bool rv0 = kv && g < N, rv1 = kv && g + 16 < N;
-      const int i0 = rv0 ? g : 0, i1 = rv1 ? g + 16 : 0;
-      const double vp0 = V[i0 + ld * p], vq0 = V[i0 + ld * q], vp1 = V[i1 + ld * p], vq1 = V[i1 + ld * q];
+      const double *Sr = SS + cur * SZ, *Vr = VV + cur * SZ;
+      double *Sw = SS + (cur ^ 1) * SZ, *Vw = VV + (cur ^ 1) * SZ;
+      const double apq = Sr[o_pq], app = Sr[o_pp], aqq = Sr[o_qq];
+      const double bpq = Sr[o_pq2], bpp = Sr[o_pp2], bqq = Sr[o_qq2];
+      const double a0 = Sr[o_a0], a1 = Sr[o_a1], a2 = Sr[o_a2], a3 = Sr[o_a3];
+      const double vp0 = Vr[o_vp0], vq0 = Vr[o_vq0], vp1 = Vr[o_vp1], vq1 = Vr[o_vq1];
       double c, s, c2, s2;
       {
         const bool rot = fabs(apq) > 1e-300;
@@ -1738,18 +1751,18 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
       const double t1 = c2 * a0 - s2 * a1, t2 = s2 * a0 + c2 * a1;
       const double t3 = c2 * a2 - s2 * a3, t4 = s2 * a2 + c2 * a3;
       if (bv) {
-        PSD_SN(p, p2) = c * t1 - s * t3;
-        PSD_SN(p, q2) = c * t2 - s * t4;
-        PSD_SN(q, p2) = s * t1 + c * t3;
-        PSD_SN(q, q2) = s * t2 + c * t4;
+        Sw[w_a0] = c * t1 - s * t3;
+        Sw[w_a1] = c * t2 - s * t4;
+        Sw[w_a2] = s * t1 + c * t3;
+        Sw[w_a3] = s * t2 + c * t4;
       }
       if (rv0) {
-        V[g + ld * p] = c * vp0 - s * vq0;
-        V[g + ld * q] = s * vp0 + c * vq0;
+        Vw[w_vp0] = c * vp0 - s * vq0;
+        Vw[w_vq0] = s * vp0 + c * vq0;
       }
       if (rv1) {
-        V[g + 16 + ld * p] = c * vp1 - s * vq1;
-        V[g + 16 + ld * q] = s * vp1 + c * vq1;
+        Vw[w_vp1] = c * vp1 - s * vq1;
+        Vw[w_vq1] = s * vp1 + c * vq1;
       }
       __syncthreads();
       cur ^= 1;
@@ -1760,7 +1773,7 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
   PSD_ACC(3, t_warmed, t_swept);
   for (int e = tid; e < N * N; e += NT) {
     const int j = e / N, i = e - j * N;
-    Vg[e] = V[i + ld * j];
+    Vg[e] = PSD_V(i, j);
     const double di = i < n ? PSD_S(i, i) : 0., dj = j < n ? PSD_S(j, j) : 0.;
     double fij;
     if (i == j) {
@@ -1775,13 +1788,13 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
   __syncthreads();
   for (int e = tid; e < N * N; e += NT) {  // S(other copy) <- V F
     const int j = e / N, i = e - j * N;
-    PSD_SN(i, j) = psd_small_dot(N, [&](int kk) { return V[i + ld * kk]; }, [&](int kk) { return T[kk + ld * j]; });
+    PSD_SN(i, j) = psd_small_dot(N, [&](int kk) { return PSD_V(i, kk); }, [&](int kk) { return T[kk + ld * j]; });
   }
   __syncthreads();
   for (int e = tid; e < n * n; e += NT) {  // X+ = (V F) V', lower triangle
     const int j = e / n, i = e - j * n;
     if (i < j) continue;
-    const double acc = psd_small_dot(N, [&](int kk) { return PSD_SN(i, kk); }, [&](int kk) { return V[j + ld * kk]; });
+    const double acc = psd_small_dot(N, [&](int kk) { return PSD_SN(i, kk); }, [&](int kk) { return PSD_V(j, kk); });
     const long base = (long)j * n - (long)j * (j - 1) / 2;
     X[base + (i - j)] = (i == j) ? acc : acc * sq2;
   }
@@ -1794,6 +1807,7 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
 #endif
 #undef PSD_S
 #undef PSD_SN
+#undef PSD_V
 }
 __global__ __launch_bounds__(kPsdSmallThreads) void k_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
                                                                       const int *stall, const double *tol2) {

@@ -124,7 +124,14 @@ int main(int argc, char **argv) {
     long diff = 0;
     for (size_t c = 0; c < outs[0].size(); ++c)
       for (size_t i = 0; i < outs[0][c].size(); ++i) diff += std::memcmp(&outs[0][c][i], &outs[1][c][i], 8) != 0;
-    std::printf("bitwise differences between the two passes over %zu calls: %ld\n", outs[0].size(), diff);
+    double worst = 0., scale = 0.;
+    for (size_t c = 0; c < outs[0].size(); ++c)
+      for (size_t i = 0; i < outs[0][c].size(); ++i) {
+        worst = std::max(worst, std::fabs(outs[0][c][i] - outs[1][c][i]));
+        scale = std::max(scale, std::fabs(outs[1][c][i]));
+      }
+    std::printf("bitwise differences between the two passes over %zu calls: %ld; max |difference| %.3e (entries up to %.3e)\n", outs[0].size(), diff,
+                worst, scale);
   }
   return 0;
 }

@@ -1700,20 +1700,62 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
   PSD_TICK(t_warmed);
   PSD_ACC(2, t_unpacked, t_warmed);
   const int lane = tid & 63;
-  // per-lane constants of the round loop (offsets in doubles inside one copy)
+  // Per-lane constants of the round loop (offsets in doubles inside one copy).  Lanes without a pair / block / row work on
+  // entry (0, 1) and write to a slot of the unused 33rd row, so that the round has no branch: the compiler then interleaves the
+  // two rotation chains instead of running the second one inside the `if` of the stores.
   const int k = tid & 15, g = tid >> 4;
   const bool kv = k < H, bv = kv && g < H;
   const int p = kv ? 2 * k : 0, q = p + 1, p2 = bv ? 2 * g : 0, q2 = p2 + 1;
   const int np = psd_small_next_pos(p, H), nq = psd_small_next_pos(q, H);
   const int np2 = psd_small_next_pos(p2, H), nq2 = psd_small_next_pos(q2, H);
+  const int dummy = 32 + ld * (tid & 31);
   const int o_pp = p + ld * p, o_qq = q + ld * q, o_pq = p + ld * q;       // diagonal block of pair k
   const int o_pp2 = p2 + ld * p2, o_qq2 = q2 + ld * q2, o_pq2 = p2 + ld * q2;  // ... of pair g
   const int o_a0 = p + ld * p2, o_a1 = p + ld * q2, o_a2 = q + ld * p2, o_a3 = q + ld * q2;
-  const int w_a0 = np + ld * np2, w_a1 = np + ld * nq2, w_a2 = nq + ld * np2, w_a3 = nq + ld * nq2;
+  const int w_a0 = bv ? np + ld * np2 : dummy, w_a1 = bv ? np + ld * nq2 : dummy;
+  const int w_a2 = bv ? nq + ld * np2 : dummy, w_a3 = bv ? nq + ld * nq2 : dummy;
   const bool rv0 = kv && g < N, rv1 = kv && g + 16 < N;
   const int i0 = rv0 ? g : 0, i1 = rv1 ? g + 16 : 0;
   const int o_vp0 = i0 + ld * p, o_vq0 = i0 + ld * q, o_vp1 = i1 + ld * p, o_vq1 = i1 + ld * q;
-  const int w_vp0 = i0 + ld * np, w_vq0 = i0 + ld * nq, w_vp1 = i1 + ld * np, w_vq1 = i1 + ld * nq;
+  const int w_vp0 = rv0 ? i0 + ld * np : dummy, w_vq0 = rv0 ? i0 + ld * nq : dummy;
+  const int w_vp1 = rv1 ? i1 + ld * np : dummy, w_vq1 = rv1 ? i1 + ld * nq : dummy;
+  // one round from copy C to copy 1 - C (compile-time: the copy's offset folds into the LDS instructions)
+  auto round = [&](auto CUR) {
+    constexpr int C = decltype(CUR)::value;
+    const double *Sr = SS + C * SZ, *Vr = VV + C * SZ;
+    double *Sw = SS + (1 - C) * SZ, *Vw = VV + (1 - C) * SZ;
+    const double apq = Sr[o_pq], app = Sr[o_pp], aqq = Sr[o_qq];
+    const double bpq = Sr[o_pq2], bpp = Sr[o_pp2], bqq = Sr[o_qq2];
+    const double a0 = Sr[o_a0], a1 = Sr[o_a1], a2 = Sr[o_a2], a3 = Sr[o_a3];
+    const double vp0 = Vr[o_vp0], vq0 = Vr[o_vq0], vp1 = Vr[o_vp1], vq1 = Vr[o_vq1];
+    double c, s, c2, s2;
+    const bool rot = fabs(apq) > 1e-300, rot2 = fabs(bpq) > 1e-300;
+    jacobi_rot(app, aqq, rot ? apq : 1.0, c, s);
+    jacobi_rot(bpp, bqq, rot2 ? bpq : 1.0, c2, s2);
+    c = rot ? c : 1.;
+    s = rot ? s : 0.;
+    c2 = rot2 ? c2 : 1.;
+    s2 = rot2 ? s2 : 0.;
+    const double t1 = c2 * a0 - s2 * a1, t2 = s2 * a0 + c2 * a1;
+    const double t3 = c2 * a2 - s2 * a3, t4 = s2 * a2 + c2 * a3;
+    Sw[w_a0] = c * t1 - s * t3;
+    Sw[w_a1] = c * t2 - s * t4;
+    Sw[w_a2] = s * t1 + c * t3;
+    Sw[w_a3] = s * t2 + c * t4;
+    Vw[w_vp0] = c * vp0 - s * vq0;
+    Vw[w_vq0] = s * vp0 + c * vq0;
+    Vw[w_vp1] = c * vp1 - s * vq1;
+    Vw[w_vq1] = s * vp1 + c * vq1;
+    __syncthreads();
+  };
+  auto sweep_rounds = [&](auto PAR) {  // the N - 1 (odd) rounds of a sweep that starts in copy PAR and ends in the other
+    constexpr int P = decltype(PAR)::value;
+    for (int r = 0; r + 2 < N; r += 2) {
+      round(std::integral_constant<int, P>{});
+      round(std::integral_constant<int, 1 - P>{});
+    }
+    round(std::integral_constant<int, P>{});
+  };
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     double off = 0., tot = 0.;  // every wavefront forms the whole sum (same order, same bits: the exit below is uniform)
     for (int e = lane; e < N * N; e += 64) {
@@ -1730,43 +1772,9 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
 #if PSD_PROFILE
     prof[7] += 1.;
 #endif
-    for (int r = 0; r < N - 1; ++r) {
-      const double *Sr = SS + cur * SZ, *Vr = VV + cur * SZ;
-      double *Sw = SS + (cur ^ 1) * SZ, *Vw = VV + (cur ^ 1) * SZ;
-      const double apq = Sr[o_pq], app = Sr[o_pp], aqq = Sr[o_qq];
-      const double bpq = Sr[o_pq2], bpp = Sr[o_pp2], bqq = Sr[o_qq2];
-      const double a0 = Sr[o_a0], a1 = Sr[o_a1], a2 = Sr[o_a2], a3 = Sr[o_a3];
-      const double vp0 = Vr[o_vp0], vq0 = Vr[o_vq0], vp1 = Vr[o_vp1], vq1 = Vr[o_vq1];
-      double c, s, c2, s2;
-      {
-        const bool rot = fabs(apq) > 1e-300;
-        jacobi_rot(app, aqq, rot ? apq : 1.0, c, s);
-        c = rot ? c : 1.;
-        s = rot ? s : 0.;
-        const bool rot2 = fabs(bpq) > 1e-300;
-        jacobi_rot(bpp, bqq, rot2 ? bpq : 1.0, c2, s2);
-        c2 = rot2 ? c2 : 1.;
-        s2 = rot2 ? s2 : 0.;
-      }
-      const double t1 = c2 * a0 - s2 * a1, t2 = s2 * a0 + c2 * a1;
-      const double t3 = c2 * a2 - s2 * a3, t4 = s2 * a2 + c2 * a3;
-      if (bv) {
-        Sw[w_a0] = c * t1 - s * t3;
-        Sw[w_a1] = c * t2 - s * t4;
-        Sw[w_a2] = s * t1 + c * t3;
-        Sw[w_a3] = s * t2 + c * t4;
-      }
-      if (rv0) {
-        Vw[w_vp0] = c * vp0 - s * vq0;
-        Vw[w_vq0] = s * vp0 + c * vq0;
-      }
-      if (rv1) {
-        Vw[w_vp1] = c * vp1 - s * vq1;
-        Vw[w_vq1] = s * vp1 + c * vq1;
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
+    if (cur == 0) sweep_rounds(std::integral_constant<int, 0>{});
+    else sweep_rounds(std::integral_constant<int, 1>{});
+    cur ^= 1;
   }
 
   PSD_TICK(t_swept);

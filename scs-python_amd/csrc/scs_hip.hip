@@ -725,6 +725,7 @@ struct ScsHipWork {
   int n_soc = 0, n_soc_big = 0, soc_G = 64;  // soc_G: lanes per cone in k_proj_soc_wave (cones.hpp soc_group)
   DevBuf<double> pow_a, box_bl, box_bu;
   DevBuf<double> box_bl_orig, box_bu_orig, box_parts;
+  DevBuf<unsigned> cg_ticket;  // k_cg_update_dir's arrival counter (0 between launches)
   DevBuf<unsigned> box_ticket;  // the caller's bounds (the working copies follow the row scaling): footer diagnostics
   DevBuf<int> psd_off, psd_order;    // orders > kPsdSmallMax first (n_psd_big of them), then the small ones
   DevBuf<long> psd_woff;
@@ -1089,10 +1090,19 @@ struct ScsHipWork {
       HIP_CHECK(hipEventRecord(evs[2], stream));
     } else
     matvec(cg_p.p, fl.p + F_DONE, fl.p + F_STEP);
+    if (cg_fuse()) {  // small systems: update + direction as one launch (vec.hpp k_cg_update_dir; same bits)
+      hipLaunchKernelGGL(k_cg_update_dir, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, (const double *)cg_Gp.p,
+                         (const double *)cg_M.p, n, yacc, (const double *)tmp_m.p, m, (const double *)part.p, At.nwg(), sc.p, fl.p, part2.p,
+                         (const double *)gp2(), cg_ticket.p);
+      return;
+    }
     hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, cg_p.p, cg_Gp.p, cg_M.p, n, yacc,
                        tmp_m.p, m, part.p, At.nwg(), sc.p, fl.p, part2.p, (const double *)gp2());
     hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
   }
+  // SCS_HIP_CG_FUSE=0: always two launches
+  bool cg_fuse_on = [] { const char *e = getenv("SCS_HIP_CG_FUSE"); return !(e && e[0] == '0'); }();  // read when the workspace is made
+  bool cg_fuse() const { return cg_fuse_on && n <= kCgFuseMaxN; }
   void enqueue_flag_readback() {
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
   }
@@ -2210,6 +2220,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   w->g.alloc_zero(l, s);
   w->h.alloc_zero(l, s);
   for (DevBuf<double> *b : {&w->cg_b, &w->cg_p, &w->cg_r, &w->cg_Gp, &w->cg_M, &w->ws}) b->alloc_zero(n, s);
+  w->cg_ticket.alloc_zero(1, s);
   w->tmp_m.alloc_zero(m, s);
   w->ensure_solution_mirror();
   w->solx.alloc_zero(n, s);
@@ -3161,6 +3172,7 @@ static int kkt_solve_entry(const ScsMatrix *A, const ScsMatrix *P, const scs_flo
     std::copy(diag_r, diag_r + n + m, dr.begin());
     w.diag_r.upload(dr.data(), w.l, s);
     for (DevBuf<double> *b : {&w.cg_b, &w.cg_p, &w.cg_r, &w.cg_Gp, &w.cg_M, &w.ws}) b->alloc_zero(n, s);
+    w.cg_ticket.alloc_zero(1, s);
     w.tmp_m.alloc_zero(m, s);
     w.part.alloc_zero((size_t)std::max({w.At.nblk, w.Ar.nblk, w.At.nwg(), w.Ar.nwg(), kMaxVecBlocks}) * kMaxEpiReductions, s);
     w.part2.alloc_zero(2 * kMaxVecBlocks, s);

@@ -365,6 +365,56 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double 
   d_cg_dir(p, r, M, n, upd_part, upd_np, sc, fl);
 }
 
+// Small systems (n <= kCgFuseMaxN): k_cg_update and k_cg_dir as ONE launch.  A CG step of a 10 000-column system is four
+// launch-bound kernels; the direction update needs beta, i.e. the z'r partials of ALL workgroups of the update — so every
+// workgroup publishes its part (agent-scope release: the XCD L2s are not coherent with each other) and takes a ticket, and the
+// LAST arriver does what k_cg_dir does, for the whole vector (n is small: 128 elements per lane at most).  Nothing waits.
+// Same partials, same reduction order, same elementwise arithmetic as the two kernels: the same bits (the grouped path keeps two).
+constexpr int kCgFuseMaxN = 32768;
+__global__ __launch_bounds__(kVecThreads) void k_cg_update_dir(double *x, double *r, double *p, const double *__restrict__ Gp,
+                                                               const double *__restrict__ M, int n, double *yacc,
+                                                               const double *__restrict__ z, int m, const double *pgp_part, int pgp_np,
+                                                               double *sc, int *fl, double *part, const double *__restrict__ Gp2,
+                                                               unsigned *ticket) {
+  if (fl[F_DONE]) return;
+  __shared__ double sm[kVecThreads / 64];
+  __shared__ double bc[2];
+  __shared__ unsigned tk;
+  const int nb = (int)gridDim.x;
+  {
+    const double pGp = part_sum(pgp_part, pgp_np, sm);
+    if (threadIdx.x == 0) {
+      bc[0] = sc[(fl[F_STEP] & 1) ? S_ZTR_B : S_ZTR] / pGp;
+      if (blockIdx.x == 0) sc[S_ALPHA] = bc[0];
+    }
+    __syncthreads();
+  }
+  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc[0], part, (int)blockIdx.x, nb, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tk != (unsigned)nb - 1) return;
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int slot = fl[F_STEP] & 1;
+  {
+    const double rn = part_max(part, nb, sm);
+    const double ztr = part_sum(part + nb, nb, sm);
+    if (threadIdx.x == 0) {
+      bc[1] = ztr / sc[slot ? S_ZTR_B : S_ZTR];
+      sc[S_RNORM] = rn;
+      sc[S_BETA] = bc[1];
+      sc[slot ? S_ZTR : S_ZTR_B] = ztr;
+      fl[F_ITERS] += 1;
+      if (rn < sc[S_TOL]) fl[F_DONE] = 1;
+    }
+    __syncthreads();
+  }
+  const double beta = bc[1];
+  for (int i = threadIdx.x; i < n; i += kVecThreads) p[i] = M[i] * r[i] + beta * p[i];
+}
+
 // R-weighted dots for the tau quadratic (root_plus): [p'Rg, p'Rp, p'Rmu, mu'Rg] over the first l-1 entries
 __device__ __forceinline__ void d_tau_dots(const double *__restrict__ p, const double *__restrict__ mu,
                                            const double *__restrict__ g, const double *__restrict__ diag_r,

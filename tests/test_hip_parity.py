@@ -720,6 +720,44 @@ def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
 
 
+# ---- small systems: CG update + direction as one launch (vec.hpp k_cg_update_dir) vs the two kernels ----
+@pytest.mark.parametrize("case", ["lp_soc", "qp_mixed", "long_cg", "tall"])
+@pytest.mark.parametrize("pipeline", ["1", "0"], ids=["run-ahead", "graphs"])
+def test_fused_cg_update_dir_bit_identical(hip, oracle, monkeypatch, case, pipeline):
+    """n <= 32768: the last workgroup to finish the CG update forms beta from everybody's partials (agent-scope release /
+    acquire around a ticket) and updates the whole direction vector.  Same partials, same order, same elementwise
+    arithmetic: iterates, CG step counts and solutions must not depend on the switch — incl. a tall problem whose update
+    grid (sized by m) is many workgroups on several XCDs."""
+    proj = lambda z, K: oracle.proj_cone(z, K, dual=True)
+    stg = dict(STG)
+    stg.update(eps_abs=1e-7, eps_rel=1e-7, max_iters=600)
+    if case == "lp_soc":
+        K, n, k, seed = pg.workload("small_lp_soc")
+        data, _, _ = pg.gen_feasible(K, n, k, seed, proj)
+    elif case == "qp_mixed":
+        K = {"z": 10, "l": 600, "q": [30, 12, 5], "s": [6, 3], "ep": 4, "ed": 3, "p": [0.4, -0.7], "bu": [1.0] * 5, "bl": [-1.0] * 5}
+        data, _, _ = pg.gen_feasible_qp(K, 420, 7, 5, proj)
+    elif case == "long_cg":
+        K = {"z": 150, "l": 300}
+        data, _, _ = pg.gen_feasible(K, 200, 12, 9, proj)
+        stg.update(scale=25.0, adaptive_scale=False, acceleration_lookback=0)
+    else:  # 120 000 rows, 3000 columns: 118 update workgroups, one direction vector of 3000
+        K = {"l": 100000, "q": [20] * 1000}
+        data, _, _ = pg.gen_feasible(K, 3000, 6, 3, proj)
+        stg.update(max_iters=150)
+    args = helpers.raw_args(data, K)
+    monkeypatch.setenv("SCS_HIP_PIPELINE", pipeline)
+    sols = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_CG_FUSE", mode)
+        sols[mode] = hip.SCS(*args, **stg).solve(False, None, None, None)
+    a, b = sols["0"]["info"], sols["1"]["info"]
+    assert (a["iter"], a["cg_iters"], a["status"]) == (b["iter"], b["cg_iters"], b["status"])
+    assert a["cg_iters"] > 0
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
+
+
 # ---- scs_init's matrix work on the device (setup_dev.hpp) vs the host builders ----
 @pytest.mark.parametrize("cs", ["1", "0"], ids=["column-sorted", "slab"])
 def test_device_setup_matches_host_setup(hip, oracle, monkeypatch, cs):

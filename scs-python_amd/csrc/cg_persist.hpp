@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kVecThreads *NG) void k_cg_persist(CgPersistArgs a)
     alpha = ztr / all_sum(a.part, nbAt);  // k_cg_update prologue
     for (int it = 0; it < itU; ++it) {
       const int b = me + it * G;
-      cg_update_block(a.ut, a.r, a.p, a.Gp, a.M, n, a.ut + n, a.z, m, alpha, a.part2, b, nbu, tid, red[g], sync, b < nbu);
+      cg_update_block(a.ut, a.r, a.p, a.Gp, a.M, n, a.ut + n, a.z, m, [&]() { return alpha; }, a.part2, b, nbu, tid, red[g], sync, b < nbu);
     }
     gbar();
     rn = all_max(a.part2, nbu);  // k_cg_dir prologue

@@ -276,16 +276,42 @@ __global__ __launch_bounds__(kVecThreads) void k_fin_head(const double *prep_par
 // single-workgroup "finalize" launch sits between the SpMV and this kernel.  z'r comes from the slot of the
 // current CG step (two slots, selected by F_STEP, which workgroup 0 of the A kernel bumps once per step).
 // Body of one (virtual) block b of nb: shared with the persistent CG kernel (cg_persist.hpp).
-template <class Sync>
+// `alpha_of()` is called AFTER the first element of every lane's two loops has been requested: those loads do not depend on
+// alpha, so the reduction of the partials that alpha comes from (a dependent chain of ~2 us) no longer runs in front of an idle
+// memory pipe (round 4; same operations on the same operands in the same order: same bits).
+template <class Sync, class AlphaFn>
 __device__ __forceinline__ void cg_update_block(double *x, double *r, const double *__restrict__ p, const double *__restrict__ Gp,
                                                 const double *__restrict__ M, int n, double *yacc, const double *__restrict__ z,
-                                                int m, double alpha, double *part, int b, int nb, int tid, double *sm, Sync sync,
+                                                int m, AlphaFn alpha_of, double *part, int b, int nb, int tid, double *sm, Sync sync,
                                                 bool active = true, const double *__restrict__ Gp2 = nullptr) {
   double mx = 0., s = 0.;
+  const long i0 = (long)b * kVecThreads + tid, stride = (long)nb * kVecThreads;
+  const bool hy = active && yacc && i0 < m, hx = active && i0 < n;
+  double y0 = 0., z0 = 0., x0 = 0., p0 = 0., r0 = 0., g0 = 0., m0 = 0.;
+  if (hy) {
+    y0 = yacc[i0];
+    z0 = z[i0];
+  }
+  if (hx) {
+    x0 = x[i0];
+    p0 = p[i0];
+    r0 = r[i0];
+    g0 = Gp2 ? Gp[i0] + Gp2[i0] : Gp[i0];
+    m0 = M[i0];
+  }
+  const double alpha = alpha_of();
   if (active) {
+    if (hy) yacc[i0] = y0 + alpha * z0;
     if (yacc)
-      for (long i = (long)b * kVecThreads + tid; i < m; i += (long)nb * kVecThreads) yacc[i] += alpha * z[i];
-    for (long i = (long)b * kVecThreads + tid; i < n; i += (long)nb * kVecThreads) {
+      for (long i = i0 + stride; i < m; i += stride) yacc[i] += alpha * z[i];
+    if (hx) {
+      x[i0] = x0 + alpha * p0;
+      const double ri = r0 - alpha * g0;
+      r[i0] = ri;
+      mx = fmax(mx, abs_nan_inf(ri));
+      s += (m0 * ri) * ri;
+    }
+    for (long i = i0 + stride; i < n; i += stride) {
       x[i] += alpha * p[i];
       const double ri = r[i] - alpha * (Gp2 ? Gp[i] + Gp2[i] : Gp[i]);
       r[i] = ri;
@@ -308,15 +334,16 @@ __device__ __forceinline__ void d_cg_update(double *x, double *r, const double *
   if (fl[F_DONE]) return;
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc;
-  {
+  auto alpha_of = [&]() {
     const double pGp = part_sum(pgp_part, pgp_np, sm);
     if (threadIdx.x == 0) {
       bc = sc[(fl[F_STEP] & 1) ? S_ZTR_B : S_ZTR] / pGp;
       if (blockIdx.x == 0) sc[S_ALPHA] = bc;
     }
     __syncthreads();
-  }
-  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
+    return bc;
+  };
+  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, alpha_of, part, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
 }
 __global__ __launch_bounds__(kVecThreads) void k_cg_update(double *x, double *r, const double *__restrict__ p,
                                                            const double *__restrict__ Gp,
@@ -338,6 +365,15 @@ __device__ __forceinline__ void d_cg_dir(double *p, const double *__restrict__ r
   __shared__ double sm[kVecThreads / 64];
   __shared__ double bc[2];
   const int slot = fl[F_STEP] & 1;
+  // the first element of every lane is requested before the partials are reduced (it does not depend on beta)
+  const long i0 = (long)blockIdx.x * kVecThreads + threadIdx.x, stride = (long)gridDim.x * kVecThreads;
+  const bool h0 = i0 < n;
+  double m0 = 0., r0 = 0., p0 = 0.;
+  if (h0) {
+    m0 = M[i0];
+    r0 = r[i0];
+    p0 = p[i0];
+  }
   {
     const double rn = part_max(upd_part, upd_np, sm);
     const double ztr = part_sum(upd_part + upd_np, upd_np, sm);
@@ -355,8 +391,8 @@ __device__ __forceinline__ void d_cg_dir(double *p, const double *__restrict__ r
     __syncthreads();
   }
   const double beta = bc[0];
-  for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads)
-    p[i] = M[i] * r[i] + beta * p[i];
+  if (h0) p[i0] = m0 * r0 + beta * p0;
+  for (long i = i0 + stride; i < n; i += stride) p[i] = M[i] * r[i] + beta * p[i];
 }
 __global__ __launch_bounds__(kVecThreads) void k_cg_dir(double *p, const double *__restrict__ r,
                                                         const double *__restrict__ M, int n,
@@ -381,15 +417,16 @@ __global__ __launch_bounds__(kVecThreads) void k_cg_update_dir(double *x, double
   __shared__ double bc[2];
   __shared__ unsigned tk;
   const int nb = (int)gridDim.x;
-  {
+  auto alpha_of = [&]() {
     const double pGp = part_sum(pgp_part, pgp_np, sm);
     if (threadIdx.x == 0) {
       bc[0] = sc[(fl[F_STEP] & 1) ? S_ZTR_B : S_ZTR] / pGp;
       if (blockIdx.x == 0) sc[S_ALPHA] = bc[0];
     }
     __syncthreads();
-  }
-  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, bc[0], part, (int)blockIdx.x, nb, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
+    return bc[0];
+  };
+  cg_update_block(x, r, p, Gp, M, n, yacc, z, m, alpha_of, part, (int)blockIdx.x, nb, (int)threadIdx.x, sm, BlockSync{}, true, Gp2);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

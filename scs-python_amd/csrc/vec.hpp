@@ -44,6 +44,7 @@ enum : int {
 enum : int { P_DO_SCALE = 0, P_RES_MIN, P_IPOW, P_FIRST, P_PSD_TOL2, P_COUNT = 8 };
 
 __host__ __device__ inline int vec_blocks(long n) {
+  // (round 4 A/B on the metric workload: 8 per lane already from 2^19, or 16 per lane beyond 2^20 / 2^21, are 1-2 % slower)
   const long per = (n > kVecLong ? 8L : 4L) * kVecThreads;
   long nb = (n + per - 1) / per;
   if (nb < 1) nb = 1;

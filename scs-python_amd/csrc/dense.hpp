@@ -187,28 +187,47 @@ __device__ __forceinline__ void d_gj_update(DenseMat D, int k) {
   const bool colpanel = J == k;
   const double *Bop = colpanel ? D.Pk : D.Rt + J0;  // B[j][kk] at Bop[j + ldb kk]   (P_k is symmetric)
   const size_t ldb = colpanel ? (size_t)kDenseB : ld;
-  const double *pa = D.L + (I0 + wave * 16 + li) + ld * lk;
-  const double *pb = Bop + li + ldb * lk;
+  // Round 4: the two 64 x 64 operand panels go through LDS, half of the k range at a time (two 16-byte loads per lane and panel,
+  // every line read once per workgroup instead of once per wavefront and MFMA operand: the first version fetched 5 operands of
+  // 8 bytes per lane for every 4 MFMAs straight from L2 and ran at 0.21 of the fp64 matrix peak).  Row stride 72: the four k-slices
+  // a wavefront reads fall on different bank halves.  Same MFMAs in the same order: same bits.
+  constexpr int KH = kDenseB / 2, LDT = kDenseB + 8;
+  __shared__ double As[KH][LDT], Bs[KH][LDT];
+  const int r2 = (tid & 31) * 2, c8 = tid >> 5;  // this lane stages rows r2, r2 + 1 of the columns c8 + 8 t
+  const double *ga = D.L + (I0 + r2), *gb = Bop + r2;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));  // (HIP's double2 in an array lands in scratch memory)
+  dbl2 va[4], vb[4];
+  auto fetch_half = [&](int half) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = KH * half + c8 + 8 * t;
+      va[t] = *reinterpret_cast<const dbl2 *>(ga + ld * c);
+      vb[t] = *reinterpret_cast<const dbl2 *>(gb + ldb * c);
+    }
+  };
+  auto stage_half = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      *reinterpret_cast<dbl2 *>(&As[c8 + 8 * t][r2]) = va[t];
+      *reinterpret_cast<dbl2 *>(&Bs[c8 + 8 * t][r2]) = vb[t];
+    }
+  };
   f64x4 acc[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) acc[jt] = f64x4{0., 0., 0., 0.};
-  constexpr int PF = 4;  // k-steps in flight; every load unconditional (a conditional load makes hipcc wait with vmcnt(0): DESIGN §4)
-  double as[PF], bs[PF][4];
-  auto fetch = [&](int st, int k0) {
-    as[st] = pa[ld * k0];
+  fetch_half(0);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) bs[st][jt] = pb[jt * 16 + ldb * k0];
-  };
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();  // every wavefront is done with the first half of the panels
+    stage_half();
+    if (half == 0) fetch_half(1);  // in flight while the first half is multiplied
+    __syncthreads();
 #pragma unroll
-  for (int st = 0; st < PF; ++st) fetch(st, 4 * st);
-  for (int k0 = 0; k0 < kDenseB; k0 += 4 * PF) {
-#pragma unroll
-    for (int st = 0; st < PF; ++st) {
-      const double a = as[st];
+    for (int k0 = 0; k0 < KH; k0 += 4) {
+      const double a = As[k0 + lk][wave * 16 + li];
       double b[4];
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) b[jt] = bs[st][jt];
-      fetch(st, min(k0 + 4 * st + 4 * PF, kDenseB - 4));
+      for (int jt = 0; jt < 4; ++jt) b[jt] = Bs[k0 + lk][jt * 16 + li];
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[jt], a, acc[jt], 0, 0, 0);
     }

@@ -216,6 +216,13 @@ __device__ __forceinline__ void d_gj_update(DenseMat D, int k) {
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) acc[jt] = f64x4{0., 0., 0., 0.};
   fetch_half(0);
+  // the tile's own entries are requested now and used after the products (unconditional: the column panel's are simply not used)
+  double *gdst = D.G + (I0 + wave * 16 + li) + ld * (J0 + lk);
+  double gold[4][4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gold[jt][t] = gdst[ld * (jt * 16 + 4 * t)];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (half) __syncthreads();  // every wavefront is done with the first half of the panels
@@ -236,10 +243,7 @@ __device__ __forceinline__ void d_gj_update(DenseMat D, int k) {
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      double *dst = D.G + (I0 + wave * 16 + li) + ld * (J0 + jt * 16 + lk + 4 * t);
-      *dst = colpanel ? -acc[jt][t] : *dst - acc[jt][t];
-    }
+    for (int t = 0; t < 4; ++t) gdst[ld * (jt * 16 + 4 * t)] = colpanel ? -acc[jt][t] : gold[jt][t] - acc[jt][t];
 }
 
 // ---- x = G^{-1} b: one wavefront per column j of the (symmetric) inverse, y_j = sum_i Ginv[i][j] b_i, fixed shuffle tree

@@ -457,7 +457,7 @@ struct GroupSolve {
     t_sumsq.gx = t_prep.gx = t_cone_pre.gx = t_v_update.gx = t_rsk.gx = t_set_diag_r.gx = t_v_rescale.gx = nbl;
     t_spmv_y.gx = t_spmv_a.gx = t_res_pri.gx = t_spmv_ax.gx = t_dense_y.gx = gx_ar;
     t_spmv_r0.gx = t_spmv_at.gx = t_res_dual.gx = t_spmv_rhs.gx = t_dense_rhs.gx = gx_at;
-    t_dense_gemv.gx = t_dense_gemv_kkt.gx = ceil_div(n, kDenseThreads / 64);
+    t_dense_gemv.gx = t_dense_gemv_kkt.gx = dense_gemv_blocks(n);
     t_symv_tiles.gx = dense ? dense_symv_tiles(dn_NP) : 1;
     t_symv_sum.gx = t_symv_sum_kkt.gx = ceil_div(n, kDenseThreads);
     if (dense) {  // the members' matrices as the batched factorisation kernels take them

@@ -246,18 +246,41 @@ __device__ __forceinline__ void d_gj_update(DenseMat D, int k) {
     for (int t = 0; t < 4; ++t) gdst[ld * (jt * 16 + 4 * t)] = colpanel ? -acc[jt][t] : gold[jt][t] - acc[jt][t];
 }
 
-// ---- x = G^{-1} b: one wavefront per column j of the (symmetric) inverse, y_j = sum_i Ginv[i][j] b_i, fixed shuffle tree
+// ---- x = G^{-1} b: one wavefront per FOUR columns j of the (symmetric) inverse, y_j = sum_i Ginv[i][j] b_i, fixed order: a lane adds
+// its rows 2 l, 2 l + 1, 2 l + 128, ... in ascending order, then the fixed shuffle tree.  (Round 4: 16-byte loads of the four
+// columns against one pair of b entries — 6 memory instructions per 4 x 128 entries where one column per wavefront needed 16; a
+// batch of 512 members streams 8 GB of inverses per lock-step iteration through this kernel.)
+constexpr int kDenseGemvCols = 4;
+inline int dense_gemv_blocks(int n) { return ceil_div(n, kDenseGemvCols * (kDenseThreads / 64)); }
 __device__ __forceinline__ void d_dense_gemv(const double *__restrict__ Ginv, int NP, int n, const double *__restrict__ b, double *x,
                                              const int *stall) {
   SCS_STALL_GUARD(stall);
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x * (kDenseThreads / 64) + wave;
-  if (j >= n) return;
-  const double *col = Ginv + (size_t)NP * j;
-  double s = 0.;
-  for (int i = lane; i < n; i += 64) s += col[i] * b[i];
-  s = wave_sum(s);
-  if (lane == 0) x[j] = s;
+  const int j0 = (blockIdx.x * (kDenseThreads / 64) + wave) * kDenseGemvCols;
+  if (j0 >= n) return;
+  // (j0 + 3 < NP: NP is a multiple of 64 >= n; rows up to NP - 1 exist too: the padding is the identity)
+  const double *c0 = Ginv + (size_t)NP * j0 + 2 * lane;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+  for (int i = 2 * lane; i < n; i += 128, c0 += 128) {
+    const double b0 = b[i], b1 = i + 1 < n ? b[i + 1] : 0.;
+    const dbl2 a0 = *reinterpret_cast<const dbl2 *>(c0), a1 = *reinterpret_cast<const dbl2 *>(c0 + NP);
+    const dbl2 a2 = *reinterpret_cast<const dbl2 *>(c0 + 2 * (size_t)NP), a3 = *reinterpret_cast<const dbl2 *>(c0 + 3 * (size_t)NP);
+    s0 += a0.x * b0; s0 += a0.y * b1;
+    s1 += a1.x * b0; s1 += a1.y * b1;
+    s2 += a2.x * b0; s2 += a2.y * b1;
+    s3 += a3.x * b0; s3 += a3.y * b1;
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  s3 = wave_sum(s3);
+  if (lane == 0) {
+    x[j0] = s0;
+    if (j0 + 1 < n) x[j0 + 1] = s1;
+    if (j0 + 2 < n) x[j0 + 2] = s2;
+    if (j0 + 3 < n) x[j0 + 3] = s3;
+  }
 }
 
 // ---- x = G^{-1} b reading only the tiles on and below the diagonal (the inverse is symmetric; a batch of 512 config-5 members streams

@@ -971,7 +971,7 @@ struct ScsHipWork {
   }
   void dense_gemv(const double *b, double *x, const int *st) {
     if (dense_full_gemv())
-      hipLaunchKernelGGL(k_dense_gemv, dim3(ceil_div(n, kDenseThreads / 64)), dim3(kDenseThreads), 0, stream, (const double *)dn_G.p, dn_NP, n, b, x, st);
+      hipLaunchKernelGGL(k_dense_gemv, dim3(dense_gemv_blocks(n)), dim3(kDenseThreads), 0, stream, (const double *)dn_G.p, dn_NP, n, b, x, st);
     else
       dense_apply(dn_G.p, dn_NP, n, b, dn_part.p, x, st, stream);
   }

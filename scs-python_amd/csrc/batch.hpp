@@ -205,6 +205,7 @@ struct GroupSolve {
   static constexpr int kListSlots = 64;
   int list_slot = 0, lists_since_sync = 0;
   const int *active_d = nullptr;  // device copy of `active`
+  double t_finish = 0.;           // host time inside finish_solve (SCS_HIP_GROUP_STATS)
   std::vector<int> active;
 
   // per-member host state of this solve
@@ -874,7 +875,9 @@ struct GroupSolve {
         const bool ends = stop[(size_t)g] || i == W[(size_t)g]->stgs.max_iters - 1;
         if (!ends) continue;
         const int iters = stop[(size_t)g] ? i : i + 1;
+        const double tf0 = now_ms();
         W[(size_t)g]->finish_solve(sols[(size_t)g], infos[(size_t)g], iters, t_start, t_lin, t_cone, t_acc, /*grouped=*/true);
+        t_finish += now_ms() - tf0;
         finished.push_back(g);
       }
       if (!finished.empty()) {
@@ -888,8 +891,8 @@ struct GroupSolve {
     }
     HIP_CHECK(hipStreamSynchronize(s));
     if (getenv("SCS_HIP_GROUP_STATS"))
-      std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %.1f ms\n",
-                   G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, now_ms() - t_start);
+      std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %.1f ms (%.1f ms of it finishing members: un-scaling, s'y, downloads)\n",
+                   G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, now_ms() - t_start, t_finish);
   }
 };
 

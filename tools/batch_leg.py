@@ -15,6 +15,8 @@ proj = lambda z, K: _scs_hip.proj_cone(z, K, dual=True)
 Kb, nb_, kb_, seedb = pg.workload("config5_small")
 t = time.perf_counter()
 extra = {"max_iters": int(os.environ["MAXIT"])} if os.environ.get("MAXIT") else {}
+if os.environ.get("NORMALIZE"):
+    extra["normalize"] = bool(int(os.environ["NORMALIZE"]))   # lab: NORMALIZE=0 shows what the equilibration launches cost scs_init
 if os.environ.get("LINSYS"):
     extra["linear_solver"] = os.environ["LINSYS"]   # hip_dense / hip_indirect
 problems = [(pg.gen_feasible(Kb, nb_, kb_, seedb + i, proj)[0], Kb, dict(verbose=False, **extra)) for i in range(N)]

@@ -166,6 +166,7 @@ def main():
     # before ANY HIP runtime is loaded (torch's comes first): the same default scs._scs_hip sets — see its _runtime_env
     if os.environ.get("SCS_HIP_RUNTIME_ENV", "1") != "0":
         os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (exported on the GPU boxes already: RCCL between ranks needs dmabuf IPC there)
     import torch  # first: its bundled HIP runtime must be the one in the process
     import torch.distributed as dist
     import numpy as np

@@ -91,6 +91,16 @@ struct GTable {
 template <auto Fn, int Threads, class... A> GTable<Fn, Threads, A...> gtable_of(void (*)(A...));
 #define SCS_GTABLE(threads, ...) decltype(gtable_of<__VA_ARGS__, threads>(__VA_ARGS__))
 
+// table bodies take their workgroup index from the launch
+__device__ __forceinline__ void d_soc_wave_blk(double *x, const int *__restrict__ off, const int *__restrict__ dim, int ncones, int G,
+                                               const int *stall) {
+  d_proj_soc_wave(x, off, dim, ncones, G, stall, (int)blockIdx.x);
+}
+__device__ __forceinline__ void d_psd_small4_blk(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall,
+                                                 const double *tol2) {
+  d_proj_psd_small4(x, B, scratch, allow_warm, stall, tol2, (int)blockIdx.x);
+}
+
 // ---- small bodies only the grouped path needs (the one-problem path uses hipMemset / hipMemcpy for these) ----
 __device__ __forceinline__ void d_copy_f64(const double *__restrict__ src, double *dst, long n) {
   for (long i = (long)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (long)gridDim.x * kVecThreads) dst[i] = src[i];
@@ -137,8 +147,9 @@ struct GroupSolve {
   SCS_GTABLE(kVecThreads, d_tau_dots) t_tau_dots;
   SCS_GTABLE(kVecThreads, d_cone_pre) t_cone_pre;
   SCS_GTABLE(kBoxThreads, d_proj_box) t_box;
-  SCS_GTABLE(kConeThreads, d_proj_soc_wave) t_soc;
-  SCS_GTABLE(kPsdSmallThreads, d_proj_psd_small4) t_psd;
+  SCS_GTABLE(kConeThreads, d_soc_wave_blk) t_soc;
+  SCS_GTABLE(kPsdSmallThreads, d_psd_small4_blk) t_psd;
+  SCS_GTABLE(kPsdSmallThreads, d_proj_soc_psd_small) t_soc_psd;  // both in one launch (members with short SOCs and small PSD matrices)
   SCS_GTABLE(kConeThreads, d_proj_exp) t_exp_p, t_exp_d;
   SCS_GTABLE(kConeThreads, d_proj_pow_dual) t_pow;
   SCS_GTABLE(kVecThreads, d_v_update) t_v_update;
@@ -204,6 +215,7 @@ struct GroupSolve {
   int *flags_h = nullptr, *lists_h = nullptr, *active_h = nullptr;  // (all pinned: every copy here is asynchronous)
   static constexpr int kListSlots = 64;
   int list_slot = 0, lists_since_sync = 0;
+  bool soc_psd_fused = false;     // short SOCs and small PSD matrices of a member in one launch
   const int *active_d = nullptr;  // device copy of `active`
   double t_finish = 0.;           // host time inside finish_solve (SCS_HIP_GROUP_STATS)
   std::vector<int> active;
@@ -335,8 +347,12 @@ struct GroupSolve {
     if (has_P) size_all(t_spmv_pws, t_spmv_p, t_res_px);
     if (dense) size_all(t_dense_rhs, t_dense_gemv, t_dense_gemv_kkt, t_dense_y, t_symv_tiles, t_symv_sum, t_symv_sum_kkt);
     if (c0.bsize > 0) t_box.resize((size_t)G);
-    if (w0->n_soc > 0) t_soc.resize((size_t)G);
-    if (w0->n_psd > 0) t_psd.resize((size_t)G);
+    soc_psd_fused = w0->soc_psd_one_launch && w0->n_soc > 0 && w0->n_psd > 0 && !w0->psd_small_one_wave;  // (member_ok: nothing big)
+    if (soc_psd_fused) t_soc_psd.resize((size_t)G);
+    else {
+      if (w0->n_soc > 0) t_soc.resize((size_t)G);
+      if (w0->n_psd > 0) t_psd.resize((size_t)G);
+    }
     if (c0.ep > 0) t_exp_p.resize((size_t)G);
     if (c0.ed > 0) t_exp_d.resize((size_t)G);
     if (!c0.p.empty()) t_pow.resize((size_t)G);
@@ -398,6 +414,10 @@ struct GroupSolve {
       t_cone_pre.set(g, w->ut.p, w->u.p, w->v.p, w->g.p, n, m, w->cone.z, w->cone.l, par, w->sc.p, w->part.p, nbl1, w->diag_r.p,
                      nullptr);
       if (t_box.used) t_box.set(g, uy + w->cone.off_box, w->box_bl.p, w->box_bu.p, w->cone.bsize, w->sc.p + S_BOX_T, 1, nostall);
+      if (t_soc_psd.used)
+        t_soc_psd.set(g, uy, w->soc_off.p, w->soc_dim.p, w->n_soc, w->soc_G, soc_wave_blocks(w->n_soc, w->soc_G),
+                      PsdBatch{w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd}, w->psd_scratch.p, w->psd_warm, nostall,
+                      (const double *)(par + P_PSD_TOL2));
       if (t_soc.used) t_soc.set(g, uy, w->soc_off.p, w->soc_dim.p, w->n_soc, w->soc_G, nostall);
       if (t_psd.used)
         t_psd.set(g, uy, PsdBatch{w->psd_off.p, w->psd_order.p, w->psd_woff.p, w->n_psd}, w->psd_scratch.p, w->psd_warm, nostall,
@@ -477,6 +497,7 @@ struct GroupSolve {
     t_kkt_prep.gx = t_kkt_y.gx = nbm;
     t_soc.gx = soc_wave_blocks(w0->n_soc, w0->soc_G);
     t_psd.gx = w0->n_psd;
+    t_soc_psd.gx = t_soc.gx + t_psd.gx;
     t_exp_p.gx = ceil_div(c0.ep, kConeThreads);
     t_exp_d.gx = ceil_div(c0.ed, kConeThreads);
     t_pow.gx = ceil_div((long)c0.p.size(), kConeThreads);
@@ -493,7 +514,7 @@ struct GroupSolve {
   template <class F> void for_tables(F &&f) {
     f(t_sumsq); f(t_prep); f(t_spmv_y); f(t_spmv_pws); f(t_spmv_p); f(t_res_px); f(t_spmv_ax); f(t_spmv_r0); f(t_fin_head);
     f(t_spmv_a); f(t_spmv_at); f(t_cg_update[0]); f(t_cg_update[1]); f(t_cg_dir[0]); f(t_cg_dir[1]); f(t_tau_dots);
-    f(t_cone_pre); f(t_box); f(t_soc); f(t_psd); f(t_exp_p); f(t_exp_d); f(t_pow); f(t_v_update); f(t_rsk); f(t_res_pri);
+    f(t_cone_pre); f(t_box); f(t_soc); f(t_psd); f(t_soc_psd); f(t_exp_p); f(t_exp_d); f(t_pow); f(t_v_update); f(t_rsk); f(t_res_pri);
     f(t_res_dual); f(t_fin_multi_p); f(t_fin_multi_d); f(t_gather_res); f(t_gather_fl); f(t_set_diag_r); f(t_precond);
     f(t_g_rhs); f(t_kkt_prep); f(t_spmv_rhs); f(t_zero_part); f(t_fin_tol); f(t_cg_init); f(t_fin_cg_init); f(t_zero_iters);
     f(t_kkt_y); f(t_copy_g); f(t_gather_aa); f(t_gg); f(t_fin_gg); f(t_v_rescale); f(t_aa_seed); f(t_aa_update);
@@ -574,6 +595,7 @@ struct GroupSolve {
 
   void enqueue_cones(const int *list, int count) {
     go(t_box, list, count);
+    go(t_soc_psd, list, count);
     go(t_soc, list, count);
     go(t_psd, list, count);
     go(t_exp_p, list, count);

@@ -36,10 +36,10 @@ __host__ __device__ inline int soc_group(int max_small_q) {
   return tail > 32 ? 64 : tail > 16 ? 32 : tail > 8 ? 16 : 8;
 }
 __device__ __forceinline__ void d_proj_soc_wave(double *x, const int *__restrict__ off,
-                                                const int *__restrict__ dim, int ncones, int G, const int *stall) {
+                                                const int *__restrict__ dim, int ncones, int G, const int *stall, int blk) {
   SCS_STALL_GUARD(stall);
   const int lane = threadIdx.x & 63, gl = lane & (G - 1);
-  const int wave = blockIdx.x * (kConeThreads / 64) + (threadIdx.x >> 6);
+  const int wave = blk * (kConeThreads / 64) + (threadIdx.x >> 6);
   const int c = wave * (64 / G) + lane / G;
   const bool live = c < ncones;
   const int q = live ? dim[c] : 0;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void d_proj_soc_wave(double *x, const int *__restrict
 __global__ __launch_bounds__(kConeThreads) void k_proj_soc_wave(double *x, const int *__restrict__ off,
                                                                 const int *__restrict__ dim, int ncones, int G,
                                                                 const int *stall) {
-  d_proj_soc_wave(x, off, dim, ncones, G, stall);
+  d_proj_soc_wave(x, off, dim, ncones, G, stall, (int)blockIdx.x);
 }
 // workgroups of k_proj_soc_wave for ncones cones in groups of G lanes
 inline int soc_wave_blocks(int ncones, int G) { return ceil_div(ceil_div(ncones, 64 / G), kConeThreads / 64); }

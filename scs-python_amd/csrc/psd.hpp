@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "cones.hpp"
 
 #ifndef PSD_INNER
 #define PSD_INNER 1
@@ -1609,12 +1610,12 @@ __device__ __forceinline__ int psd_small_next_pos(int a, int H) {
   return kk == H - 1 ? 2 * H - 1 : 2 * kk + 2;
 }
 __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
-                                                  const int *stall, const double *tol2) {
+                                                  const int *stall, const double *tol2, int cidx) {
   SCS_STALL_GUARD(stall);
   constexpr int NT = kPsdSmallThreads, SZ = 32 * kPsdSLd;
   const double offtol2 = psd_offtol2(tol2);
   __shared__ double SS[2 * SZ], VV[2 * SZ], T[SZ];
-  const int tid = threadIdx.x, cidx = blockIdx.x;
+  const int tid = threadIdx.x;
   const int n = B.order[cidx];
   double *X = x + B.off[cidx];
   if (n == 0) return;
@@ -1819,7 +1820,24 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
 }
 __global__ __launch_bounds__(kPsdSmallThreads) void k_proj_psd_small4(double *x, PsdBatch B, double *scratch, int allow_warm,
                                                                       const int *stall, const double *tol2) {
-  d_proj_psd_small4(x, B, scratch, allow_warm, stall, tol2);
+  d_proj_psd_small4(x, B, scratch, allow_warm, stall, tol2, (int)blockIdx.x);
+}
+
+// Short second-order cones and small PSD matrices in ONE launch (both project slices of the same vector in place and are independent
+// of each other): workgroups [0, soc_blocks) run d_proj_soc_wave, the others one matrix each.  A lone config-5 problem's iteration is
+// nine dependent launches of a few microseconds; this is one less (same bodies: same bits).
+static_assert(kConeThreads == kPsdSmallThreads, "one launch geometry for both bodies");
+__device__ __forceinline__ void d_proj_soc_psd_small(double *x, const int *__restrict__ soc_off, const int *__restrict__ soc_dim, int n_soc,
+                                                     int soc_G, int soc_blocks, PsdBatch B, double *scratch, int allow_warm,
+                                                     const int *stall, const double *tol2) {
+  if ((int)blockIdx.x < soc_blocks) d_proj_soc_wave(x, soc_off, soc_dim, n_soc, soc_G, stall, (int)blockIdx.x);
+  else d_proj_psd_small4(x, B, scratch, allow_warm, stall, tol2, (int)blockIdx.x - soc_blocks);
+}
+__global__ __launch_bounds__(kPsdSmallThreads) void k_proj_soc_psd_small(double *x, const int *__restrict__ soc_off,
+                                                                         const int *__restrict__ soc_dim, int n_soc, int soc_G, int soc_blocks,
+                                                                         PsdBatch B, double *scratch, int allow_warm, const int *stall,
+                                                                         const double *tol2) {
+  d_proj_soc_psd_small(x, soc_off, soc_dim, n_soc, soc_G, soc_blocks, B, scratch, allow_warm, stall, tol2);
 }
 
 // ---------------------------------------------------------------------------

@@ -802,6 +802,8 @@ struct ScsHipWork {
   // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
   // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
   // small matrices (order <= 32): four wavefronts per matrix (psd.hpp d_proj_psd_small4); SCS_HIP_PSD_SMALL_WAVES=1: the one-wavefront kernel (lab; agrees to rounding)
+  // SCS_HIP_SOC_PSD_FUSE=0: separate launches for short SOCs and small PSD matrices (same bits)
+  bool soc_psd_one_launch = [] { const char *e = getenv("SCS_HIP_SOC_PSD_FUSE"); return !(e && e[0] == '0'); }();
   bool psd_small_one_wave = [] { const char *e = getenv("SCS_HIP_PSD_SMALL_WAVES"); return e && e[0] == '1'; }();
   int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
   // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
@@ -1499,14 +1501,20 @@ struct ScsHipWork {
       hipLaunchKernelGGL(k_proj_box, dim3(1), dim3(kBoxThreads), 0, stream, y + cone.off_box, box_bl.p, box_bu.p, cone.bsize,
                          sc.p + S_BOX_T, dual, stall);
     }
-    if (n_soc > 0) {  // self-dual
+    // short SOCs + small PSD matrices (nothing big of either kind): one launch for both (psd.hpp k_proj_soc_psd_small)
+    const bool soc_psd_fused = soc_psd_one_launch && n_soc > 0 && n_soc_big == 0 && n_psd > 0 && n_psd_big == 0 && !psd_small_one_wave;
+    if (soc_psd_fused) {
+      const int sb = soc_wave_blocks(n_soc, soc_G);
+      hipLaunchKernelGGL(k_proj_soc_psd_small, dim3(sb + n_psd), dim3(kPsdSmallThreads), 0, stream, y, soc_off.p, soc_dim.p, n_soc, soc_G, sb,
+                         PsdBatch{psd_off.p, psd_order.p, psd_woff.p, n_psd}, psd_scratch.p, psd_warm, stall, psd_tol2);
+    } else if (n_soc > 0) {  // self-dual
       hipLaunchKernelGGL(k_proj_soc_wave, dim3(soc_wave_blocks(n_soc, soc_G)), dim3(kConeThreads), 0, stream, y,
                          soc_off.p, soc_dim.p, n_soc, soc_G, stall);
       if (n_soc_big > 0)
         hipLaunchKernelGGL(k_proj_soc_block, dim3(n_soc_big), dim3(kConeThreads), 0, stream, y, soc_off.p, soc_dim.p,
                            soc_big.p, n_soc_big, stall);
     }
-    if (n_psd > 0) launch_psd(y, psd_off.p, psd_order.p, psd_woff.p, n_psd, n_psd_big);  // self-dual
+    if (n_psd > 0 && !soc_psd_fused) launch_psd(y, psd_off.p, psd_order.p, psd_woff.p, n_psd, n_psd_big);  // self-dual
     if (n_cs > 0) {  // Hermitian PSD: self-dual
       CsBatch C{cs_off.p, cs_order.p, cs_soff.p, n_cs};
       hipLaunchKernelGGL(k_cs_expand, dim3(n_cs), dim3(256), 0, stream, y, C, cs_stage.p, stall);

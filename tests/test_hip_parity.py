@@ -758,6 +758,26 @@ def test_fused_cg_update_dir_bit_identical(hip, oracle, monkeypatch, case, pipel
         np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
 
 
+# ---- short SOCs + small PSD matrices in one launch (psd.hpp k_proj_soc_psd_small) vs two ----
+@pytest.mark.parametrize("linsys", ["indirect", "dense"])
+def test_soc_and_small_psd_in_one_launch_bit_identical(hip, oracle, monkeypatch, linsys):
+    """the same two bodies, selected by the workgroup index: iterates, counts and solutions must not depend on the switch
+    (config-5-shaped cone: l + 20 SOCs of 50 + 5 PSD matrices of order 20, plus ragged small ones)"""
+    import scs
+    proj = lambda z, K: oracle.proj_cone(z, K, dual=True)
+    K = {"l": 200, "q": [50] * 20 + [3, 1, 7], "s": [20] * 5 + [2, 1, 9]}
+    data, _, _ = pg.gen_feasible(K, 300, 6, 17, proj)
+    ls = scs.LinearSolver.HIP_DENSE if linsys == "dense" else scs.LinearSolver.HIP_INDIRECT
+    sols = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_SOC_PSD_FUSE", mode)
+        sols[mode] = scs.SCS(data, K, linear_solver=ls, verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iters=800).solve()
+    a, b = sols["0"]["info"], sols["1"]["info"]
+    assert (a["iter"], a["cg_iters"], a["status"]) == (b["iter"], b["cg_iters"], b["status"]) and a["iter"] > 50
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(sols["0"][key], sols["1"][key], err_msg=key)
+
+
 # ---- scs_init's matrix work on the device (setup_dev.hpp) vs the host builders ----
 @pytest.mark.parametrize("cs", ["1", "0"], ids=["column-sorted", "slab"])
 def test_device_setup_matches_host_setup(hip, oracle, monkeypatch, cs):

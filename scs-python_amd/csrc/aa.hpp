@@ -454,35 +454,61 @@ __device__ __forceinline__ void d_aa_solve(const double *__restrict__ R, int len
     w[j] = s;
   }
   __syncthreads();
+  __shared__ double reg_s;
+  __shared__ int piv_s, sing_s;
   if (lane == 0) {
     double nrm = 0.;
     for (int j = 0; j < len; ++j)
       for (int i = 0; i < len; ++i) nrm += M[i + len * j] * M[i + len * j];
-    const double reg = regularization * sqrt(nrm);
-    if (regularization > 0)
-      for (int i = 0; i < len; ++i) M[i + len * i] += reg;
-    int rank = 0;
-    bool singular = false;
-    for (int k = 0; k < len && !singular; ++k) {
+    reg_s = regularization * sqrt(nrm);
+    sing_s = 0;
+  }
+  __syncthreads();
+  const double reg = reg_s;
+  if (regularization > 0 && lane < len) M[lane + len * lane] += reg;
+  __syncthreads();
+  // LU with partial pivoting.  Round 4: the row swap and the elimination of a step run across the lanes (every entry still goes
+  // through the same operations in the same order: same bits as the one-lane loop, which took 36 us for a 10 x 10 system — a
+  // chain of dependent LDS read-modify-writes); the pivot scan keeps its sequential first-maximum / NaN semantics on lane 0.
+  int rank = 0;
+  for (int k = 0; k < len; ++k) {
+    if (lane == 0) {
       int piv = k;
       double mx = fabs(M[k + len * k]);
       for (int i = k + 1; i < len; ++i) {
         const double a = fabs(M[i + len * k]);
         if (a > mx) { mx = a; piv = i; }
       }
-      if (!(mx > 0.) || !isfinite(mx)) { singular = true; break; }
-      rank++;
-      if (piv != k) {
-        for (int j = 0; j < len; ++j) { const double t = M[k + len * j]; M[k + len * j] = M[piv + len * j]; M[piv + len * j] = t; }
-        const double t = w[k]; w[k] = w[piv]; w[piv] = t;
-      }
-      for (int i = k + 1; i < len; ++i) {
-        const double f = M[i + len * k] / M[k + len * k];
-        if (f == 0.) continue;
-        for (int j = k + 1; j < len; ++j) M[i + len * j] -= f * M[k + len * j];
-        w[i] -= f * w[k];
-      }
+      piv_s = piv;
+      if (!(mx > 0.) || !isfinite(mx)) sing_s = 1;
     }
+    __syncthreads();
+    if (sing_s) break;
+    rank++;
+    const int piv = piv_s;
+    if (piv != k) {
+      for (int j = lane; j <= len; j += 64) {  // column `len` = the right-hand side
+        double *a = j < len ? &M[k + len * j] : &w[k], *b = j < len ? &M[piv + len * j] : &w[piv];
+        const double t = *a;
+        *a = *b;
+        *b = t;
+      }
+      __syncthreads();
+    }
+    const int nr = len - 1 - k, nc = len - k;  // rows k+1 .. len-1, columns k+1 .. len-1 and the right-hand side
+    const double dkk = M[k + len * k];
+    for (int e = lane; e < nr * nc; e += 64) {
+      const int i = k + 1 + e % nr, jj = e / nr, j = k + 1 + jj;
+      const double f = M[i + len * k] / dkk;
+      if (f == 0.) continue;
+      if (j < len) M[i + len * j] -= f * M[k + len * j];
+      else w[i] -= f * w[k];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const bool singular = sing_s != 0;
+    (void)singular;
     int code = AA_CODE_OK;
     double nw = 0.;
     if (rank == 0) code = AA_CODE_RANK0;

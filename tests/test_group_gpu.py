@@ -162,7 +162,9 @@ def test_config5_workload_matches_oracle_ldl():
         pstars.append(p_star)
     # (the dual of these instances is poorly conditioned: at eps = 1e-8 either solver is ~3e-5 (relative) off the
     # constructed y, at 1e-4 ~5e-2; the 1e-4 bar on y needs the solves at 1e-10 — x and s are there long before)
-    stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=60000)
+    # (seed 1023 of the long list needs 57 025 iterations with the oracle's CG variant, 63 000 here — 23 825 / 21 650 with the direct solvers,
+    #  tools/dbg/config5_tight.py: inexact linear solves at 1e-10 — hence the larger cap there)
+    stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=60000 if count == 8 else 200000)
     solo, grp, _ = _solo_and_group(probs, stg)
     for i, ((d, K), a, b) in enumerate(zip(probs, solo, grp)):
         _assert_same(a, b, "config5 seed %d" % (seed + i))

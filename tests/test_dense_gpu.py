@@ -49,6 +49,7 @@ def _rand_csc(m, n, density, seed):
     (90, 40, 0.2, False), (600, 250, 0.03, True), (600, 250, 0.03, False), (1500, 700, 0.01, True),
     (4050, 1350, 0.03, False),   # a config-5 member's shape: 22 block steps of the Gauss-Jordan sweep
     (300, 64, 0.1, False), (300, 65, 0.1, True), (20, 1, 0.9, False),
+    (30, 2, 0.9, False), (40, 3, 0.8, True), (400, 127, 0.1, False), (400, 129, 0.1, True), (500, 130, 0.08, False),   # GEMV: 4 columns per wavefront, row pairs
     (6000, 4096, 0.001, False),  # the largest order the backend takes: 64 block steps, 64 KiB of LDS per build workgroup
 ])
 def test_kkt_solve_dense_vs_direct_ldl(hip, oracle, m, n, density, with_P):

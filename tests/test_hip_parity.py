@@ -295,6 +295,32 @@ def test_config1_lp_golden_against_stored_optimum_and_oracle(hip, oracle):
     assert got["y"].min() > -1e-7 and got["s"].min() > -1e-7
 
 
+def test_psd_every_small_order_against_lapack(hip):
+    """orders 1..32 run in the four-wavefront kernel (psd.hpp d_proj_psd_small4: rows / columns move between fixed positions, odd orders
+    padded to even): every order, several matrices per launch, against numpy's eigh — random spectra, a matrix that is already PSD,
+    one that is negative definite and one of rank 1"""
+    rng = np.random.default_rng(2)
+    for order in range(1, 33):
+        mats = []
+        for kind in range(5):
+            G = rng.standard_normal((order, order))
+            X = (G + G.T) / 2
+            if kind == 2:
+                X = G @ G.T + 0.1 * np.eye(order)
+            elif kind == 3:
+                X = -(G @ G.T) - 0.1 * np.eye(order)
+            elif kind == 4:
+                v = rng.standard_normal(order)
+                X = np.outer(v, v) - 0.5 * np.eye(order)
+            mats.append(X)
+        z = np.concatenate([helpers.sym_to_svec(X) for X in mats])
+        K = {"s": [order] * len(mats)}
+        want = helpers.proj_dual_l_s_numpy(z, K)
+        got = hip.proj_cone(z, K, dual=True)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg="order %d" % order)
+        np.testing.assert_allclose(hip.proj_cone(z, K, dual=True), got, rtol=0, atol=1e-12 * max(1.0, np.abs(want).max()))   # again
+
+
 @pytest.mark.parametrize("cone,order", [("s", 1500), ("cs", 600)])
 def test_psd_orders_beyond_1024(hip, cone, order):
     """PSD order 1500 / complex PSD order 600 (embedding 1200): refused by this backend in rounds 1-2 (pivots per step

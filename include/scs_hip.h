@@ -86,6 +86,12 @@ double scs_hip_spmv_bench(const ScsMatrix *A, int transpose, int reps);
  * exp_cone.c, R:meson.build:188,190). */
 int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual);
 
+/* The same projection applied to `count` vectors one after the other (xs: count x m, row-major, in place) through ONE set of cone
+ * workspaces, warm-started from call to call as inside the ADMM loop (K9: eigenvectors of the previous call, periodic
+ * re-orthogonalisation, refinement stage; box cone: the previous t).  stats (may be NULL): scs_hip_psd_refine_stats records of the
+ * first stats_cap large PSD matrices after the last call.  Returns the number of records written, -1 on error.  (parity tests) */
+int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, int count, scs_float *stats, int stats_cap);
+
 /* One indirect KKT solve [[R_x+P, A'],[A,-R_y]] z = rhs (in place, length n+m)
  * with the device PCG (row a4; scs_source/linsys/cpu/indirect/private.c,
  * R:meson.build:261).  cg_iters may be NULL. */
@@ -169,6 +175,12 @@ void scs_hip_aa_finish(ScsHipAa *a);
  * the ADMM loop) on the solver's stream; out[4] = {ms per projection, matrices, largest order, reference flop count
  * ((16/3 + 2) n^3 per matrix)}.  0 on success, 1 when the problem has no PSD cone. */
 int scs_hip_time_psd(ScsWork *w, int reps, double *out);
+
+/* K9's refinement stage (csrc/psd.hpp psd_stop_test), diagnostics for tests and bench: for each of the first `cap` PSD matrices of
+ * order > 32 of the workspace five doubles {calls that took the refinement stage so far, refinements whose a-posteriori test sent the
+ * matrix back to the sweeps, |K1|_F^2 at the last gate, mixed-sign off-norm^2 / |A|_F^2 after the last refinement, stage flag of the
+ * last call (0 none, 1 refined, 2 refined + sweeps)}.  Returns the number of matrices written, -1 on error. */
+int scs_hip_psd_refine_stats(ScsWork *w, double *out, int cap);
 
 /* last error message of the calling thread ("" if none) */
 const char *scs_hip_last_error(void);

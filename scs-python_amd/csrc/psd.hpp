@@ -89,7 +89,7 @@ constexpr size_t kPsdLdsBytes = (size_t)(kPsdWaves * kPsdWaveLds + 16 + 2) * siz
 struct PsdBatch {
   const int *off;    // start of each cone's vector inside the m-vector slice
   const int *order;  // matrix order n_c
-  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T, V' (NP*NP each), W (NB/2 * 16x17), rotation log, lam (NP), state (8)
+  const long *woff;  // offset (doubles) of this matrix's scratch: A, V, T, V' (NP*NP each), W (NB/2 * 16x17), rotation log, lam (NP), state (kPsdStateDoubles)
   int count;
 };
 
@@ -107,12 +107,20 @@ __host__ __device__ inline long psd_log_doubles(long n) {  // rotation log: swee
   const long np = psd_np(n), nb = np / kPsdB;
   return (long)kPsdLogSweeps * (nb - 1) * (nb / 2) * kPsdWsz;
 }
+// state block at the end of a matrix's scratch:
+//   [0] consecutive warm-started calls (0 = V invalid)        split mode: [1] sweeps finished  [2] steps logged in this round
+//   [3..5] barrier counters of k_psd_sweep_mc, one per round  [6] XCD mask of the group
+//   [7] refinement stage of this call: 0 none, 1 requested by the sweep kernel (gate passed), 2 done but its test failed (sweeps resumed)
+//   [8] kfro2 = |K1|_F^2 at the gate   [9] calls refined so far   [10] refinements whose a-posteriori test failed so far
+//   [11] mixed-sign off-norm^2 / |A|_F^2 found by the test after the last refinement
+constexpr int kPsdStateDoubles = 16;
 __host__ __device__ inline long psd_scratch_doubles(long n) {
   const long np = psd_np(n);
-  return 4 * np * np + (np / 16) * kPsdWsz + psd_log_doubles(n) + np + 8;
+  return 4 * np * np + (np / 16) * kPsdWsz + psd_log_doubles(n) + np + kPsdStateDoubles;
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double lds_f64;  // explicit LDS address space for pointers hipcc would treat as generic
 
 __device__ __forceinline__ void rr_pair(int r, int k, int N, int &p, int &q) {
@@ -392,6 +400,102 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
   for (int task = wave; task < ntask; task += kPsdWaves) psd_task_r2(task, n, NP, Tm, V, X, li, lk);
 }
 
+// ---- What the sweeps of the split pipeline stop on (round 5) ----
+// The projection does not need the eigenvectors, only the SPLIT between the positive and the non-positive invariant subspace: for
+// S = V'AV = [[S_PP, C], [C', S_NN]] (P: positive diagonal entries, N: the others) with S_PP > 0 >= S_NN and C = 0 the second-order
+// reconstruction F = Pi_+(S) = [[S_PP, 0], [0, 0]] is EXACT whatever is left inside the two diagonal blocks, and for C != 0 its error
+// is at most |C| (Pi_+ is 1-Lipschitz), ~|C|^2 / gap in practice.  In the warm-started steady state of ADMM S is nearly diagonal and
+// the mixed-sign part is removed by ONE step of a GEMM-only refinement (Ogita-Aishima restricted to the mixed-sign pairs, with the
+// same-sign blocks kept in the Sylvester operator to second order) instead of a Jacobi sweep — the latency chain of 25 outer steps:
+//     K1_ij = S_ij / (d_j - d_i)  (d_i d_j mixed),   K2_ij = (S_ij + [S_off, K1]_ij) / (d_j - d_i),   Q = I + K2 + K2^2 / 2,
+//     V <- V Q,   S1 = Q' S Q,   |C(S1)| = O(third order)          (k_psd_plan, k_psd_gemm<COMM / KK / T / S1>, k_psd_apply_q)
+// (tools/dbg/psd_refine_model.py on the matrices config 4 really projects: |C| 1e-4 |A| -> 1e-10 .. 5e-9 |A|, error against LAPACK
+// <= 1.2e-11; Q is orthogonal to |K2|^4 / 4 <= 1e-11, and V is re-orthogonalised every kPsdWarmPeriod calls as before.)
+//   PSD_STOP_STRICT   the test of rounds 1-4: |off(A)|_F^2 <= tol2 |A|_F^2 (identical sums: identical decisions, identical bits)
+//   PSD_STOP_GATE     ... or REFINABLE (code 2): |K1|_F^2 <= R.k2, |off|^2 <= R.off2 |A|^2 and omega <= R.omega, where
+//                     omega = sum over same-sign pairs of a_ij^2 / (d_i d_j) bounds |D^-1/2 E D^-1/2|_F^2 of both diagonal blocks
+//                     (< 1 => they are definite); the third-order remainder of the step is then below the strict level
+//   PSD_STOP_RELAXED  after a refinement: mixed-sign off-norm^2 <= tol2 |A|^2 and omega <= R.omega_relaxed — what the
+//                     reconstruction needs; a matrix that fails it goes back to the sweeps (from S1, with the refined V: nothing is lost)
+enum : int { PSD_STOP_STRICT = 0, PSD_STOP_GATE = 1, PSD_STOP_RELAXED = 2 };
+struct PsdRefineCfg {
+  int on;  // 0: strict sweeps only (bit-identical to the one-launch kernel)
+  double k2, off2, omega, omega_relaxed;
+};
+__host__ inline PsdRefineCfg psd_refine_default(bool on) { return PsdRefineCfg{on ? 1 : 0, 3.6e-5, 2.25e-6, 0.05, 0.25}; }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// every lane of the 1024-lane workgroup returns the code: 0 go on sweeping, 1 converged, 2 refinable.  `diag`: n doubles of LDS;
+// `lead`: this workgroup records the statistics of the decision in state[].  All members of a multi-CU group evaluate the test on
+// the same data in the same order: the same decision everywhere.
+// K1 (PSD_STOP_GATE, lead only): the first step of the refinement, K1_ij = a_ij / (d_j - d_i) on the mixed-sign pairs and 0 elsewhere
+// (padding included), is written while the gate's sums are formed — speculatively: whether the matrix IS refinable is known a
+// reduction later, and a matrix that is not simply never reads it.  a_ij = a_ji exactly and the reciprocal estimate is odd in its
+// argument: K1 is exactly antisymmetric.
+template <bool AGENT>
+__device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, double *diag, double *red, double *bc, double offtol2, int mode,
+                                             const PsdRefineCfg &R, double *state, bool lead, double *K1 = nullptr) {
+  const int tid = threadIdx.x;
+  const bool wk = K1 != nullptr && lead && mode == PSD_STOP_GATE;
+  if (wk) {  // rows / columns of the padding
+    const int NP = ld;
+    for (int e = tid; e < (NP - n) * NP; e += kPsdThreads) {
+      const int j = n + e / NP, i = e % NP;  // columns n .. NP-1 whole, then the rows n .. NP-1 of the other columns
+      K1[i + (size_t)ld * j] = 0.;
+      if (i < n) K1[j + (size_t)ld * i] = 0.;
+    }
+  }
+  if (mode != PSD_STOP_STRICT) {
+    for (int j = tid; j < n; j += kPsdThreads) diag[j] = AGENT ? ld_agent(&A[j + (size_t)ld * j]) : A[j + (size_t)ld * j];
+    __syncthreads();
+  }
+  double off = 0., tot = 0., mix = 0., kf = 0., om = 0.;
+  for (int e = tid; e < n * n; e += kPsdThreads) {
+    const int i = e % n, j = e / n;
+    const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
+    const double a2 = a * a;
+    tot += a2;
+    if (i != j) {
+      off += a2;
+      if (mode != PSD_STOP_STRICT) {
+        const double di = diag[i], dj = diag[j];
+        double k1 = 0.;
+        if ((di > 0.) != (dj > 0.)) {
+          const double r = __builtin_amdgcn_rcp(dj - di);  // (a hardware estimate is enough for a gate, and K1 only enters the second-order term)
+          k1 = a * r;
+          mix += a2;
+          kf += k1 * k1;
+        } else if (a2 > 0.) {
+          om += a2 * __builtin_amdgcn_rcp(di * dj);  // same sign: positive; a zero diagonal entry under a nonzero row: inf, no refinement
+        }
+        if (wk) K1[i + (size_t)ld * j] = k1;
+      }
+    } else if (wk) {
+      K1[i + (size_t)ld * j] = 0.;
+    }
+  }
+  off = block_sum<kPsdThreads>(off, red);
+  tot = block_sum<kPsdThreads>(tot, red);
+  if (mode != PSD_STOP_STRICT) {
+    mix = block_sum<kPsdThreads>(mix, red);
+    kf = block_sum<kPsdThreads>(kf, red);
+    om = block_sum<kPsdThreads>(om, red);
+  }
+  if (tid == 0) {
+    int code = (off <= offtol2 * tot || off == 0.) ? 1 : 0;
+    if (!code && mode == PSD_STOP_GATE && kf <= R.k2 && off <= R.off2 * tot && om <= R.omega) code = 2;
+    if (!code && mode == PSD_STOP_RELAXED && mix <= offtol2 * tot && om <= R.omega_relaxed) code = 1;
+    if (lead && code == 2) state[8] = kf;
+    if (lead && mode == PSD_STOP_RELAXED) state[11] = tot > 0. ? mix / tot : 0.;
+    bc[0] = (double)code;
+  }
+  __syncthreads();
+  const int code = (int)bc[0];
+  __syncthreads();
+  return code;
+}
+
 // MODE 0: the whole projection in one launch (one workgroup = one CU per matrix; right when the batch fills the GPU).
 // Split mode for small batches of large matrices (config 4: 50 matrices on 256 CUs), everything that parallelises
 // beyond one CU per matrix in its own multi-workgroup launch:
@@ -404,9 +508,11 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
 //   k_psd_apply_v: V <- V W_1 W_2 ... per 16-row strip (the V update is 2/3 of the update work)   13 / matrix
 //   k_psd_fmap: F = Pi_+(D + E) element by element; k_psd_gemm<R1>, <R2>: X+ = V F V'   7 / matrix (2 x 4 tiles per wavefront)
 // Same rotations, same MFMA sequences: bit-identical to MODE 0.
+// MODE 1, `R.on`: rounds before the refinement stage stop on PSD_STOP_GATE, the round behind it (`post`) re-tests a refined matrix with
+// PSD_STOP_RELAXED — the same decisions as k_psd_sweep_mc, bit for bit.
 template <int MODE>
 __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B, double *scratch, int allow_warm, int round, const int *stall,
-                                                          const double *tol2) {
+                                                          const double *tol2, PsdRefineCfg R, int post) {
   SCS_STALL_GUARD(stall);
   const double offtol2 = psd_offtol2(tol2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -449,7 +555,8 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   const bool warm = allow_warm && state[0] >= 1.;
   const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
   const bool resumed = MODE == 1;  // split mode: the front and the warm-start GEMMs ran in their own launches
-  const bool finished = MODE == 1 && round > 0 && state[1] != 0.;
+  const bool refined = MODE == 1 && R.on && post && state[7] == 1.;  // this call's refinement stage ran: re-test what it left
+  const bool finished = MODE == 1 && round > 0 && state[1] != 0. && !refined;
   __syncthreads();  // everyone has read state[]
   if (MODE == 1) {
     if (tid == 0) {
@@ -567,34 +674,30 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   }  // !resumed
   if (MODE == 3) return;
   if (MODE == 2) {
-    if (tid == 0) state[3] = state[4] = state[5] = state[6] = 0.;  // barrier counters of k_psd_sweep_mc, one per round
+    if (tid == 0) state[3] = state[4] = state[5] = state[6] = state[7] = 0.;  // barrier counters of k_psd_sweep_mc, one per round; refinement flag
     return;
   }
   int nlog = 0;  // split mode: steps logged in this round
+  int stop_mode = (MODE == 1 && R.on) ? (refined ? PSD_STOP_RELAXED : (post ? PSD_STOP_STRICT : PSD_STOP_GATE)) : PSD_STOP_STRICT;
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_sw0);
-    double off = 0., tot = 0.;
-    for (int e = tid; e < n * n; e += kPsdThreads) {
-      const int i = e % n, j = e / n;
-      const double a = A[i + (size_t)ld * j];
-      tot += a * a;
-      if (i != j) off += a * a;
-    }
-    off = block_sum<kPsdThreads>(off, red);
-    tot = block_sum<kPsdThreads>(tot, red);
     // relative off-norm 1e-8: the reconstruction below is second-order accurate in what is left
-#if PSD_PROFILE >= 2
-    if (tid == 0 && cidx == 0) printf("  block: before sweep %d  off_rel %.3e\n", sweep, sqrt(off / tot));
-#endif
-    if (tid == 0) bc[0] = (off <= offtol2 * tot || off == 0.) ? 1. : 0.;
-    __syncthreads();
-    const bool done = bc[0] != 0.;
-    __syncthreads();
+    const int code = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, true, Vt);
     PSD_TICK(t_sw1);
     PSD_ACC(5, t_sw0, t_sw1);
-    if (done) {
-      if (MODE == 1 && tid == 0) state[1] = 1.;
+    if (code != 0) {
+      if (MODE == 1 && tid == 0) {
+        state[1] = 1.;
+        if (code == 2) state[7] = 1.;  // the refinement stage takes it from here
+      }
+      if (MODE == 1 && code == 2)
+        for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;  // the diagonal the gate saw (k_psd_plan)
       break;
+    }
+    if (MODE == 1 && refined && sweep == 0 && tid == 0) {  // the refinement left too much: back to the sweeps
+      state[1] = 0.;
+      state[7] = 2.;
+      state[10] += 1.;
     }
     if (MODE == 1 && sweep >= kPsdLogSweeps) break;  // log full: the next round continues
 #if PSD_PROFILE
@@ -776,11 +879,30 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
 // The periodic re-orthogonalisation of V stays with the one-workgroup kernel (MODE 3, which returns at once otherwise):
 // on those calls V' is formed there, after V has changed.
 // ---------------------------------------------------------------------------
+// Multi-workgroup launches of the split pipeline: a 1-D grid of psd_xcd_grid(per, count) workgroups, `per` of them for every matrix.
+// Workgroup ids are dealt round-robin to the 8 XCDs, so (id & 7) is the XCD and the matrices are dealt to the XCDs the same way:
+// everything that works on one matrix shares ONE L2 (round 5: with a (per, count) grid the 14 GEMM workgroups of a matrix were spread
+// over all eight, every L2 pulled the operands of all 50 matrices, 35 MB through 4 MB, and the operand fetches ran at HBM latency).
+struct PsdWg { int cidx, bx, per; bool ok; };
+__device__ __forceinline__ PsdWg psd_wg(int count) {
+  const int per = (int)gridDim.x / (8 * ((count + 7) / 8));
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  PsdWg w;
+  w.per = per;
+  w.cidx = (slot / per) * 8 + xcd;
+  w.bx = slot % per;
+  w.ok = w.cidx < count;
+  return w;
+}
+__host__ inline unsigned psd_xcd_grid(int per, int count) { return 8u * (unsigned)per * (unsigned)((count + 7) / 8); }
+
 constexpr int kPsdFrontThreads = 256;
 __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
   SCS_STALL_GUARD(stall);
+  const PsdWg wg = psd_wg(B.count);
+  if (!wg.ok) return;
   __shared__ double Sws[kPsdFrontThreads / 64][16 * 17];
-  const int cidx = blockIdx.y;
+  const int cidx = wg.cidx;
   const int n = B.order[cidx];
   if (n < 2) return;  // orders 0 and 1: the MODE 3 launch behind this one
   const double *X = x + B.off[cidx];
@@ -793,7 +915,7 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
   const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const double isq2 = 0.70710678118654752440;
-  for (long e = (long)blockIdx.x * kPsdFrontThreads + tid; e < (long)NP * NP; e += (long)gridDim.x * kPsdFrontThreads) {
+  for (long e = (long)wg.bx * kPsdFrontThreads + tid; e < (long)NP * NP; e += (long)wg.per * kPsdFrontThreads) {
     const int i = (int)(e % NP), j = (int)(e / NP);
     double v = 0.;
     if (i < n && j < n) {
@@ -806,7 +928,7 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
   }
   if (warm && !reorth) {
     double *Sw = Sws[wave];
-    for (int tile = blockIdx.x * (kPsdFrontThreads / 64) + wave; tile < ntile * ntile; tile += gridDim.x * (kPsdFrontThreads / 64)) {
+    for (int tile = wg.bx * (kPsdFrontThreads / 64) + wave; tile < ntile * ntile; tile += wg.per * (kPsdFrontThreads / 64)) {
       const int ti = tile % ntile, tj = tile / ntile;
 #pragma unroll
       for (int t = 0; t < 4; ++t) Sw[li + 17 * (lk + 4 * t)] = V[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)];
@@ -816,7 +938,7 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
       wave_sync();
     }
   }
-  if (blockIdx.x == 0 && tid == 0) state[3] = state[4] = state[5] = state[6] = 0.;  // barrier counters of k_psd_sweep_mc
+  if (wg.bx == 0 && tid == 0) state[3] = state[4] = state[5] = state[6] = state[7] = 0.;  // barrier counters of k_psd_sweep_mc, refinement flag
 }
 
 // ---------------------------------------------------------------------------
@@ -836,9 +958,6 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
 // not an assumption about what else runs on the GPU; a spin budget still turns a would-be hang into an error flag.
 // ---------------------------------------------------------------------------
 constexpr int kPsdMcMaxG = 8;
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 __device__ __forceinline__ unsigned psd_xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -853,7 +972,7 @@ constexpr size_t kPsdMcLdsBytes = kPsdLdsBytes + 4 * kPsdMaxH * sizeof(int);  //
 // itself, keeps the results in registers, assembles the block in LDS, solves it and logs W_{t+1}: the 8 us pivot solve
 // disappears behind the 6 us of A tasks.  Same MFMA sequences on the same inputs: the same bits.
 __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int look_ahead, int *err,
-                                                              const int *stall, const double *tol2) {
+                                                              const int *stall, const double *tol2, PsdRefineCfg R, int post) {
   SCS_STALL_GUARD(stall);
   const double offtol2 = psd_offtol2(tol2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -873,14 +992,33 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP;
   double *A = scratch + B.woff[cidx];
   double *Wlog = A + 4 * (size_t)NP * NP + (size_t)H * kPsdWsz;
-  double *state = Wlog + psd_log_doubles(n) + NP;
+  double *lam = Wlog + psd_log_doubles(n);
+  double *state = lam + NP;
   unsigned *bar = reinterpret_cast<unsigned *>(state + 3 + round);
-  const bool finished = round > 0 && state[1] != 0.;  // written by the previous round's launch
+  const bool refined = R.on && post && state[7] == 1.;  // this call's refinement stage ran: re-test what it left
+  const bool finished = round > 0 && state[1] != 0. && !refined;  // written by the previous round's launch
+  __syncthreads();  // everyone has read state[]
   if (g == 0 && tid == 0) {
     state[2] = 0.;
     if (round == 0) state[1] = 0.;
   }
   if (finished) return;
+  // The first stopping test comes before anything spins: a matrix with nothing to do (refinable as it arrives — the steady state of
+  // ADMM — or refined to the relaxed level) leaves without a barrier.  Every member decides on the same data: the same decision.
+  const int stop_mode = R.on ? (refined ? PSD_STOP_RELAXED : (post ? PSD_STOP_STRICT : PSD_STOP_GATE)) : PSD_STOP_STRICT;
+  double *Vt = A + 3 * (size_t)NP * NP;  // free between the warm-start GEMMs and k_psd_fmap: K1 / Q' of the refinement stage
+  const int code_first = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt);  // (plain loads: written by earlier kernels)
+  if (code_first != 0) {
+    if (g == 0) {
+      if (tid == 0) {
+        state[1] = 1.;
+        if (code_first == 2) state[7] = 1.;
+      }
+      if (code_first == 2)
+        for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;  // the diagonal the gate saw (k_psd_plan)
+    }
+    return;
+  }
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int nblk = H * (H + 1) / 2;
   unsigned bar_target = 0;
@@ -913,6 +1051,12 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
 #ifdef PSD_MC_FORCE_WT
     wt = true;
 #endif
+  }
+  // (behind the group's first barrier: every member has read state[] by now — a member that starts late must not see this)
+  if (refined && g == 0 && tid == 0) {  // the refinement left too much: back to the sweeps
+    state[1] = 0.;
+    state[7] = 2.;
+    state[10] += 1.;
   }
   auto st_shared = [&](double *p, double v) {
     if (wt) st_agent(p, v);
@@ -1046,23 +1190,18 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_n0);
     // every member evaluates the stopping test on the same data in the same order: the same decision everywhere
-    double off = 0., tot = 0.;
-    for (int e = tid; e < n * n; e += kPsdThreads) {
-      const int i = e % n, j = e / n;
-      const double a = ld_agent(&Acur[i + (size_t)ld * j]);
-      tot += a * a;
-      if (i != j) off += a * a;
-    }
-    off = block_sum<kPsdThreads>(off, red);
-    tot = block_sum<kPsdThreads>(tot, red);
-    if (tid == 0) bc[0] = (off <= offtol2 * tot || off == 0.) ? 1. : 0.;
-    __syncthreads();
-    const bool done = bc[0] != 0.;
-    __syncthreads();
+    const int code = sweep == 0 ? 0 : psd_stop_test<true>(Acur, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt);
     PSD_TICK(t_n1);
     PSD_ACC(1, t_n0, t_n1);
-    if (done) {
-      if (g == 0 && tid == 0) state[1] = 1.;
+    if (code != 0) {
+      if (g == 0) {
+        if (tid == 0) {
+          state[1] = 1.;
+          if (code == 2) state[7] = 1.;
+        }
+        if (code == 2)
+          for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;
+      }
       break;
     }
     if (sweep >= kPsdLogSweeps) break;  // log full: the next round continues
@@ -1147,13 +1286,15 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
 constexpr int kPsdApplyThreads = PSD_APPLY_THREADS;
 __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, double *scratch, const int *stall) {
   SCS_STALL_GUARD(stall);
+  const PsdWg wg = psd_wg(B.count);
+  if (!wg.ok) return;
   extern __shared__ __attribute__((aligned(16))) double strip[];  // [row + 16 * col]
-  const int n = B.order[blockIdx.y];
+  const int n = B.order[wg.cidx];
   if (n < 2) return;
   const int NP = (int)psd_np(n), NB = NP / kPsdB, H = NB / 2, ld = NP, ntile = NP / 16;
-  const int rt = blockIdx.x;
+  const int rt = wg.bx;
   if (rt >= ntile) return;
-  double *A = scratch + B.woff[blockIdx.y];
+  double *A = scratch + B.woff[wg.cidx];
   double *V = A + (size_t)NP * NP;
   const double *Wlog = V + 3 * (size_t)NP * NP + (size_t)H * kPsdWsz;
   const double *state = Wlog + psd_log_doubles(n) + NP;
@@ -1189,16 +1330,77 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_v(PsdBatch B, do
 // buffer of V' (free after the warm-start GEMMs) — the B operand of the R1 GEMM.
 __global__ __launch_bounds__(256) void k_psd_fmap(PsdBatch B, double *scratch, const int *stall) {
   SCS_STALL_GUARD(stall);
-  const int n = B.order[blockIdx.y];
+  const PsdWg wg = psd_wg(B.count);
+  if (!wg.ok) return;
+  const int n = B.order[wg.cidx];
   if (n < 2) return;
   const int NP = (int)psd_np(n), ld = NP;
-  const double *A = scratch + B.woff[blockIdx.y];
-  double *F = scratch + B.woff[blockIdx.y] + 3 * (size_t)NP * NP;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)NP * NP; e += (long)gridDim.x * 256) {
+  const double *A = scratch + B.woff[wg.cidx];
+  double *F = scratch + B.woff[wg.cidx] + 3 * (size_t)NP * NP;
+  for (long e = (long)wg.bx * 256 + threadIdx.x; e < (long)NP * NP; e += (long)wg.per * 256) {
     const int r = (int)(e % NP), k = (int)(e / NP);
     const double dj = r < n ? A[r + (size_t)ld * r] : 0., dk = k < n ? A[k + (size_t)ld * k] : 0.;
     F[e] = psd_fmap(A[e], dj, dk, r == k);
   }
+}
+
+// Refinement stage, V <- V Q in place: one 512-lane workgroup per (matrix, 16-row strip of V), the strip in LDS (as k_psd_apply_v);
+// out[i][j] = sum_k strip[i][k] Q'[j][k], Q' (Tm) read down its columns; the new strip is assembled in a second LDS buffer.
+__global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_q(PsdBatch B, double *scratch, const int *stall) {
+  SCS_STALL_GUARD(stall);
+  const PsdWg wg = psd_wg(B.count);
+  if (!wg.ok) return;
+  extern __shared__ __attribute__((aligned(16))) double strip[];  // [row + 16 * col], twice
+  const int n = B.order[wg.cidx];
+  if (n < 2) return;
+  const int NP = (int)psd_np(n), H = NP / kPsdB / 2, ld = NP, ntile = NP / 16;
+  const int rt = wg.bx;
+  if (rt >= ntile) return;
+  double *A = scratch + B.woff[wg.cidx];
+  double *V = A + (size_t)NP * NP;
+  const double *Qt = V + 2 * (size_t)NP * NP;  // (Vt)
+  double *state = A + 4 * (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n) + NP;
+  if (state[7] != 1.) return;
+  double *out = strip + 16 * (size_t)NP;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) strip[e] = V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)];
+  __syncthreads();
+  // a wavefront takes a PAIR of column tiles: one 16-byte load per lane brings the Q' operands of both (columns 2 li, 2 li + 1 of the
+  // pair; k_psd_gemm has the reasoning), so the 13 column tiles of an order-200 matrix are one round of the 8 wavefronts
+  const int ldh = ld / 2;
+  for (int tp = wave; 2 * tp < ntile; tp += kPsdApplyThreads / 64) {
+    const f64x2 *pb = reinterpret_cast<const f64x2 *>(Qt + tp * 32 + 2 * li + (size_t)ld * lk);
+    f64x4 acc[2] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}};
+    f64x2 bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bq[u] = pb[(size_t)ldh * (4 * u)];
+    for (int k0 = 0; k0 < NP; k0 += 16) {  // four k-steps per trip, the next trip's operands in flight (the last trip re-fetches)
+      f64x2 bn[4];
+      const int kn = min(k0 + 16, NP - 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bn[u] = pb[(size_t)ldh * (kn + 4 * u)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double a = strip[li + 16 * (k0 + 4 * u + lk)];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].y, acc[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bq[u] = bn[u];
+    }
+    // lane holds out[row = lk + 4t][col = tp * 32 + 2 li + cq]
+#pragma unroll
+    for (int cq = 0; cq < 2; ++cq) {
+      const int col = tp * 32 + 2 * li + cq;
+      if (col < NP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[(lk + 4 * t) + 16 * col] = acc[cq][t];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * NP; e += kPsdApplyThreads) V[(rt * 16 + (e & 15)) + (size_t)ld * (e >> 4)] = out[e];
+  if (rt == 0 && tid == 0) state[9] += 1.;  // calls refined
 }
 
 // Split mode: the four GEMM phases as multi-workgroup launches — grid (workgroups per matrix, matrices), 4 wavefronts per
@@ -1209,7 +1411,16 @@ __global__ __launch_bounds__(256) void k_psd_fmap(PsdBatch B, double *scratch, c
 // (tools/dbg/psd_gemm_threads.sh): 44 us per launch with 1 x 4 tiles and no pipeline, 53 us with 2 x 4 tiles alone (fewer
 // wavefronts, every k-step one L2 round trip), 38 us with both; the workgroup size (64 / 128 / 256 lanes) does not matter.
 // Every output tile still accumulates its k-steps in order: the bits of psd_task_*.
-enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2 };
+// Round 5, the refinement stage (see psd_stop_test) as four more kinds, all gated by state[7] == 1:
+//   COMM  K2 = mixed((2 S - (S K1' + K1 S')) ./ den)  — the two products accumulate into one tile; S carries its diagonal, which
+//         contributes (d_j - d_i) K1_ij = S_ij to the sum: [S_off, K1]_ij = S_ij - acc_ij on the mixed pairs.  Tiles on and below the
+//         diagonal, mirrored with the opposite sign (diagonal tiles antisymmetrised): K2 is EXACTLY antisymmetric.      A, Vt -> Tm
+//         (K1: written into Vt by the sweep kernel's gate, psd_stop_test)
+//   KK    Q' = I - K2 + K2^2 / 2 = I - K2 - (K2 K2') / 2, lower tiles + mirror: the symmetric part exactly symmetric    Tm -> Vt
+//   T     T' = (S Q)' stored transposed (the B-operand layout of the next product)                                      A, Vt -> Tm
+//   S1    S1 = Q' T, lower tiles + mirror + symmetrised diagonal tiles (the epilogue of G2)                              Vt, Tm -> A
+//   (Tm is the sweeps' second copy of A while they run: it is free again when the stage starts, and the round behind it finds Q' dead)
+enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2, PSD_COMM, PSD_KK, PSD_T, PSD_S1 };
 #ifndef PSD_GEMM_THREADS
 #define PSD_GEMM_THREADS 128
 #endif
@@ -1221,11 +1432,14 @@ __host__ inline unsigned psd_gemm_wgs(int max_tiles) { return (unsigned)((psd_ge
 template <int KIND>
 __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
   SCS_STALL_GUARD(stall);
+  const PsdWg wg = psd_wg(B.count);
+  if (!wg.ok) return;
   __shared__ double Sws[kPsdGemmThreads / 64][16 * 17];
-  const int n = B.order[blockIdx.y];
+  __shared__ double Rws[kPsdGemmThreads / 64][32 * 33];  // a tile pair x column pair of accumulators on their way back to whole tiles
+  const int n = B.order[wg.cidx];
   if (n < 2) return;  // orders 0 and 1 were finished by the front kernel
   const int NP = (int)psd_np(n), ntile = NP / 16, H = NP / kPsdB / 2, ld = NP;
-  double *A = scratch + B.woff[blockIdx.y];
+  double *A = scratch + B.woff[wg.cidx];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;
   double *Vt = Tm + (size_t)NP * NP;  // V' for G1 / G2; F = Pi_+(D + E) (k_psd_fmap) for R1
@@ -1233,102 +1447,193 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const bool warm = allow_warm && state[0] >= 1.;
   if ((KIND == PSD_G1 || KIND == PSD_G2) && !warm) return;  // cold start: A0 = A
-  constexpr bool lower = KIND == PSD_G2 || KIND == PSD_R2;   // symmetric results: tiles on and below the diagonal only
+  if (KIND >= PSD_COMM && state[7] != 1.) return;            // no refinement stage for this matrix in this call
+  constexpr bool lower = KIND == PSD_G2 || KIND == PSD_R2 || KIND == PSD_COMM || KIND == PSD_KK || KIND == PSD_S1;  // (anti)symmetric results: tiles on and below the diagonal only
+  constexpr int npass = KIND == PSD_COMM ? 2 : 1;
+  const double *lam = state - NP;
   // C[i][j] = sum_k Aop[i][k] Bop[j][k]:  G1 Tt = Vt A (A symmetric)   G2 A0 = Vt Tt'   R1 T = V F   R2 X+ = T V'
-  const double *Aop = KIND == PSD_G1 || KIND == PSD_G2 ? Vt : KIND == PSD_R1 ? V : Tm;
-  const double *Bop = KIND == PSD_G1 ? A : KIND == PSD_G2 ? Tm : KIND == PSD_R1 ? Vt : V;
-  double *X = x + B.off[blockIdx.y];
+  //   COMM S K1' + K1 S' (two passes)   KK K2 K2'   T S Q   S1 Q' T
+  const double *Aop = KIND == PSD_G1 || KIND == PSD_G2 || KIND == PSD_S1 ? Vt : KIND == PSD_R1 ? V : KIND == PSD_COMM || KIND == PSD_T ? A : Tm;
+  const double *Bop = KIND == PSD_G1 ? A : KIND == PSD_G2 || KIND == PSD_KK || KIND == PSD_S1 ? Tm : KIND == PSD_R1 || KIND == PSD_COMM || KIND == PSD_T ? Vt : V;
+  double *Ko = KIND == PSD_COMM || KIND == PSD_T ? Tm : Vt;  // where COMM / T (Tm) and KK (Vt) leave their result; KK reads K2 from Tm
+  double *X = x + B.off[wg.cidx];
   const double sq2 = 1.41421356237309504880;
   const int ntr = (ntile + kPsdRT - 1) / kPsdRT, ntask = psd_gemm_tasks(ntile);
-  double *Sw = Sws[wave];
-  for (int task = blockIdx.x * (kPsdGemmThreads / 64) + wave; task < ntask; task += gridDim.x * (kPsdGemmThreads / 64)) {
+  double *Sw = Sws[wave], *Rw = Rws[wave];
+  for (int task = wg.bx * (kPsdGemmThreads / 64) + wave; task < ntask; task += wg.per * (kPsdGemmThreads / 64)) {
     const int ti0 = (task % ntr) * kPsdRT, tj0 = (task / ntr) * kPsdNJ;
     const int tilast = min(ti0 + kPsdRT - 1, ntile - 1);
     if (lower && tj0 > tilast) continue;
-    const int tjmax = lower ? tilast : ntile - 1;  // tiles beyond it are computed on a clamped tile and ignored
-    const double *pa[kPsdRT], *pb[kPsdNJ];
     f64x4 acc[kPsdRT][kPsdNJ];
 #pragma unroll
-    for (int r = 0; r < kPsdRT; ++r) pa[r] = Aop + (min(ti0 + r, ntile - 1) * 16 + li) + (size_t)ld * lk;
-#pragma unroll
-    for (int j = 0; j < kPsdNJ; ++j) {
-      pb[j] = Bop + (min(tj0 + j, tjmax) * 16 + li) + (size_t)ld * lk;
+    for (int j = 0; j < kPsdNJ; ++j)
 #pragma unroll
       for (int r = 0; r < kPsdRT; ++r) acc[r][j] = f64x4{0., 0., 0., 0.};
-    }
-    // Software pipeline over the k-steps: the operands of kPsdPf steps are in flight while the MFMAs of the oldest run.  Every
-    // load is unconditional (the last stages re-fetch the final step: a conditional load in this loop makes hipcc fall back to
-    // s_waitcnt vmcnt(0) and the steps serialise on the L2 latency — 52 round trips per task at order 200).
-    double as[kPsdPf][kPsdRT], bs[kPsdPf][kPsdNJ];
-    auto fetch = [&](int st, int k0) {
+    // Operand fetches (round 5): ONE 16-byte load per lane brings the A operands of both row tiles and one brings the B operands of
+    // two column tiles — lane li holds rows 2 li and 2 li + 1 of the 32 rows of the tile pair, so the "tiles" the matrix cores work on
+    // are the even and the odd rows (columns) of the pair; which row a lane feeds does not enter an output element's arithmetic
+    // (its four k-terms are added in the same order), so every element keeps its bits.  3 load instructions per k-step instead
+    // of 6: these launches were bound by the texture addresser (~35 clocks per load instruction against 16 per MFMA and CU).
+    // The accumulators come out interleaved the same way and are put back into whole tiles through LDS before the epilogue.
+    // Rows / columns beyond the matrix (the odd tile at the edge) are read from whatever follows in the scratch — finite numbers
+    // that only reach accumulator entries the epilogue skips.
+    const int ldh = ld / 2;  // (NP is a multiple of 16; every operand buffer starts on a 16-byte boundary)
 #pragma unroll
-      for (int r = 0; r < kPsdRT; ++r) as[st][r] = pa[r][(size_t)ld * k0];
+    for (int pass = 0; pass < npass; ++pass) {
+    const double *Ao = pass == 0 ? Aop : Bop, *Bo = pass == 0 ? Bop : Aop;  // (COMM: the second product has the operands swapped)
+    const f64x2 *pa2 = reinterpret_cast<const f64x2 *>(Ao + ti0 * 16 + 2 * li + (size_t)ld * lk);
+    const f64x2 *pb2[kPsdNJ / 2];
 #pragma unroll
-      for (int j = 0; j < kPsdNJ; ++j) bs[st][j] = pb[j][(size_t)ld * k0];
-    };
-#pragma unroll
-    for (int st = 0; st < kPsdPf; ++st) fetch(st, 4 * st);  // NP >= 16 and NP / 4 is a multiple of kPsdPf = 4
-    for (int k0 = 0; k0 < NP; k0 += 4 * kPsdPf) {
+    for (int j = 0; j < kPsdNJ / 2; ++j) pb2[j] = reinterpret_cast<const f64x2 *>(Bo + tj0 * 16 + 32 * j + 2 * li + (size_t)ld * lk);
+    // Software pipeline over the k-steps, a TRIP = kPsdPf k-steps: two register sets, the loads of the next trip are issued before the
+    // MFMAs of the current one.  Every load is unconditional (the tail re-fetches the last trip: a conditional load in this loop makes
+    // hipcc fall back to s_waitcnt vmcnt(0)).  Round 5: until now the loop carried ONE set around its back edge and refilled each stage
+    // behind its use; hipcc rotated that into load - wait - use (ISA: s_waitcnt vmcnt(9) right behind the twelve loads of a trip),
+    // i.e. the L2 latency once per trip, 13 times per task — 22 us of a 33 us launch at order 200.  With two named sets whichever way
+    // the loop is rotated a trip's MFMAs only wait for loads issued a whole trip earlier.
+    f64x2 a0[kPsdPf], b0[kPsdPf][kPsdNJ / 2], a1[kPsdPf], b1[kPsdPf][kPsdNJ / 2];
+    auto load = [&](f64x2 (&as)[kPsdPf], f64x2 (&bs)[kPsdPf][kPsdNJ / 2], int trip) {
 #pragma unroll
       for (int st = 0; st < kPsdPf; ++st) {
-        double a[kPsdRT], b[kPsdNJ];
+        const size_t at = (size_t)ldh * (4 * (kPsdPf * trip + st));
+        as[st] = pa2[at];
 #pragma unroll
-        for (int r = 0; r < kPsdRT; ++r) a[r] = as[st][r];
+        for (int j = 0; j < kPsdNJ / 2; ++j) bs[st][j] = pb2[j][at];
+      }
+    };
+    auto use = [&](const f64x2 (&as)[kPsdPf], const f64x2 (&bs)[kPsdPf][kPsdNJ / 2]) {
 #pragma unroll
-        for (int j = 0; j < kPsdNJ; ++j) b[j] = bs[st][j];
-        fetch(st, min(k0 + 4 * st + 4 * kPsdPf, NP - 4));
+      for (int st = 0; st < kPsdPf; ++st) {
+        const double a[kPsdRT] = {as[st].x, as[st].y};
+        double b[kPsdNJ];
+#pragma unroll
+        for (int j = 0; j < kPsdNJ / 2; ++j) { b[2 * j] = bs[st][j].x; b[2 * j + 1] = bs[st][j].y; }
 #pragma unroll
         for (int r = 0; r < kPsdRT; ++r)
 #pragma unroll
           for (int j = 0; j < kPsdNJ; ++j) acc[r][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[j], acc[r][j], 0, 0, 0);
       }
+    };
+    const int ntrips = NP / (4 * kPsdPf);  // NP is a multiple of 16 = 4 kPsdPf
+    load(a0, b0, 0);
+    int trip = 0;
+    for (; trip + 1 < ntrips; trip += 2) {
+      load(a1, b1, trip + 1);
+      use(a0, b0);
+      load(a0, b0, min(trip + 2, ntrips - 1));
+      use(a1, b1);
     }
+    if (trip < ntrips) use(a0, b0);  // an odd number of trips: the last one sits in the first set
+    }  // pass
+    // acc[r][j][t] = C[row 2 (lk + 4t) + r of the tile pair][column 2 li + (j & 1) of column pair j >> 1]
 #pragma unroll
-    for (int r = 0; r < kPsdRT; ++r) {
-      const int ti = ti0 + r;
-      if (ti >= ntile) break;
+    for (int jp = 0; jp < kPsdNJ / 2; ++jp) {
+      if (tj0 + 2 * jp >= ntile || (lower && tj0 + 2 * jp > tilast)) break;  // (uniform: nothing of this column pair is wanted)
 #pragma unroll
-      for (int j = 0; j < kPsdNJ; ++j) {
-        const int tj = tj0 + j;
-        if (tj >= ntile || (lower && tj > ti)) break;
-        const f64x4 c = acc[r][j];  // lane holds C[row = lk + 4t][col = li] of tile (ti, tj)
+      for (int r = 0; r < kPsdRT; ++r)
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Rw[(2 * (lk + 4 * t) + r) + 33 * (2 * li + cq)] = acc[r][2 * jp + cq][t];
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < kPsdRT; ++r) {
+        const int ti = ti0 + r;
+        if (ti >= ntile) break;
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+          const int tj = tj0 + 2 * jp + cq;
+          if (tj >= ntile || (lower && tj > ti)) break;
+          f64x4 c;  // lane holds C[row = lk + 4t][col = li] of tile (ti, tj)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) c[t] = Rw[(16 * r + lk + 4 * t) + 33 * (16 * cq + li)];
         if (KIND == PSD_G1 || KIND == PSD_R1) {  // stored through the 16x17 transpose: li runs down the columns of the result
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
-          wave_sync();
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
-          wave_sync();
-        } else if (KIND == PSD_G2) {  // mirrored; diagonal tiles symmetrised (average of the two triangles): A0 exactly symmetric
-          if (ti != tj) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
-          }
-#pragma unroll
-          for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
-          wave_sync();
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int rr = li, cc = lk + 4 * t;
-            double v = Sw[rr + 17 * cc];
-            if (ti == tj && rr != cc) v = 0.5 * ((rr > cc ? v : Sw[cc + 17 * rr]) + (rr > cc ? Sw[cc + 17 * rr] : v));
-            A[(ti * 16 + rr) + (size_t)ld * (tj * 16 + cc)] = v;
-          }
-          wave_sync();
-        } else {  // R2: lower-triangular tiles straight into the packed vector
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
-            if (i < n && jc <= i) {
-              const long base = (long)jc * n - (long)jc * (jc - 1) / 2;
-              X[base + (i - jc)] = (i == jc) ? c[t] : c[t] * sq2;
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
+            wave_sync();
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
+            wave_sync();
+          } else if (KIND == PSD_T) {  // T' straight from the C layout: li runs down a column of the transpose
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Ko[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
+          } else if (KIND == PSD_COMM) {
+            double val[4];
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
+              const double di = lam[i], dj = lam[jc];
+              const double sij = A[i + (size_t)ld * jc];
+              val[t] = ((di > 0.) != (dj > 0.)) ? (2. * sij - c[t]) / (dj - di) : 0.;
+            }
+            if (ti != tj) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) Ko[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = -val[t];  // K2_ji = -K2_ij
+            }
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = val[t];
+            wave_sync();
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int rr = li, cc = lk + 4 * t;
+              double v = Sw[rr + 17 * cc];
+              if (ti == tj) v = 0.5 * (v - Sw[cc + 17 * rr]);
+              Ko[(ti * 16 + rr) + (size_t)ld * (tj * 16 + cc)] = v;
+            }
+            wave_sync();
+          } else if (KIND == PSD_KK) {  // Q'_ij = delta_ij - K2_ij - acc_ij / 2 (acc = K2 K2' = -K2^2), both triangles from the lower tiles
+            if (ti != tj) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) {  // the mirror entry (jc, i): its own K2 entry is read where it lies (coalesced)
+                const size_t at = (tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t);
+                Ko[at] = -Tm[at] - 0.5 * c[t];
+              }
+            }
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
+            wave_sync();
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int rr = li, cc = lk + 4 * t;
+              double v = Sw[rr + 17 * cc];
+              if (ti == tj) v = 0.5 * (v + Sw[cc + 17 * rr]);
+              const size_t at = (ti * 16 + rr) + (size_t)ld * (tj * 16 + cc);
+              Ko[at] = ((ti == tj && rr == cc) ? 1. : 0.) - Tm[at] - 0.5 * v;
+            }
+            wave_sync();
+          } else if (KIND == PSD_G2 || KIND == PSD_S1) {  // mirrored; diagonal tiles symmetrised (average of the two triangles): A0 exactly symmetric
+            if (ti != tj) {
+  #pragma unroll
+              for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
+            }
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
+            wave_sync();
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int rr = li, cc = lk + 4 * t;
+              double v = Sw[rr + 17 * cc];
+              if (ti == tj && rr != cc) v = 0.5 * ((rr > cc ? v : Sw[cc + 17 * rr]) + (rr > cc ? Sw[cc + 17 * rr] : v));
+              A[(ti * 16 + rr) + (size_t)ld * (tj * 16 + cc)] = v;
+            }
+            wave_sync();
+          } else {  // R2: lower-triangular tiles straight into the packed vector
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
+              if (i < n && jc <= i) {
+                const long base = (long)jc * n - (long)jc * (jc - 1) / 2;
+                X[base + (i - jc)] = (i == jc) ? c[t] : c[t] * sq2;
+              }
             }
           }
+  
         }
       }
+      wave_sync();
     }
   }
-  if (KIND == PSD_R2 && blockIdx.x == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;
+  if (KIND == PSD_R2 && wg.bx == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;
 }
 
 // ---------------------------------------------------------------------------
@@ -1378,7 +1683,7 @@ __device__ __forceinline__ void d_proj_psd_small(double *x, PsdBatch B, double *
   }
   const int N = (n + 1) & ~1, H = N / 2, ld = kPsdSLd;
   double *Vg = scratch + B.woff[cidx];
-  double *state = Vg + psd_scratch_doubles(n) - 8;
+  double *state = Vg + psd_scratch_doubles(n) - kPsdStateDoubles;
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
   const bool warm = allow_warm && state[0] >= 1.;
   const bool reorth = warm && ((long)state[0] % kPsdWarmPeriod) == 0;
@@ -1625,7 +1930,7 @@ __device__ __forceinline__ void d_proj_psd_small4(double *x, PsdBatch B, double 
   }
   const int N = (n + 1) & ~1, H = N / 2, ld = kPsdSLd;
   double *Vg = scratch + B.woff[cidx];
-  double *state = Vg + psd_scratch_doubles(n) - 8;
+  double *state = Vg + psd_scratch_doubles(n) - kPsdStateDoubles;
   const double isq2 = 0.70710678118654752440, sq2 = 1.41421356237309504880;
   const double st0 = state[0];
   const bool warm = allow_warm && st0 >= 1.;

@@ -729,6 +729,8 @@ struct ScsHipWork {
   DevBuf<unsigned> box_ticket;  // the caller's bounds (the working copies follow the row scaling): footer diagnostics
   DevBuf<int> psd_off, psd_order;    // orders > kPsdSmallMax first (n_psd_big of them), then the small ones
   DevBuf<long> psd_woff;
+  std::vector<long> psd_woff_h;  // host copies (scs_hip_psd_refine_stats)
+  std::vector<int> psd_order_h;
   DevBuf<double> psd_scratch;
   int n_psd = 0, n_psd_big = 0;
   // split mode of the block kernel (psd.hpp): worth it when the large matrices alone leave most CUs idle
@@ -747,15 +749,30 @@ struct ScsHipWork {
       PsdBatch B{off, order, woff, big};
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
-        const dim3 gg(psd_gemm_wgs(psd_max_tiles), (unsigned)big), gb(kPsdGemmThreads);
+        const dim3 gg(psd_xcd_grid((int)psd_gemm_wgs(psd_max_tiles), big)), gb(kPsdGemmThreads);  // 1-D grids: a matrix's workgroups on one XCD (psd.hpp psd_wg)
+        const dim3 gt(psd_xcd_grid(std::max(psd_max_tiles, 1), big));
         // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
-        hipLaunchKernelGGL(k_psd_front, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(kPsdFrontThreads), 0, stream,
+        hipLaunchKernelGGL(k_psd_front, gt, dim3(kPsdFrontThreads), 0, stream,
                            (const double *)base, B, psd_scratch.p, psd_warm, stall);
-        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2);
+        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
+                           psd_refine_default(false), 0);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         int mc = in_capture ? 1 : psd_mc_members(big);
+        PsdRefineCfg R = psd_refine;
+        if ((size_t)32 * psd_max_np * sizeof(double) > 160 * 1024) R.on = 0;  // k_psd_apply_q keeps two 16-row strips in LDS
         for (int round = 0; round < kPsdSplitRounds; ++round) {
+          const int post = (R.on && round == kPsdSplitRounds - 1) ? 1 : 0;
+          if (post) {
+            // the refinement stage (psd.hpp psd_stop_test): matrices the sweeps left REFINABLE get the mixed-sign part of S = V'AV
+            // removed by GEMMs; the round behind it re-tests them (and goes on sweeping whatever is not done: nothing is lost)
+            hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_T>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_S1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+            hipLaunchKernelGGL(k_psd_apply_q, gt, dim3(kPsdApplyThreads), (size_t)32 * psd_max_np * sizeof(double), stream, B,
+                               psd_scratch.p, stall);
+          }
           if (mc > 1) {  // sweeps of one matrix over `mc` CUs (k_psd_sweep_mc): cooperative launch, spinning barriers
             double *scr = psd_scratch.p;
             int G = mc, rnd = round;
@@ -763,7 +780,9 @@ struct ScsHipWork {
             const int *st = stall;
             int la = psd_mc_look_ahead;
             const double *tl = psd_tol2;
-            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl};
+            PsdRefineCfg Rr = R;
+            int pst = post;
+            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl, &Rr, &pst};
             if (psd_mc_coop) {
               const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
                                                              dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream);
@@ -775,18 +794,20 @@ struct ScsHipWork {
               }
             } else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
               hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
-                                 la, err, st, tl);
+                                 la, err, st, tl, Rr, pst);
           }
           if (mc <= 1)
-          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall, psd_tol2);
-          hipLaunchKernelGGL(k_psd_apply_v, dim3(psd_max_tiles, big), dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
+          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall, psd_tol2,
+                             R, post);
+          hipLaunchKernelGGL(k_psd_apply_v, gt, dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
         }
-        hipLaunchKernelGGL(k_psd_fmap, dim3((unsigned)std::max(psd_max_tiles, 1), (unsigned)big), dim3(256), 0, stream, B, psd_scratch.p, stall);
+        hipLaunchKernelGGL(k_psd_fmap, gt, dim3(256), 0, stream, B, psd_scratch.p, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
       } else {
-        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2);
+        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
+                           psd_refine_default(false), 0);
       }
     }
     if (count > big) {
@@ -804,6 +825,16 @@ struct ScsHipWork {
   // small matrices (order <= 32): four wavefronts per matrix (psd.hpp d_proj_psd_small4); SCS_HIP_PSD_SMALL_WAVES=1: the one-wavefront kernel (lab; agrees to rounding)
   // SCS_HIP_SOC_PSD_FUSE=0: separate launches for short SOCs and small PSD matrices (same bits)
   bool soc_psd_one_launch = [] { const char *e = getenv("SCS_HIP_SOC_PSD_FUSE"); return !(e && e[0] == '0'); }();
+  // Round 5: GEMM-only refinement of the sign split instead of the last Jacobi sweep(s) in split mode (psd.hpp psd_stop_test).
+  // SCS_HIP_PSD_REFINE=0: strict sweeps only (bit-identical to the one-launch kernel); SCS_HIP_PSD_GATE_K / _OFF / _OMEGA: the gate (lab knobs).
+  PsdRefineCfg psd_refine = [] {
+    const char *e = getenv("SCS_HIP_PSD_REFINE");
+    PsdRefineCfg r = psd_refine_default(!(e && e[0] == '0'));
+    if (const char *v = getenv("SCS_HIP_PSD_GATE_K")) { const double x = atof(v); if (x > 0.) r.k2 = x * x; }
+    if (const char *v = getenv("SCS_HIP_PSD_GATE_OFF")) { const double x = atof(v); if (x > 0.) r.off2 = x * x; }
+    if (const char *v = getenv("SCS_HIP_PSD_GATE_OMEGA")) { const double x = atof(v); if (x > 0.) r.omega = x; }
+    return r;
+  }();
   bool psd_small_one_wave = [] { const char *e = getenv("SCS_HIP_PSD_SMALL_WAVES"); return e && e[0] == '1'; }();
   int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
   // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
@@ -1917,6 +1948,8 @@ static void upload_cone_meta(ScsHipWork *w) {
     w->psd_off.upload(poff.data(), poff.size(), s);
     w->psd_order.upload(pord.data(), pord.size(), s);
     w->psd_woff.upload(woff.data(), woff.size(), s);
+    w->psd_woff_h = woff;
+    w->psd_order_h = pord;
   }
   std::vector<int> coff, cord, cpoff, cpord;
   std::vector<long> csoff, cwoff;
@@ -2860,6 +2893,30 @@ void scs_hip_get_mark(const ScsWork *w, double *out) {
  * times (warm-started eigenvectors, as inside the ADMM loop); the copies are timed separately and subtracted.
  * out[4] = {ms per projection, number of matrices, largest order, flops of a LAPACK-style eigensolve of them all
  * (16/3 n^3 + 2 n^3 per matrix)}.  Returns 0 on success, 1 when the problem has no PSD cone. */
+int scs_hip_psd_refine_stats(ScsWork *w, double *out, int cap) {
+  if (!w || !out || cap < 0) return -1;
+  try {
+    std::lock_guard<std::mutex> lock(w->mtx);
+    HIP_CHECK(hipSetDevice(w->device));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    const int cnt = std::min(cap, w->n_psd_big);
+    for (int c = 0; c < cnt; ++c) {
+      double st[kPsdStateDoubles];
+      const long at = w->psd_woff_h[(size_t)c] + psd_scratch_doubles(w->psd_order_h[(size_t)c]) - kPsdStateDoubles;
+      HIP_CHECK(hipMemcpy(st, w->psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
+      out[5 * c + 0] = st[9];
+      out[5 * c + 1] = st[10];
+      out[5 * c + 2] = st[8];
+      out[5 * c + 3] = st[11];
+      out[5 * c + 4] = st[7];
+    }
+    return cnt;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
 int scs_hip_time_psd(ScsWork *w, int reps, double *out) {
   if (!w || !out || reps <= 0) return -1;
   try {
@@ -3129,6 +3186,50 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
     dx.download(x, m, ts.s);
     HIP_CHECK(hipStreamSynchronize(ts.s));
     return 0;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
+int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, int count, scs_float *stats, int stats_cap) {
+  try {
+    set_last_error("");
+    if (count < 0 || !xs) throw std::runtime_error("invalid sequence");
+    ScsHipWork w;
+    if (!build_cone(k, w.cone) || w.cone.m != m) throw std::runtime_error("invalid cone");
+    TmpStream ts;
+    w.stream = ts.s;
+    w.owns_stream = false;
+    w.m = m;
+    w.psd_warm = 1;  // as inside the ADMM loop: the eigenvectors (and every other cone's warm-start state) carry over
+    upload_cone_meta(&w);
+    w.sc.alloc_zero(S_COUNT, ts.s);
+    const double one = 1.0;
+    HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, ts.s));
+    DevBuf<double> dx;
+    dx.alloc((size_t)std::max(m, 1));
+    for (int c = 0; c < count; ++c) {
+      HIP_CHECK(hipMemcpyAsync(dx.p, xs + (size_t)c * m, sizeof(double) * m, hipMemcpyHostToDevice, ts.s));
+      if (w.cone.z + w.cone.l > 0)
+        hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
+                           w.cone.z, w.cone.l, dual);
+      w.project_nonlinear_cones(dx.p, dual);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(xs + (size_t)c * m, dx.p, sizeof(double) * m, hipMemcpyDeviceToHost, ts.s));
+      HIP_CHECK(hipStreamSynchronize(ts.s));
+    }
+    int nst = 0;
+    if (stats && stats_cap > 0) {
+      nst = std::min(stats_cap, w.n_psd_big);
+      for (int c = 0; c < nst; ++c) {
+        double st[kPsdStateDoubles];
+        const long at = w.psd_woff_h[(size_t)c] + psd_scratch_doubles(w.psd_order_h[(size_t)c]) - kPsdStateDoubles;
+        HIP_CHECK(hipMemcpy(st, w.psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
+        stats[5 * c + 0] = st[9]; stats[5 * c + 1] = st[10]; stats[5 * c + 2] = st[8]; stats[5 * c + 3] = st[11]; stats[5 * c + 4] = st[7];
+      }
+    }
+    return nst;
   } catch (const std::exception &e) {
     set_last_error(e.what());
     return -1;

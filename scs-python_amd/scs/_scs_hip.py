@@ -169,6 +169,8 @@ def _load():
     lib.scs_hip_spmv_bench.argtypes = [C.POINTER(_ScsMatrix), c_int, c_int]
     lib.scs_hip_proj_cone.restype = c_int
     lib.scs_hip_proj_cone.argtypes = [_PD, C.POINTER(_ScsCone), c_int, c_int]
+    lib.scs_hip_proj_cone_seq.restype = c_int
+    lib.scs_hip_proj_cone_seq.argtypes = [_PD, C.POINTER(_ScsCone), c_int, c_int, c_int, _PD, c_int]
     lib.scs_hip_kkt_solve.restype = c_int
     lib.scs_hip_kkt_solve.argtypes = [C.POINTER(_ScsMatrix), C.POINTER(_ScsMatrix), _PD, _PD, c_dbl, _PI]
     lib.scs_hip_normalize.restype = c_int
@@ -186,6 +188,8 @@ def _load():
     lib.scs_hip_get_mark.argtypes = [C.c_void_p, _PD]
     lib.scs_hip_time_psd.restype = c_int
     lib.scs_hip_time_psd.argtypes = [C.c_void_p, c_int, _PD]
+    lib.scs_hip_psd_refine_stats.restype = c_int
+    lib.scs_hip_psd_refine_stats.argtypes = [C.c_void_p, _PD, c_int]
     lib.scs_hip_time_matvec.restype = c_int
     lib.scs_hip_time_matvec.argtypes = [C.c_void_p, c_int, _PD]
     lib.scs_hip_copy_bandwidth.restype = c_dbl
@@ -628,6 +632,16 @@ class SCS(object):
         _check(rc)
         return {"ms": float(out[0]), "matrices": int(out[1]), "max_order": int(out[2]), "ref_flops": float(out[3])}
 
+    def _psd_refine_stats(self, cap=4096):
+        """per PSD matrix of order > 32: [calls refined, refinements sent back to the sweeps, |K1|_F^2 at the last gate,
+        mixed-sign off-norm^2 / |A|^2 after the last refinement, stage flag of the last call] (include/scs_hip.h)"""
+        out = np.zeros(5 * cap)
+        with self._lock:
+            cnt = _lib.scs_hip_psd_refine_stats(self._work, _pd(out), int(cap))
+        if cnt < 0:
+            raise RuntimeError("libscs_hip: " + last_error())
+        return out[:5 * cnt].reshape(cnt, 5)
+
     def _time_matvec(self, reps=20):
         out = np.zeros(2)
         with self._lock:
@@ -762,6 +776,19 @@ def proj_cone(z, cone, dual=False):
     k, keep = _cone_struct(cone)
     _check(_lib.scs_hip_proj_cone(_pd(x), C.byref(k), x.size, 1 if dual else 0))
     return x
+
+
+def proj_cone_seq(zs, cone, dual=False, stats_cap=0):
+    """rows of zs projected one after the other through one set of warm-started cone workspaces (include/scs_hip.h);
+    returns (projections, refinement records of the large PSD matrices)"""
+    xs = np.array(zs, dtype=np.float64, copy=True, order="C")
+    assert xs.ndim == 2
+    k, keep = _cone_struct(cone)
+    st = np.zeros(5 * max(stats_cap, 1))
+    cnt = _lib.scs_hip_proj_cone_seq(_pd(xs), C.byref(k), xs.shape[1], 1 if dual else 0, xs.shape[0], _pd(st), int(stats_cap))
+    if cnt < 0:
+        raise RuntimeError("libscs_hip: " + last_error())
+    return xs, st[:5 * cnt].reshape(cnt, 5)
 
 
 def kkt_solve(A, P, diag_r, rhs, tol=1e-12):

@@ -639,6 +639,7 @@ def test_persistent_cg_bit_identical(hip, oracle, monkeypatch, cfg, with_P):
 
 # ---- K9 split mode (sweeps on one CU + V updates / reconstruction on the others) vs the one-launch kernel ----
 def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
+    monkeypatch.setenv("SCS_HIP_PSD_REFINE", "0")  # strict sweeps (the refinement stage of round 5 exists in split mode only: tests/test_psd_refine_gpu.py)
     rng = np.random.RandomState(11)
     K = {"l": 5, "s": [40, 64, 33, 100], "cs": [20]}
     z = rng.randn(pg.cone_dims(K))

@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
   std::printf("order %d (padded %ld), %d matrices, perturbation %.1e; ticks are 10 ns (thread 0 of matrix 0)\n", n, psd_np(n), cnt, pert);
   std::printf("call   total_us | unpack  warmGEMM   pivots  updates  norms+sched  reconstruct | sweeps  steps  pivot_us/step  update_us/step\n");
   const long np = psd_np(n);
-  const long st_off = psd_scratch_doubles(n) - 8;  // state[] at the end of matrix 0's scratch
+  const long st_off = psd_scratch_doubles(n) - kPsdStateDoubles;  // state[] at the end of matrix 0's scratch
   for (int call = 0; call < calls; ++call) {
     for (size_t i = 0; i < x.size(); ++i) x[i] = x0[i] * (1.0 + pert * call) + pert * call * nd(g);
     HIP_CHECK(hipMemcpy(d_x, x.data(), x.size() * 8, hipMemcpyHostToDevice));

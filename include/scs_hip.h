@@ -177,9 +177,10 @@ void scs_hip_aa_finish(ScsHipAa *a);
 int scs_hip_time_psd(ScsWork *w, int reps, double *out);
 
 /* K9's refinement stage (csrc/psd.hpp psd_stop_test), diagnostics for tests and bench: for each of the first `cap` PSD matrices of
- * order > 32 of the workspace five doubles {calls that took the refinement stage so far, refinements whose a-posteriori test sent the
+ * order > 32 of the workspace EIGHT doubles {calls that took the refinement stage so far, refinements whose a-posteriori test sent the
  * matrix back to the sweeps, |K1|_F^2 at the last gate, mixed-sign off-norm^2 / |A|_F^2 after the last refinement, stage flag of the
- * last call (0 none, 1 refined, 2 refined + sweeps)}.  Returns the number of matrices written, -1 on error. */
+ * last call (0 none, 1 refined, 2 refined + sweeps), and the gate's view of the last call's matrix as it arrived: |K1|_F^2,
+ * |off|_F^2 / |A|_F^2, omega}.  Returns the number of matrices written, -1 on error. */
 int scs_hip_psd_refine_stats(ScsWork *w, double *out, int cap);
 
 /* last error message of the calling thread ("" if none) */

@@ -435,7 +435,7 @@ __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_sto
 // argument: K1 is exactly antisymmetric.
 template <bool AGENT>
 __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, double *diag, double *red, double *bc, double offtol2, int mode,
-                                             const PsdRefineCfg &R, double *state, bool lead, double *K1 = nullptr) {
+                                             const PsdRefineCfg &R, double *state, bool lead, double *K1 = nullptr, bool first = false) {
   const int tid = threadIdx.x;
   const bool wk = K1 != nullptr && lead && mode == PSD_STOP_GATE;
   if (wk) {  // rows / columns of the padding
@@ -451,6 +451,34 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
     __syncthreads();
   }
   double off = 0., tot = 0., mix = 0., kf = 0., om = 0.;
+  if (mode != PSD_STOP_STRICT) {
+    // column by column (wavefront w: columns w, w + 16, ...; lanes down the rows): no index arithmetic, coalesced loads and K1 stores.
+    // (The strict test below keeps the element order of rounds 1-4 — the bits of the one-launch kernel's decision.)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < n; j += kPsdWaves) {
+      const double dj = diag[j];
+      const bool pj = dj > 0.;
+      for (int i = lane; i < n; i += 64) {
+        const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
+        const double a2 = a * a;
+        tot += a2;
+        double k1 = 0.;
+        if (i != j) {
+          off += a2;
+          const double di = diag[i];
+          if ((di > 0.) != pj) {
+            const double r = __builtin_amdgcn_rcp(dj - di);  // (a hardware estimate is enough for a gate, and K1 only enters the second-order term)
+            k1 = a * r;
+            mix += a2;
+            kf += k1 * k1;
+          } else if (a2 > 0.) {
+            om += a2 * __builtin_amdgcn_rcp(di * dj);  // same sign: positive; a zero diagonal entry under a nonzero row: inf, no refinement
+          }
+        }
+        if (wk) K1[i + (size_t)ld * j] = k1;
+      }
+    }
+  } else
   for (int e = tid; e < n * n; e += kPsdThreads) {
     const int i = e % n, j = e / n;
     const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
@@ -487,6 +515,7 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
     if (!code && mode == PSD_STOP_GATE && kf <= R.k2 && off <= R.off2 * tot && om <= R.omega) code = 2;
     if (!code && mode == PSD_STOP_RELAXED && mix <= offtol2 * tot && om <= R.omega_relaxed) code = 1;
     if (lead && code == 2) state[8] = kf;
+    if (lead && mode == PSD_STOP_GATE && first) { state[12] = kf; state[13] = tot > 0. ? off / tot : 0.; state[14] = om; }  // (diagnostics: what the matrix looked like as it arrived)
     if (lead && mode == PSD_STOP_RELAXED) state[11] = tot > 0. ? mix / tot : 0.;
     bc[0] = (double)code;
   }
@@ -682,7 +711,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_proj_psd(double *x, PsdBatch B,
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_sw0);
     // relative off-norm 1e-8: the reconstruction below is second-order accurate in what is left
-    const int code = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, true, Vt);
+    const int code = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, true, Vt, round == 0 && sweep == 0);
     PSD_TICK(t_sw1);
     PSD_ACC(5, t_sw0, t_sw1);
     if (code != 0) {
@@ -1007,7 +1036,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   // ADMM — or refined to the relaxed level) leaves without a barrier.  Every member decides on the same data: the same decision.
   const int stop_mode = R.on ? (refined ? PSD_STOP_RELAXED : (post ? PSD_STOP_STRICT : PSD_STOP_GATE)) : PSD_STOP_STRICT;
   double *Vt = A + 3 * (size_t)NP * NP;  // free between the warm-start GEMMs and k_psd_fmap: K1 / Q' of the refinement stage
-  const int code_first = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt);  // (plain loads: written by earlier kernels)
+  const int code_first = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt, round == 0);  // (plain loads: written by earlier kernels)
   if (code_first != 0) {
     if (g == 0) {
       if (tid == 0) {
@@ -1421,30 +1450,44 @@ __global__ __launch_bounds__(kPsdApplyThreads) void k_psd_apply_q(PsdBatch B, do
 //   S1    S1 = Q' T, lower tiles + mirror + symmetrised diagonal tiles (the epilogue of G2)                              Vt, Tm -> A
 //   (Tm is the sweeps' second copy of A while they run: it is free again when the stage starts, and the round behind it finds Q' dead)
 enum : int { PSD_G1 = 0, PSD_G2, PSD_R1, PSD_R2, PSD_COMM, PSD_KK, PSD_T, PSD_S1 };
-#ifndef PSD_GEMM_THREADS
-#define PSD_GEMM_THREADS 128
-#endif
-constexpr int kPsdGemmThreads = PSD_GEMM_THREADS;
+// Round 5: who computes what.  A launch was 28 tasks of 2 x 4 tiles per order-200 matrix, two wavefronts per workgroup: 1400 wavefronts
+// on 1024 SIMDs, so the launch took as long as the SIMDs that got two of them — 2 x 8 tiles x 52 k-steps x 64 clocks = 22 us of matrix-core
+// time, whatever the operand fetches did (16-byte loads, a real software pipeline: no change) — and the kinds that only need the lower
+// triangle took as long as the full ones.  Now a task is a ROW PAIR x a column group of about five tiles (the trailing single row of an
+// odd tile count: groups of about eight), ONE wavefront = one workgroup per task, so that the tasks of a launch fit the SIMDs one each:
+// order 200 (13 tiles): 6 x 3 + 2 = 20 tasks of <= 10 tiles per matrix, 1000 per launch of 50; lower-triangular kinds 14.
+// Tasks are dealt to the XCDs in contiguous runs (psd_gemm_grid): an L2 sees the operands of ~1/8 of the matrices.
+constexpr int kPsdGemmThreads = 64;
 constexpr int kPsdRT = 2;
-constexpr int kPsdPf = 4;  // k-steps in flight
-__host__ __device__ inline int psd_gemm_tasks(int ntile) { return ((ntile + kPsdRT - 1) / kPsdRT) * ((ntile + kPsdNJ - 1) / kPsdNJ); }
-__host__ inline unsigned psd_gemm_wgs(int max_tiles) { return (unsigned)((psd_gemm_tasks(max_tiles) + kPsdGemmThreads / 64 - 1) / (kPsdGemmThreads / 64)); }
+constexpr int kPsdPf = 4;      // k-steps per trip of the software pipeline
+constexpr int kPsdNJ2max = 4;  // column tiles of a task come in pairs (one 16-byte load): at most 8
+__host__ __device__ inline int psd_gemm_ncg(int ntile) { return (ntile + 4) / 5; }           // column groups of a row pair
+__host__ __device__ inline int psd_gemm_ncg1(int ntile) { return (ntile + 7) / 8; }          // ... of the trailing single row
+__host__ __device__ inline int psd_gemm_cstart(int g, int ncg, int ntile) { return g >= ncg ? ntile : 2 * ((g * ntile) / (2 * ncg)); }
+__host__ __device__ inline int psd_gemm_cstart1(int g, int ncg, int ntile) { return g >= ncg ? ntile : 2 * ((2 * g * ntile + 2 * ncg) / (4 * ncg)); }  // (rounded: widths <= 8)
+__host__ __device__ inline int psd_gemm_tasks(int ntile) { return (ntile / 2) * psd_gemm_ncg(ntile) + (ntile & 1) * psd_gemm_ncg1(ntile); }
+// 1-D grid of 8 * chunk workgroups, chunk = ceil(count * per / 8): workgroup id -> XCD (id & 7) -> global task xcd * chunk + (id >> 3)
+__host__ inline unsigned psd_gemm_grid(int per, int count) { return 8u * (unsigned)(((long)count * per + 7) / 8); }
+
 template <int KIND>
-__global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall) {
+__global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatch B, double *scratch, int allow_warm, const int *stall, int per) {
   SCS_STALL_GUARD(stall);
-  const PsdWg wg = psd_wg(B.count);
-  if (!wg.ok) return;
-  __shared__ double Sws[kPsdGemmThreads / 64][16 * 17];
-  __shared__ double Rws[kPsdGemmThreads / 64][32 * 33];  // a tile pair x column pair of accumulators on their way back to whole tiles
-  const int n = B.order[wg.cidx];
+  __shared__ double Sw[16 * 17];
+  __shared__ double Rw[32 * 33];  // a tile pair x column pair of accumulators on their way back to whole tiles
+  const int chunk = (int)gridDim.x >> 3;
+  const int gtask = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int cidx = gtask / per, task = gtask - cidx * per;
+  if (cidx >= B.count) return;
+  const int n = B.order[cidx];
   if (n < 2) return;  // orders 0 and 1 were finished by the front kernel
   const int NP = (int)psd_np(n), ntile = NP / 16, H = NP / kPsdB / 2, ld = NP;
-  double *A = scratch + B.woff[wg.cidx];
+  if (task >= psd_gemm_tasks(ntile)) return;  // (`per` is the task count of the largest matrix of the batch)
+  double *A = scratch + B.woff[cidx];
   double *V = A + (size_t)NP * NP;
   double *Tm = V + (size_t)NP * NP;
   double *Vt = Tm + (size_t)NP * NP;  // V' for G1 / G2; F = Pi_+(D + E) (k_psd_fmap) for R1
   double *state = Vt + (size_t)NP * NP + (size_t)H * kPsdWsz + psd_log_doubles(n) + NP;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
   const bool warm = allow_warm && state[0] >= 1.;
   if ((KIND == PSD_G1 || KIND == PSD_G2) && !warm) return;  // cold start: A0 = A
   if (KIND >= PSD_COMM && state[7] != 1.) return;            // no refinement stage for this matrix in this call
@@ -1456,110 +1499,138 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
   const double *Aop = KIND == PSD_G1 || KIND == PSD_G2 || KIND == PSD_S1 ? Vt : KIND == PSD_R1 ? V : KIND == PSD_COMM || KIND == PSD_T ? A : Tm;
   const double *Bop = KIND == PSD_G1 ? A : KIND == PSD_G2 || KIND == PSD_KK || KIND == PSD_S1 ? Tm : KIND == PSD_R1 || KIND == PSD_COMM || KIND == PSD_T ? Vt : V;
   double *Ko = KIND == PSD_COMM || KIND == PSD_T ? Tm : Vt;  // where COMM / T (Tm) and KK (Vt) leave their result; KK reads K2 from Tm
-  double *X = x + B.off[wg.cidx];
+  double *X = x + B.off[cidx];
   const double sq2 = 1.41421356237309504880;
-  const int ntr = (ntile + kPsdRT - 1) / kPsdRT, ntask = psd_gemm_tasks(ntile);
-  double *Sw = Sws[wave], *Rw = Rws[wave];
-  for (int task = wg.bx * (kPsdGemmThreads / 64) + wave; task < ntask; task += wg.per * (kPsdGemmThreads / 64)) {
-    const int ti0 = (task % ntr) * kPsdRT, tj0 = (task / ntr) * kPsdNJ;
-    const int tilast = min(ti0 + kPsdRT - 1, ntile - 1);
-    if (lower && tj0 > tilast) continue;
-    f64x4 acc[kPsdRT][kPsdNJ];
+  // task -> (row pair | trailing single row, column group)
+  const int npair = ntile / 2, ncg = psd_gemm_ncg(ntile), ncg1 = psd_gemm_ncg1(ntile);
+  int ti0, rows, tj0, tj1;
+  if (task < npair * ncg) {
+    const int rp = task / ncg, g = task - rp * ncg;
+    ti0 = 2 * rp;
+    rows = 2;
+    tj0 = psd_gemm_cstart(g, ncg, ntile);
+    tj1 = psd_gemm_cstart(g + 1, ncg, ntile);
+  } else {
+    const int g = task - npair * ncg;
+    ti0 = ntile - 1;
+    rows = 1;
+    tj0 = psd_gemm_cstart1(g, ncg1, ntile);
+    tj1 = psd_gemm_cstart1(g + 1, ncg1, ntile);
+  }
+  const int tilast = ti0 + rows - 1;
+  if (lower && tj0 > tilast) return;
+  if (lower) tj1 = min(tj1, tilast + 1);
+  const int nj2 = (tj1 - tj0 + 1) / 2;  // column-tile pairs of this task (1 .. kPsdNJ2max)
+  f64x4 acc[kPsdRT][2 * kPsdNJ2max];
 #pragma unroll
-    for (int j = 0; j < kPsdNJ; ++j)
+  for (int j = 0; j < 2 * kPsdNJ2max; ++j)
 #pragma unroll
-      for (int r = 0; r < kPsdRT; ++r) acc[r][j] = f64x4{0., 0., 0., 0.};
-    // Operand fetches (round 5): ONE 16-byte load per lane brings the A operands of both row tiles and one brings the B operands of
-    // two column tiles — lane li holds rows 2 li and 2 li + 1 of the 32 rows of the tile pair, so the "tiles" the matrix cores work on
-    // are the even and the odd rows (columns) of the pair; which row a lane feeds does not enter an output element's arithmetic
-    // (its four k-terms are added in the same order), so every element keeps its bits.  3 load instructions per k-step instead
-    // of 6: these launches were bound by the texture addresser (~35 clocks per load instruction against 16 per MFMA and CU).
-    // The accumulators come out interleaved the same way and are put back into whole tiles through LDS before the epilogue.
-    // Rows / columns beyond the matrix (the odd tile at the edge) are read from whatever follows in the scratch — finite numbers
-    // that only reach accumulator entries the epilogue skips.
-    const int ldh = ld / 2;  // (NP is a multiple of 16; every operand buffer starts on a 16-byte boundary)
+    for (int r = 0; r < kPsdRT; ++r) acc[r][j] = f64x4{0., 0., 0., 0.};
+  // Operand fetches (round 5): ONE 16-byte load per lane brings the A operands of both row tiles and one brings the B operands of
+  // two column tiles — lane li holds rows 2 li and 2 li + 1 of the 32 rows of the tile pair, so the "tiles" the matrix cores work on
+  // are the even and the odd rows (columns) of the pair; which row a lane feeds does not enter an output element's arithmetic
+  // (its four k-terms are added in the same order), so every element keeps its bits.  The accumulators come out interleaved the
+  // same way and are put back into whole tiles through LDS before the epilogue.  Rows / columns beyond the matrix (the odd tile
+  // at the edge) are read from whatever follows in the scratch — finite numbers that only reach accumulator entries the
+  // epilogue skips.
+  const int ldh = ld / 2;  // (NP is a multiple of 16; every operand buffer starts on a 16-byte boundary)
+  // Software pipeline over the k-steps, a TRIP = kPsdPf k-steps: two register sets, the loads of the next trip are issued before the
+  // MFMAs of the current one.  Every load is unconditional (the tail re-fetches the last trip: a conditional load in this loop makes
+  // hipcc fall back to s_waitcnt vmcnt(0)).  (One set carried around the back edge and refilled behind its use was rotated by hipcc
+  // into load - wait - use: s_waitcnt vmcnt(9) right behind the twelve loads of a trip.)
+  auto product = [&](auto rows_tag, auto nj2_tag) {
+    constexpr int ROWS = decltype(rows_tag)::value, NJ2 = decltype(nj2_tag)::value;
 #pragma unroll
     for (int pass = 0; pass < npass; ++pass) {
-    const double *Ao = pass == 0 ? Aop : Bop, *Bo = pass == 0 ? Bop : Aop;  // (COMM: the second product has the operands swapped)
-    const f64x2 *pa2 = reinterpret_cast<const f64x2 *>(Ao + ti0 * 16 + 2 * li + (size_t)ld * lk);
-    const f64x2 *pb2[kPsdNJ / 2];
+      const double *Ao = pass == 0 ? Aop : Bop, *Bo = pass == 0 ? Bop : Aop;  // (COMM: the second product has the operands swapped)
+      const f64x2 *pa2 = reinterpret_cast<const f64x2 *>(Ao + ti0 * 16 + 2 * li + (size_t)ld * lk);
+      const double *pa1 = Ao + ti0 * 16 + li + (size_t)ld * lk;
+      const f64x2 *pb2[NJ2];
 #pragma unroll
-    for (int j = 0; j < kPsdNJ / 2; ++j) pb2[j] = reinterpret_cast<const f64x2 *>(Bo + tj0 * 16 + 32 * j + 2 * li + (size_t)ld * lk);
-    // Software pipeline over the k-steps, a TRIP = kPsdPf k-steps: two register sets, the loads of the next trip are issued before the
-    // MFMAs of the current one.  Every load is unconditional (the tail re-fetches the last trip: a conditional load in this loop makes
-    // hipcc fall back to s_waitcnt vmcnt(0)).  Round 5: until now the loop carried ONE set around its back edge and refilled each stage
-    // behind its use; hipcc rotated that into load - wait - use (ISA: s_waitcnt vmcnt(9) right behind the twelve loads of a trip),
-    // i.e. the L2 latency once per trip, 13 times per task — 22 us of a 33 us launch at order 200.  With two named sets whichever way
-    // the loop is rotated a trip's MFMAs only wait for loads issued a whole trip earlier.
-    f64x2 a0[kPsdPf], b0[kPsdPf][kPsdNJ / 2], a1[kPsdPf], b1[kPsdPf][kPsdNJ / 2];
-    auto load = [&](f64x2 (&as)[kPsdPf], f64x2 (&bs)[kPsdPf][kPsdNJ / 2], int trip) {
+      for (int j = 0; j < NJ2; ++j) pb2[j] = reinterpret_cast<const f64x2 *>(Bo + tj0 * 16 + 32 * j + 2 * li + (size_t)ld * lk);
+      f64x2 a0[kPsdPf], b0[kPsdPf][NJ2], a1[kPsdPf], b1[kPsdPf][NJ2];
+      auto load = [&](f64x2 (&as)[kPsdPf], f64x2 (&bs)[kPsdPf][NJ2], int trip) {
 #pragma unroll
-      for (int st = 0; st < kPsdPf; ++st) {
-        const size_t at = (size_t)ldh * (4 * (kPsdPf * trip + st));
-        as[st] = pa2[at];
+        for (int st = 0; st < kPsdPf; ++st) {
+          const size_t at = (size_t)ldh * (4 * (kPsdPf * trip + st));
+          if (ROWS == 2) as[st] = pa2[at];
+          else as[st].x = pa1[2 * at];  // the trailing single row tile: lane li feeds row li, as in the one-workgroup kernels
 #pragma unroll
-        for (int j = 0; j < kPsdNJ / 2; ++j) bs[st][j] = pb2[j][at];
+          for (int j = 0; j < NJ2; ++j) bs[st][j] = pb2[j][at];
+        }
+      };
+      auto use = [&](const f64x2 (&as)[kPsdPf], const f64x2 (&bs)[kPsdPf][NJ2]) {
+#pragma unroll
+        for (int st = 0; st < kPsdPf; ++st) {
+          const double a[kPsdRT] = {as[st].x, as[st].y};
+#pragma unroll
+          for (int j = 0; j < NJ2; ++j)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+              acc[r][2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bs[st][j].x, acc[r][2 * j], 0, 0, 0);
+              acc[r][2 * j + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], bs[st][j].y, acc[r][2 * j + 1], 0, 0, 0);
+            }
+        }
+      };
+      const int ntrips = NP / (4 * kPsdPf);  // NP is a multiple of 16 = 4 kPsdPf
+      load(a0, b0, 0);
+      int trip = 0;
+      for (; trip + 1 < ntrips; trip += 2) {
+        load(a1, b1, trip + 1);
+        use(a0, b0);
+        load(a0, b0, min(trip + 2, ntrips - 1));
+        use(a1, b1);
       }
-    };
-    auto use = [&](const f64x2 (&as)[kPsdPf], const f64x2 (&bs)[kPsdPf][kPsdNJ / 2]) {
-#pragma unroll
-      for (int st = 0; st < kPsdPf; ++st) {
-        const double a[kPsdRT] = {as[st].x, as[st].y};
-        double b[kPsdNJ];
-#pragma unroll
-        for (int j = 0; j < kPsdNJ / 2; ++j) { b[2 * j] = bs[st][j].x; b[2 * j + 1] = bs[st][j].y; }
-#pragma unroll
-        for (int r = 0; r < kPsdRT; ++r)
-#pragma unroll
-          for (int j = 0; j < kPsdNJ; ++j) acc[r][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[j], acc[r][j], 0, 0, 0);
-      }
-    };
-    const int ntrips = NP / (4 * kPsdPf);  // NP is a multiple of 16 = 4 kPsdPf
-    load(a0, b0, 0);
-    int trip = 0;
-    for (; trip + 1 < ntrips; trip += 2) {
-      load(a1, b1, trip + 1);
-      use(a0, b0);
-      load(a0, b0, min(trip + 2, ntrips - 1));
-      use(a1, b1);
+      if (trip < ntrips) use(a0, b0);  // an odd number of trips: the last one sits in the first set
     }
-    if (trip < ntrips) use(a0, b0);  // an odd number of trips: the last one sits in the first set
-    }  // pass
-    // acc[r][j][t] = C[row 2 (lk + 4t) + r of the tile pair][column 2 li + (j & 1) of column pair j >> 1]
+  };
+  using std::integral_constant;
+  if (rows == 2) {
+    if (nj2 == 1) product(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    else if (nj2 == 2) product(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    else product(integral_constant<int, 2>{}, integral_constant<int, 3>{});
+  } else {
+    if (nj2 <= 2) product(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    else product(integral_constant<int, 1>{}, integral_constant<int, 4>{});
+  }
+  // acc[r][j][t] = C[row 2 (lk + 4t) + r of the tile pair (single row tile: row lk + 4t)][column 2 li + (j & 1) of column pair j >> 1]
 #pragma unroll
-    for (int jp = 0; jp < kPsdNJ / 2; ++jp) {
-      if (tj0 + 2 * jp >= ntile || (lower && tj0 + 2 * jp > tilast)) break;  // (uniform: nothing of this column pair is wanted)
+  for (int jp = 0; jp < kPsdNJ2max; ++jp) {
+    if (tj0 + 2 * jp >= tj1) break;  // (uniform: nothing of this column pair is wanted)
 #pragma unroll
-      for (int r = 0; r < kPsdRT; ++r)
+    for (int r = 0; r < kPsdRT; ++r)
 #pragma unroll
-        for (int cq = 0; cq < 2; ++cq)
+      for (int cq = 0; cq < 2; ++cq)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) Rw[(2 * (lk + 4 * t) + r) + 33 * (2 * li + cq)] = acc[r][2 * jp + cq][t];
-      wave_sync();
+        for (int t = 0; t < 4; ++t) {
+          const int row = rows == 2 ? 2 * (lk + 4 * t) + r : 16 * r + lk + 4 * t;
+          Rw[row + 33 * (2 * li + cq)] = acc[r][2 * jp + cq][t];
+        }
+    wave_sync();
 #pragma unroll
-      for (int r = 0; r < kPsdRT; ++r) {
-        const int ti = ti0 + r;
-        if (ti >= ntile) break;
+    for (int r = 0; r < kPsdRT; ++r) {
+      const int ti = ti0 + r;
+      if (r >= rows) break;
 #pragma unroll
-        for (int cq = 0; cq < 2; ++cq) {
-          const int tj = tj0 + 2 * jp + cq;
-          if (tj >= ntile || (lower && tj > ti)) break;
-          f64x4 c;  // lane holds C[row = lk + 4t][col = li] of tile (ti, tj)
+      for (int cq = 0; cq < 2; ++cq) {
+        const int tj = tj0 + 2 * jp + cq;
+        if (tj >= tj1 || (lower && tj > ti)) break;
+        f64x4 c;  // lane holds C[row = lk + 4t][col = li] of tile (ti, tj)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) c[t] = Rw[(16 * r + lk + 4 * t) + 33 * (16 * cq + li)];
-        if (KIND == PSD_G1 || KIND == PSD_R1) {  // stored through the 16x17 transpose: li runs down the columns of the result
-  #pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = Rw[(16 * r + lk + 4 * t) + 33 * (16 * cq + li)];
+          if (KIND == PSD_G1 || KIND == PSD_R1) {  // stored through the 16x17 transpose: li runs down the columns of the result
+#pragma unroll
             for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
             wave_sync();
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)] = Sw[li + 17 * (lk + 4 * t)];
             wave_sync();
           } else if (KIND == PSD_T) {  // T' straight from the C layout: li runs down a column of the transpose
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) Ko[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
           } else if (KIND == PSD_COMM) {
             double val[4];
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
               const double di = lam[i], dj = lam[jc];
@@ -1567,13 +1638,13 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
               val[t] = ((di > 0.) != (dj > 0.)) ? (2. * sij - c[t]) / (dj - di) : 0.;
             }
             if (ti != tj) {
-  #pragma unroll
+#pragma unroll
               for (int t = 0; t < 4; ++t) Ko[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = -val[t];  // K2_ji = -K2_ij
             }
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = val[t];
             wave_sync();
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int rr = li, cc = lk + 4 * t;
               double v = Sw[rr + 17 * cc];
@@ -1583,16 +1654,16 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
             wave_sync();
           } else if (KIND == PSD_KK) {  // Q'_ij = delta_ij - K2_ij - acc_ij / 2 (acc = K2 K2' = -K2^2), both triangles from the lower tiles
             if (ti != tj) {
-  #pragma unroll
+#pragma unroll
               for (int t = 0; t < 4; ++t) {  // the mirror entry (jc, i): its own K2 entry is read where it lies (coalesced)
                 const size_t at = (tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t);
                 Ko[at] = -Tm[at] - 0.5 * c[t];
               }
             }
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
             wave_sync();
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int rr = li, cc = lk + 4 * t;
               double v = Sw[rr + 17 * cc];
@@ -1603,13 +1674,13 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
             wave_sync();
           } else if (KIND == PSD_G2 || KIND == PSD_S1) {  // mirrored; diagonal tiles symmetrised (average of the two triangles): A0 exactly symmetric
             if (ti != tj) {
-  #pragma unroll
+#pragma unroll
               for (int t = 0; t < 4; ++t) A[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] = c[t];
             }
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) Sw[(lk + 4 * t) + 17 * li] = c[t];
             wave_sync();
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int rr = li, cc = lk + 4 * t;
               double v = Sw[rr + 17 * cc];
@@ -1618,7 +1689,7 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
             }
             wave_sync();
           } else {  // R2: lower-triangular tiles straight into the packed vector
-  #pragma unroll
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
               const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
               if (i < n && jc <= i) {
@@ -1627,13 +1698,12 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
               }
             }
           }
-  
-        }
+
       }
-      wave_sync();
     }
+    wave_sync();
   }
-  if (KIND == PSD_R2 && wg.bx == 0 && tid == 0) state[0] = warm ? state[0] + 1. : 1.;
+  if (KIND == PSD_R2 && task == 0 && lane == 0) state[0] = warm ? state[0] + 1. : 1.;
 }
 
 // ---------------------------------------------------------------------------

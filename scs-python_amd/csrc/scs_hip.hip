@@ -749,15 +749,16 @@ struct ScsHipWork {
       PsdBatch B{off, order, woff, big};
       if (psd_split) {
         // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
-        const dim3 gg(psd_xcd_grid((int)psd_gemm_wgs(psd_max_tiles), big)), gb(kPsdGemmThreads);  // 1-D grids: a matrix's workgroups on one XCD (psd.hpp psd_wg)
+        const int gper = psd_gemm_tasks(std::max(psd_max_tiles, 1));  // tasks (= workgroups of one wavefront) per matrix, dealt to the XCDs in runs
+        const dim3 gg(psd_gemm_grid(gper, big)), gb(kPsdGemmThreads);
         const dim3 gt(psd_xcd_grid(std::max(psd_max_tiles, 1), big));
         // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
         hipLaunchKernelGGL(k_psd_front, gt, dim3(kPsdFrontThreads), 0, stream,
                            (const double *)base, B, psd_scratch.p, psd_warm, stall);
         hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
                            psd_refine_default(false), 0);
-        hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-        hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
         int mc = in_capture ? 1 : psd_mc_members(big);
         PsdRefineCfg R = psd_refine;
         if ((size_t)32 * psd_max_np * sizeof(double) > 160 * 1024) R.on = 0;  // k_psd_apply_q keeps two 16-row strips in LDS
@@ -766,10 +767,10 @@ struct ScsHipWork {
           if (post) {
             // the refinement stage (psd.hpp psd_stop_test): matrices the sweeps left REFINABLE get the mixed-sign part of S = V'AV
             // removed by GEMMs; the round behind it re-tests them (and goes on sweeping whatever is not done: nothing is lost)
-            hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-            hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-            hipLaunchKernelGGL(k_psd_gemm<PSD_T>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-            hipLaunchKernelGGL(k_psd_gemm<PSD_S1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_T>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_S1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
             hipLaunchKernelGGL(k_psd_apply_q, gt, dim3(kPsdApplyThreads), (size_t)32 * psd_max_np * sizeof(double), stream, B,
                                psd_scratch.p, stall);
           }
@@ -803,8 +804,8 @@ struct ScsHipWork {
                              stream, B, psd_scratch.p, stall);
         }
         hipLaunchKernelGGL(k_psd_fmap, gt, dim3(256), 0, stream, B, psd_scratch.p, stall);
-        hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
-        hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
       } else {
         hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
                            psd_refine_default(false), 0);
@@ -2904,11 +2905,14 @@ int scs_hip_psd_refine_stats(ScsWork *w, double *out, int cap) {
       double st[kPsdStateDoubles];
       const long at = w->psd_woff_h[(size_t)c] + psd_scratch_doubles(w->psd_order_h[(size_t)c]) - kPsdStateDoubles;
       HIP_CHECK(hipMemcpy(st, w->psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
-      out[5 * c + 0] = st[9];
-      out[5 * c + 1] = st[10];
-      out[5 * c + 2] = st[8];
-      out[5 * c + 3] = st[11];
-      out[5 * c + 4] = st[7];
+      out[8 * c + 0] = st[9];
+      out[8 * c + 1] = st[10];
+      out[8 * c + 2] = st[8];
+      out[8 * c + 3] = st[11];
+      out[8 * c + 4] = st[7];
+      out[8 * c + 5] = st[12];
+      out[8 * c + 6] = st[13];
+      out[8 * c + 7] = st[14];
     }
     return cnt;
   } catch (const std::exception &e) {
@@ -3226,7 +3230,8 @@ int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, 
         double st[kPsdStateDoubles];
         const long at = w.psd_woff_h[(size_t)c] + psd_scratch_doubles(w.psd_order_h[(size_t)c]) - kPsdStateDoubles;
         HIP_CHECK(hipMemcpy(st, w.psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
-        stats[5 * c + 0] = st[9]; stats[5 * c + 1] = st[10]; stats[5 * c + 2] = st[8]; stats[5 * c + 3] = st[11]; stats[5 * c + 4] = st[7];
+        stats[8 * c + 0] = st[9]; stats[8 * c + 1] = st[10]; stats[8 * c + 2] = st[8]; stats[8 * c + 3] = st[11]; stats[8 * c + 4] = st[7];
+        stats[8 * c + 5] = st[12]; stats[8 * c + 6] = st[13]; stats[8 * c + 7] = st[14];
       }
     }
     return nst;

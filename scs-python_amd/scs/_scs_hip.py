@@ -634,13 +634,14 @@ class SCS(object):
 
     def _psd_refine_stats(self, cap=4096):
         """per PSD matrix of order > 32: [calls refined, refinements sent back to the sweeps, |K1|_F^2 at the last gate,
-        mixed-sign off-norm^2 / |A|^2 after the last refinement, stage flag of the last call] (include/scs_hip.h)"""
-        out = np.zeros(5 * cap)
+        mixed-sign off-norm^2 / |A|^2 after the last refinement, stage flag of the last call, then what the last call's matrix looked like
+        as it arrived: |K1|_F^2, |off|^2 / |A|^2, omega] (include/scs_hip.h)"""
+        out = np.zeros(8 * cap)
         with self._lock:
             cnt = _lib.scs_hip_psd_refine_stats(self._work, _pd(out), int(cap))
         if cnt < 0:
             raise RuntimeError("libscs_hip: " + last_error())
-        return out[:5 * cnt].reshape(cnt, 5)
+        return out[:8 * cnt].reshape(cnt, 8)
 
     def _time_matvec(self, reps=20):
         out = np.zeros(2)
@@ -784,11 +785,11 @@ def proj_cone_seq(zs, cone, dual=False, stats_cap=0):
     xs = np.array(zs, dtype=np.float64, copy=True, order="C")
     assert xs.ndim == 2
     k, keep = _cone_struct(cone)
-    st = np.zeros(5 * max(stats_cap, 1))
+    st = np.zeros(8 * max(stats_cap, 1))
     cnt = _lib.scs_hip_proj_cone_seq(_pd(xs), C.byref(k), xs.shape[1], 1 if dual else 0, xs.shape[0], _pd(st), int(stats_cap))
     if cnt < 0:
         raise RuntimeError("libscs_hip: " + last_error())
-    return xs, st[:5 * cnt].reshape(cnt, 5)
+    return xs, st[:8 * cnt].reshape(cnt, 8)
 
 
 def kkt_solve(A, P, diag_r, rhs, tol=1e-12):

@@ -17,7 +17,7 @@ for rep in range(2):
     st = s._solver._psd_refine_stats()
     print("%s rep %d: [0,105) %.1f ms = %.0f it/s   [105,225) %.1f ms = %.0f it/s   refined calls/matrix %.1f failed %.1f" % (
         tag, rep, mk["ms"], 105e3 / mk["ms"], i["solve_time"] - mk["ms"], 120e3 / (i["solve_time"] - mk["ms"]), st[:, 0].mean(), st[:, 1].mean()), flush=True)
-s = scs.SCS(d, K, verbose=False)
+s = scs.SCS(d, K, verbose=False, max_iters=3000)
 t0 = time.time()
 r = s.solve()
 t1 = time.time()

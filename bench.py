@@ -167,6 +167,9 @@ def main():
     if os.environ.get("SCS_HIP_RUNTIME_ENV", "1") != "0":
         os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (exported on the GPU boxes already: RCCL between ranks needs dmabuf IPC there)
+    # the library's device block pool (csrc/common.hpp DevPool) keeps 1 GiB by default; this process owns its GPU and tears down 512
+    # workspaces at a time in the batch leg: the cap of round 4 (an existing value wins)
+    os.environ.setdefault("SCS_HIP_POOL_MB", "16384")
     import torch  # first: its bundled HIP runtime must be the one in the process
     import torch.distributed as dist
     import numpy as np

@@ -176,6 +176,14 @@ void scs_hip_aa_finish(ScsHipAa *a);
  * ((16/3 + 2) n^3 per matrix)}.  0 on success, 1 when the problem has no PSD cone. */
 int scs_hip_time_psd(ScsWork *w, int reps, double *out);
 
+/* Hands the device blocks this library caches for reuse (dead workspaces' buffers, at most SCS_HIP_POOL_MB = 1024 MiB by default) back
+ * to the driver: for a process that shares its GPUs with allocators this library does not see (torch, RCCL, other processes). */
+void scs_hip_trim_pool(void);
+
+/* How many solves of this process were restarted because a spinning multi-workgroup kernel (multi-CU PSD sweeps, persistent CG)
+ * timed out at a barrier — another process held part of the GPU — and were then finished without such kernels (tests). */
+long scs_hip_spin_fallbacks(void);
+
 /* K9's refinement stage (csrc/psd.hpp psd_stop_test), diagnostics for tests and bench: for each of the first `cap` PSD matrices of
  * order > 32 of the workspace EIGHT doubles {calls that took the refinement stage so far, refinements whose a-posteriori test sent the
  * matrix back to the sweeps, |K1|_F^2 at the last gate, mixed-sign off-norm^2 / |A|_F^2 after the last refinement, stage flag of the

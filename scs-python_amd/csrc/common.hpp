@@ -35,7 +35,12 @@ inline void set_last_error(const std::string &s);
 // 0.3-0.5 s per batch of 512), hipMalloc maps: a workspace that dies hands its blocks here instead — only from ~ScsHipWork, which has
 // synchronised its stream first (t_pool_release; temporaries that die while their stream is still busy keep using hipFree, whose
 // implicit synchronisation is what makes that safe) — and every allocation looks here first (exact size, same device).
-// Bounded (SCS_HIP_POOL_MB, default 16384; 0 disables); emptied when a hipMalloc fails.
+// Bounded: SCS_HIP_POOL_MB, default 1024 (round 5, ADVICE r04: the 16 GiB of round 4 starved torch / RCCL and other processes of the
+// same GPU, whose failing allocations never reach trim() here; bench.py asks for 16384 itself: its batch legs tear down 512 workspaces
+// at a time); 0 disables; emptied when a hipMalloc of this library fails and by scs_hip_trim_pool().  Recycled blocks carry the
+// previous owner's data where driver-fresh pages were zero: every DevBuf user either writes its buffer before reading it or asks
+// for alloc_zero (which clears recycled blocks); SCS_HIP_POOL_POISON=1 fills every recycled block with NaN bit patterns first
+// (synchronously — a debug mode for running the test suite against that assumption).
 struct DevPool {
   std::mutex m;
   std::vector<std::pair<std::pair<int, size_t>, void *>> blocks;  // ((device, bytes), pointer)
@@ -43,7 +48,7 @@ struct DevPool {
   bool cap_read = false;
   static DevPool &inst() { static DevPool p; return p; }
   size_t capacity() {
-    if (!cap_read) { const char *e = getenv("SCS_HIP_POOL_MB"); cap = (size_t)(e ? atol(e) : 16384) << 20; cap_read = true; }
+    if (!cap_read) { const char *e = getenv("SCS_HIP_POOL_MB"); cap = (size_t)(e ? atol(e) : 1024) << 20; cap_read = true; }
     return cap;
   }
   void *get(size_t bytes) {
@@ -55,6 +60,8 @@ struct DevPool {
         void *p = blocks[i].second;
         blocks.erase(blocks.begin() + (long)i);
         cached -= bytes;
+        static const bool poison = [] { const char *e = getenv("SCS_HIP_POOL_POISON"); return e && e[0] == '1'; }();
+        if (poison) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
         return p;
       }
     return nullptr;

@@ -983,8 +983,11 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
 //   * every member publishes its HW_REG_XCC_ID first; a group that is NOT on one XCD (other partition modes, a
 //     different dispatcher) falls back to sc1 (write-through to memory) stores, which are coherent across XCDs
 //     (6.2 us per ping-pong) — plain stores would be 100 % stale there.
-// Launched with hipLaunchCooperativeKernel: co-residency of every spinning workgroup is the runtime's guarantee,
-// not an assumption about what else runs on the GPU; a spin budget still turns a would-be hang into an error flag.
+// Co-residency of every spinning workgroup: the grid is sized to one workgroup per CU of the device (scs_hip.hip psd_mc_members), and
+// inside a process the spinning launches of different workspaces / streams of a device are CHAINED (scs_hip.hip SpinChain: each waits
+// for the event behind the previous one), so two such grids never share the device; hipLaunchCooperativeKernel (SCS_HIP_PSD_COOP=1)
+// makes it the runtime's guarantee at ~0.1-2 ms per launch.  What is left — another PROCESS on the same GPU — is caught by the spin
+// budget: error flag, every barrier of the launch opens, the host restarts the solve with one workgroup per matrix.
 // ---------------------------------------------------------------------------
 constexpr int kPsdMcMaxG = 8;
 __device__ __forceinline__ unsigned psd_xcc_id() {
@@ -1001,7 +1004,7 @@ constexpr size_t kPsdMcLdsBytes = kPsdLdsBytes + 4 * kPsdMaxH * sizeof(int);  //
 // itself, keeps the results in registers, assembles the block in LDS, solves it and logs W_{t+1}: the 8 us pivot solve
 // disappears behind the 6 us of A tasks.  Same MFMA sequences on the same inputs: the same bits.
 __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double *scratch, int round, int G, int look_ahead, int *err,
-                                                              const int *stall, const double *tol2, PsdRefineCfg R, int post) {
+                                                              const int *stall, const double *tol2, PsdRefineCfg R, int post, long spin_budget) {
   SCS_STALL_GUARD(stall);
   const double offtol2 = psd_offtol2(tol2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1061,7 +1064,11 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
         long spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1L << 25)) { *err = 1; break; }  // seconds: a member never arrived
+          // a member never arrived (spin_budget: seconds by default): raise the error flag — the host restarts the solve with one
+          // workgroup per matrix (scs_hip.hip spin_fallback) — and stop waiting, here and at every later barrier of every group of
+          // this launch: what is computed from now on is thrown away, it only has to end soon
+          if (++spins > spin_budget) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
       }
       __syncthreads();

@@ -603,6 +603,27 @@ using namespace scship;
 static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, const double *diffs, double aa_norm,
                           double time_s);
 
+// A spinning multi-workgroup kernel (k_psd_sweep_mc, k_cg_persist) gave up at a barrier: scs_solve restarts the solve without them
+struct SpinTimeout : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+static std::atomic<long> g_spin_fallbacks{0};  // scs_hip_spin_fallbacks(): tests
+// Spinning kernels need ALL their workgroups on the device at once.  One workspace alone sizes its grid for that; two workspaces of a
+// device that launch such grids on different streams at the same time (threads with their own SCS objects: R:test/test_thread_safety.py:78-93)
+// could each get half of theirs placed and wait for the other half for good.  So inside a process the spinning launches of a device
+// form a chain: once more than one workspace of the device uses them, each launch waits for the event recorded behind the previous one
+// (hipStreamWaitEvent: nothing on the host waits) and leaves its own.  A lone user pays nothing.
+struct SpinChain {
+  std::mutex mu;
+  int users = 0;
+  hipEvent_t last = nullptr;
+  hipStream_t last_stream = nullptr;
+};
+static SpinChain &spin_chain(int device) {
+  static SpinChain c[64];
+  return c[device & 63];
+}
+
 // ============================================================== workspace
 struct ScsHipWork {
   // first member = destroyed last: ends the window in which this workspace's device blocks go to the block pool (common.hpp DevPool)
@@ -762,6 +783,8 @@ struct ScsHipWork {
         int mc = in_capture ? 1 : psd_mc_members(big);
         PsdRefineCfg R = psd_refine;
         if ((size_t)32 * psd_max_np * sizeof(double) > 160 * 1024) R.on = 0;  // k_psd_apply_q keeps two 16-row strips in LDS
+        std::unique_ptr<SpinLink> link;
+        if (mc > 1) link.reset(new SpinLink(this));  // spinning launches of this device, one grid at a time (SpinChain)
         for (int round = 0; round < kPsdSplitRounds; ++round) {
           const int post = (R.on && round == kPsdSplitRounds - 1) ? 1 : 0;
           if (post) {
@@ -783,7 +806,8 @@ struct ScsHipWork {
             const double *tl = psd_tol2;
             PsdRefineCfg Rr = R;
             int pst = post;
-            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl, &Rr, &pst};
+            long budget = spin_budget;
+            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl, &Rr, &pst, &budget};
             if (psd_mc_coop) {
               const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
                                                              dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream);
@@ -795,7 +819,7 @@ struct ScsHipWork {
               }
             } else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
               hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
-                                 la, err, st, tl, Rr, pst);
+                                 la, err, st, tl, Rr, pst, budget);
           }
           if (mc <= 1)
           hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall, psd_tol2,
@@ -803,6 +827,7 @@ struct ScsHipWork {
           hipLaunchKernelGGL(k_psd_apply_v, gt, dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
                              stream, B, psd_scratch.p, stall);
         }
+        link.reset();
         hipLaunchKernelGGL(k_psd_fmap, gt, dim3(256), 0, stream, B, psd_scratch.p, stall);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
         hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
@@ -847,6 +872,50 @@ struct ScsHipWork {
   // whose members are late spins within its budget (F_PERSIST_ERR otherwise: an error, not a hang).  SCS_HIP_PSD_COOP=1: cooperative launch.
   bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return e && e[0] == '1'; }();
   int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
+  long spin_budget = [] { const char *e = getenv("SCS_HIP_SPIN_BUDGET_LOG2"); const int v = e ? atoi(e) : 25; return 1L << std::max(0, std::min(v, 40)); }();  // barrier polls before a member gives up (tests: 0)
+  bool spin_user = false;
+  hipEvent_t ev_spin = nullptr;
+  void spin_register() {  // before this workspace's first spinning launch
+    if (spin_user) return;
+    SpinChain &c = spin_chain(device);
+    bool others;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      others = ++c.users >= 2;
+    }
+    spin_user = true;
+    HIP_CHECK(hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming));
+    if (others) HIP_CHECK(hipDeviceSynchronize());  // what the others launched before they had to leave events is done now
+  }
+  void spin_unregister() {
+    if (!spin_user) return;
+    SpinChain &c = spin_chain(device);
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      --c.users;
+      if (c.last == ev_spin) c.last = nullptr;
+    }
+    if (ev_spin) (void)hipEventDestroy(ev_spin);
+    ev_spin = nullptr;
+    spin_user = false;
+  }
+  // around the spinning launches of one call (held while they are enqueued: the chain is a total order)
+  struct SpinLink {
+    ScsHipWork *w;
+    SpinChain &c;
+    std::unique_lock<std::mutex> lk;
+    explicit SpinLink(ScsHipWork *w_) : w(w_), c(spin_chain(w_->device)) {
+      w->spin_register();
+      lk = std::unique_lock<std::mutex>(c.mu);
+      if (c.users >= 2 && c.last && c.last_stream != w->stream) HIP_CHECK(hipStreamWaitEvent(w->stream, c.last, 0));
+    }
+    ~SpinLink() {
+      if (c.users >= 2 && hipEventRecord(w->ev_spin, w->stream) == hipSuccess) {
+        c.last = w->ev_spin;
+        c.last_stream = w->stream;
+      }
+    }
+  };
   int psd_mc_members(int big) {
     if (psd_mc_cap < 0) {
       int coop = 0, per_cu = 0, cus = 0;
@@ -952,6 +1021,7 @@ struct ScsHipWork {
       pool_window_end.armed = true;
       ++t_pool_release;
     }
+    spin_unregister();
     for (auto &g : g_pre) if (g) (void)hipGraphExecDestroy(g);
     for (auto &g : g_cg) if (g) (void)hipGraphExecDestroy(g);
     if (g_post) (void)hipGraphExecDestroy(g_post);
@@ -1083,7 +1153,7 @@ struct ScsHipWork {
   }
 
   void process_pending_flags() {
-    if (h_flags[F_PERSIST_ERR]) throw std::runtime_error("a spinning multi-workgroup kernel (persistent CG / PSD sweeps) timed out at its barrier");
+    if (h_flags[F_PERSIST_ERR]) throw SpinTimeout("a spinning multi-workgroup kernel (persistent CG / PSD sweeps) timed out at its barrier");
     if (aa.pending_safeguard) {
       const bool bad = h_flags[F_SAFE_BAD] != 0;
       aa.safeguard_verdict(bad);
@@ -1272,6 +1342,8 @@ struct ScsHipWork {
   }
   // small-problem variant: same normalisation / warm start, then ONE launch for tolerance, CG start and CG loop
   void enqueue_lin_sys_persist() {
+    std::unique_ptr<SpinLink> link;
+    if (!in_capture) link.reset(new SpinLink(this));  // (a captured launch is replayed outside any chain: SCS_HIP_PERSIST is a lab switch)
     const int nbl = vb(l);
     hipLaunchKernelGGL(k_prep, dim3(nbl), dim3(kVecThreads), 0, stream, v.p, v_prev.p, ut.p, ws.p, u.p, g.p, diag_r.p, n, m,
                        d_params, part_v.p, nbl, sc.p, part2.p, stall);
@@ -1293,7 +1365,7 @@ struct ScsHipWork {
   }
   void finish_lin_sys_persist() {
     sync_flags();
-    if (h_flags[F_PERSIST_ERR]) throw std::runtime_error("persistent CG kernel: grid barrier timed out");
+    if (h_flags[F_PERSIST_ERR]) throw SpinTimeout("persistent CG kernel: grid barrier timed out");
     last_cg_iters = h_flags[F_ITERS];
     note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
@@ -1671,6 +1743,30 @@ struct ScsHipWork {
       return true;
     }
     return false;
+  }
+  // A spinning kernel timed out (another process holds part of the GPU): put the workspace back where scs_solve found it, as far as
+  // that is possible — the scale and what hangs on it, the device scalars and flags, cold cone workspaces (the eigenvectors of
+  // earlier solves are gone: a first solve restarts bit for bit, a later one from a cold projection) — and never spin again.
+  void spin_fallback(double scale_entry) {
+    (void)hipStreamSynchronize(stream);
+    (void)hipGetLastError();
+    psd_mc_cap = 0;
+    if (persist_wgs > 0) { persist_wgs = 0; graphs_ready = false; }
+    stall = nullptr;
+    stall_fl = nullptr;
+    in_capture = false;
+    HIP_CHECK(hipMemsetAsync(fl.p, 0, sizeof(int) * F_COUNT, stream));
+    std::memset(h_flags, 0, sizeof(int) * F_COUNT);
+    for (auto &hf : h_flags_slot) if (hf) std::memset(hf, 0, sizeof(int) * F_COUNT);
+    HIP_CHECK(hipMemsetAsync(sc.p, 0, sizeof(double) * S_COUNT, stream));
+    const double one = 1.0;
+    HIP_CHECK(hipMemcpyAsync(sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, stream));
+    if (psd_scratch.p) HIP_CHECK(hipMemsetAsync(psd_scratch.p, 0, sizeof(double) * psd_scratch.n, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    scale = scale_entry;
+    set_diag_r();
+    update_work_cache();
+    HIP_CHECK(hipStreamSynchronize(stream));
   }
   void update_scale(int iter) {
     if (!decide_scale_update(iter)) return;
@@ -2597,7 +2693,19 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
   if (!w || !sol || !info) return SCS_FAILED;
   try {
     set_last_error("");
-    return solve_impl(w, sol, info, warm_start);
+    const double scale_entry = w->scale;
+    try {
+      return solve_impl(w, sol, info, warm_start);
+    } catch (const SpinTimeout &) {
+      // not a failure of the problem: restart without the spinning kernels (the caller's sol is untouched until a solve finishes)
+      ++g_spin_fallbacks;
+      {
+        std::lock_guard<std::mutex> lock(w->mtx);
+        HIP_CHECK(hipSetDevice(w->device));
+        w->spin_fallback(scale_entry);
+      }
+      return solve_impl(w, sol, info, warm_start);
+    }
   } catch (const std::exception &e) {
     set_last_error(e.what());
     info->status_val = SCS_FAILED;
@@ -2894,6 +3002,10 @@ void scs_hip_get_mark(const ScsWork *w, double *out) {
  * times (warm-started eigenvectors, as inside the ADMM loop); the copies are timed separately and subtracted.
  * out[4] = {ms per projection, number of matrices, largest order, flops of a LAPACK-style eigensolve of them all
  * (16/3 n^3 + 2 n^3 per matrix)}.  Returns 0 on success, 1 when the problem has no PSD cone. */
+long scs_hip_spin_fallbacks(void) { return g_spin_fallbacks.load(); }
+
+void scs_hip_trim_pool(void) { DevPool::inst().trim(); }
+
 int scs_hip_psd_refine_stats(ScsWork *w, double *out, int cap) {
   if (!w || !out || cap < 0) return -1;
   try {

@@ -188,6 +188,10 @@ def _load():
     lib.scs_hip_get_mark.argtypes = [C.c_void_p, _PD]
     lib.scs_hip_time_psd.restype = c_int
     lib.scs_hip_time_psd.argtypes = [C.c_void_p, c_int, _PD]
+    lib.scs_hip_trim_pool.restype = None
+    lib.scs_hip_trim_pool.argtypes = []
+    lib.scs_hip_spin_fallbacks.restype = C.c_long
+    lib.scs_hip_spin_fallbacks.argtypes = []
     lib.scs_hip_psd_refine_stats.restype = c_int
     lib.scs_hip_psd_refine_stats.argtypes = [C.c_void_p, _PD, c_int]
     lib.scs_hip_time_matvec.restype = c_int
@@ -424,9 +428,10 @@ def _info_dict(info):
 class SCS(object):
     """Raw backend type; `scs.SCS` (scs/__init__.py) is the user-facing wrapper."""
 
-    # linear-system solver this backend type builds (include/scs_hip.h scs_hip_init_linsys): 0 = the library's default
-    # (sparse indirect unless SCS_HIP_LINSYS=dense); scs._scs_hip_dense.SCS sets 2 (dense direct)
-    _LINSYS = 0
+    # linear-system solver this backend type builds (include/scs_hip.h scs_hip_init_linsys): the MODULE decides, as in the reference
+    # (R:scs/py/__init__.py:40-66) — 1 = sparse indirect (PCG) here, scs._scs_hip_dense.SCS sets 2 (dense direct).  Only the bare
+    # C entry scs_init consults SCS_HIP_LINSYS (ADVICE r04: LinearSolver.HIP_INDIRECT must not turn dense behind the caller's back).
+    _LINSYS = 1
 
     def __init__(self, shape, Ax, Ai, Ap, Px, Pi, Pp, b, c, cone, **settings):
         if getattr(self, "_work", None):
@@ -777,6 +782,16 @@ def proj_cone(z, cone, dual=False):
     k, keep = _cone_struct(cone)
     _check(_lib.scs_hip_proj_cone(_pd(x), C.byref(k), x.size, 1 if dual else 0))
     return x
+
+
+def trim_pool():
+    """return the library's cached device blocks to the driver (include/scs_hip.h scs_hip_trim_pool)"""
+    _lib.scs_hip_trim_pool()
+
+
+def spin_fallbacks():
+    """solves of this process restarted without spinning multi-workgroup kernels after a barrier timed out (include/scs_hip.h)"""
+    return int(_lib.scs_hip_spin_fallbacks())
 
 
 def proj_cone_seq(zs, cone, dual=False, stats_cap=0):

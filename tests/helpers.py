@@ -126,3 +126,80 @@ def proj_dual_l_s_numpy(z, K):
         out[o:o + d] = sym_to_svec((U * np.maximum(w, 0.0)) @ U.T)
         o += d
     return out
+
+
+def cone_violation(v, K, dual=False):
+    """Largest violation of the defining INEQUALITIES of K (dual=False) or K* (dual=True) by v, per cone family, in numpy — no
+    projection of any implementation involved (R:test/test_solve_random_cone_prob.py:55-65 checks membership through the
+    reference's Python projections; here the cones' definitions themselves: exp s e^{r/s} <= t
+    (R:test/test_scs_coverage.py:916,926-929), power x^a y^(1-a) >= |z| with a < 0 meaning the dual cone (:988,1027), box
+    bl t <= s <= bu t (:553-560), SOC |v| <= t (R:test/gen_random_cone_prob.py:140-149)).  Cone order z, l, box, q, s, ep, ed, p.
+    Returns {family: max violation} (0 = inside); every entry is an absolute amount in the units of v."""
+    v = np.asarray(v, dtype=np.float64)
+    out = {}
+    o = 0
+    z = int(K.get("z", 0))
+    if z:
+        out["z"] = 0.0 if dual else float(np.abs(v[o:o + z]).max())  # K = {0}, K* = everything
+        o += z
+    l = int(K.get("l", 0))
+    if l:
+        out["l"] = float(max(0.0, -v[o:o + l].min()))
+        o += l
+    bu, bl = np.asarray(K.get("bu", []), dtype=np.float64), np.asarray(K.get("bl", []), dtype=np.float64)
+    if bu.size:
+        t, sb = v[o], v[o + 1:o + 1 + bu.size]
+        if not dual:
+            out["box"] = float(max(0.0, -t, (sb - bu * t).max(), (bl * t - sb).max()))
+        else:  # K* = {(tau, y): tau + sum_i min(bl_i y_i, bu_i y_i) >= 0}  (the minimum of y's over the box at t = 1)
+            out["box"] = float(max(0.0, -(t + np.minimum(bl * sb, bu * sb).sum())))
+        o += 1 + bu.size
+    viol = 0.0
+    for q in K.get("q", []):
+        if q:
+            viol = max(viol, float(np.linalg.norm(v[o + 1:o + q]) - v[o]))
+        o += q
+    if K.get("q"):
+        out["q"] = max(0.0, viol)
+    viol = 0.0
+    for k in K.get("s", []):
+        d = k * (k + 1) // 2
+        if k:
+            viol = max(viol, float(-np.linalg.eigvalsh(svec_to_sym(v[o:o + d], k)).min()))
+        o += d
+    if K.get("s"):
+        out["s"] = max(0.0, viol)
+
+    def exp_primal(T):  # rows (r, s, t): s e^{r/s} <= t, s > 0; closure: s = 0, r <= 0, t >= 0
+        r, s_, t = T[:, 0], T[:, 1], T[:, 2]
+        with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+            inner = np.where(s_ > 0, s_ * np.exp(np.minimum(r / np.where(s_ > 0, s_, 1.0), 700.0)) - t, np.maximum(np.maximum(r, 0.0), -t))
+        return float(max(0.0, inner.max(), (-s_).max())) if T.size else 0.0
+
+    def exp_dual(T):  # rows (u, v, w): -u e^{v/u} <= e w, u < 0; closure: u = 0, v >= 0, w >= 0
+        u, vv, w = T[:, 0], T[:, 1], T[:, 2]
+        with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+            inner = np.where(u < 0, -u * np.exp(np.minimum(vv / np.where(u < 0, u, -1.0), 700.0)) - np.e * w, np.maximum(np.maximum(-vv, 0.0), -w))
+        return float(max(0.0, inner.max(), u.max())) if T.size else 0.0
+
+    ep, ed = int(K.get("ep", 0)), int(K.get("ed", 0))
+    if ep:
+        T = v[o:o + 3 * ep].reshape(-1, 3)
+        out["ep"] = exp_dual(T) if dual else exp_primal(T)
+        o += 3 * ep
+    if ed:
+        T = v[o:o + 3 * ed].reshape(-1, 3)
+        out["ed"] = exp_primal(T) if dual else exp_dual(T)
+        o += 3 * ed
+    pw = np.asarray(K.get("p", []), dtype=np.float64)
+    if pw.size:
+        T = v[o:o + 3 * pw.size].reshape(-1, 3)
+        x, y, zz = T[:, 0], T[:, 1], T[:, 2]
+        a = np.abs(pw)
+        primal = (pw > 0) != dual  # a < 0: the block is the dual power cone with exponent |a|
+        xs, ys = np.maximum(x, 0.0), np.maximum(y, 0.0)
+        lhs = np.where(primal, xs ** a * ys ** (1 - a), (xs / a) ** a * (ys / (1 - a)) ** (1 - a))
+        out["p"] = float(max(0.0, (np.abs(zz) - lhs).max(), (-x).max(), (-y).max()))
+        o += 3 * pw.size
+    assert o == v.size, (o, v.size)
+    return out

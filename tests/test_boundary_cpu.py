@@ -244,3 +244,11 @@ def test_no_cpu_fallback_exists():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "scs_oracle" not in src and "liboscs" not in src and "oracle/" not in src.replace("the oracle", ""), f
+
+
+def test_backend_modules_bind_their_linear_solver():
+    """The module decides the linear solver, as in the reference (R:scs/py/__init__.py:40-66): scs._scs_hip binds the sparse indirect
+    solver (1) whatever SCS_HIP_LINSYS says — only the bare C scs_init consults the environment — and scs._scs_hip_dense binds 2."""
+    from scs import _scs_hip, _scs_hip_dense
+    assert _scs_hip.SCS._LINSYS == 1
+    assert _scs_hip_dense.SCS._LINSYS == 2

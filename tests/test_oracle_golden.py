@@ -267,3 +267,22 @@ def test_cs_solves_reference_cases(cone, seed):
         for vec in (sol["s"], sol["y"]):
             assert np.linalg.eigvalsh(helpers.cvec_to_herm(vec[o:o + k * k], k)).min() > -1e-6
         o += k * k
+
+
+def test_numpy_cone_membership_agrees_with_the_oracle_projections():
+    """helpers.cone_violation (the defining inequalities of every cone family and of its dual, used by the full-size GPU tests as
+    the judge of membership) against the oracle: what the oracle projects onto K / K* is inside to 1e-8, a random point is not."""
+    import helpers
+    import problem_gen as pg
+    rng = np.random.RandomState(1)
+    K = {"z": 3, "l": 5, "bu": [1.0, 2.0, 0.5], "bl": [-1.0, 0.0, -3.0], "q": [4, 3], "s": [3, 2], "ep": 6, "ed": 5,
+         "p": [0.3, -0.6, 0.5, -0.25]}
+    m = pg.cone_dims(K)
+    for dual in (False, True):
+        for _ in range(10):
+            z = 3.0 * rng.randn(m)
+            viol = helpers.cone_violation(oracle.proj_cone(z, K, dual=dual), K, dual=dual)
+            assert set(viol) == {"z", "l", "box", "q", "s", "ep", "ed", "p"}
+            assert max(viol.values()) <= 1e-8, (dual, viol)
+            outside = helpers.cone_violation(z, K, dual=dual)
+            assert sum(x > 1e-3 for x in outside.values()) >= 5, outside

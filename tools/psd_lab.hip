@@ -62,33 +62,49 @@ int main(int argc, char **argv) {
       else
         hipLaunchKernelGGL(k_proj_psd_small4, dim3(cnt), dim3(kPsdSmallThreads), 0, 0, d_x, B, d_scr, 1, (const int *)nullptr, (const double *)nullptr);
     }
-    else if (split) {
+    else if (split) {  // the launch sequence of scs_hip.hip launch_psd (round 5: 1-D XCD-aware grids, refinement stage; PSD_LAB_REFINE0: strict sweeps)
       const int ntile = (int)np / 16;
-      const dim3 gg(psd_gemm_wgs(ntile), (unsigned)cnt), gb(kPsdGemmThreads);
-      hipLaunchKernelGGL(k_psd_front, dim3(ntile, cnt), dim3(kPsdFrontThreads), 0, 0, (const double *)d_x, B, d_scr, 1, (const int *)nullptr);
-      hipLaunchKernelGGL(k_proj_psd<3>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr);
-      hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
-      hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
+      const int gper = psd_gemm_tasks(ntile);
+      const dim3 gg(psd_gemm_grid(gper, cnt)), gb(kPsdGemmThreads), gt(psd_xcd_grid(ntile, cnt));
+      const PsdRefineCfg R = psd_refine_default(!getenv("PSD_LAB_REFINE0"));
+      hipLaunchKernelGGL(k_psd_front, gt, dim3(kPsdFrontThreads), 0, 0, (const double *)d_x, B, d_scr, 1, (const int *)nullptr);
+      hipLaunchKernelGGL(k_proj_psd<3>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr,
+                         psd_refine_default(false), 0);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
       for (int round = 0; round < 3; ++round) {
+        int post = (R.on && round == 2) ? 1 : 0;
+        if (post) {
+          hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+          hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+          hipLaunchKernelGGL(k_psd_gemm<PSD_T>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+          hipLaunchKernelGGL(k_psd_gemm<PSD_S1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+          hipLaunchKernelGGL(k_psd_apply_q, gt, dim3(kPsdApplyThreads), (size_t)32 * np * 8, 0, B, d_scr, nullptr);
+        }
         if (mc >= 2) {
           int G = mc, rnd = round;
           const int *st = nullptr;
           int la = getenv("PSD_LAB_LA0") ? 0 : 1;  // look-ahead (one barrier per step)
           const double *tl = nullptr;
-          void *args[] = {&B, &d_scr, &rnd, &G, &la, &d_err, &st, &tl};
+          PsdRefineCfg Rr = R;
+          long budget = 1L << 25;
+          void *args[] = {&B, &d_scr, &rnd, &G, &la, &d_err, &st, &tl, &Rr, &post, &budget};
           if (getenv("PSD_LAB_PLAIN"))  // ordinary launch (e.g. under rocprofv3)
-            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdMcLdsBytes, 0, B, d_scr, rnd, G, la, d_err, st, tl);
+            hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads), kPsdMcLdsBytes, 0, B, d_scr, rnd, G, la, d_err, st, tl, Rr,
+                               post, budget);
           else
           HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(cnt, G)), dim3(kPsdThreads),
                                                args, (unsigned)kPsdMcLdsBytes, 0));
         } else
-        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, (const int *)nullptr, (const double *)nullptr);
-        hipLaunchKernelGGL(k_psd_apply_v, dim3((int)np / 16, cnt), dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
+        hipLaunchKernelGGL(k_proj_psd<1>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, round, (const int *)nullptr, (const double *)nullptr,
+                           R, post);
+        hipLaunchKernelGGL(k_psd_apply_v, gt, dim3(kPsdApplyThreads), (size_t)16 * np * 8, 0, B, d_scr, nullptr);
       }
-      hipLaunchKernelGGL(k_psd_fmap, dim3(ntile, cnt), dim3(256), 0, 0, B, d_scr, (const int *)nullptr);
-      hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
-      hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr);
-    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr);
+      hipLaunchKernelGGL(k_psd_fmap, gt, dim3(256), 0, 0, B, d_scr, (const int *)nullptr);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+      hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
+    } else hipLaunchKernelGGL(k_proj_psd<0>, dim3(cnt), dim3(kPsdThreads), kPsdLdsBytes, 0, d_x, B, d_scr, 1, 0, (const int *)nullptr, (const double *)nullptr,
+                              psd_refine_default(false), 0);
     HIP_CHECK(hipEventRecord(e1)); HIP_CHECK(hipEventSynchronize(e1));
     float ms; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     double st[8];

@@ -269,7 +269,7 @@ struct DeviceCsr {
   // parts + combine) => off by default.
   static bool cs_combine_enabled() {
     const char *e = getenv("SCS_HIP_CS_COMBINE");
-    return e && e[0] == '1' && cs_schedule() == 2;
+    return e && e[0] == '1' && cs_schedule() >= 2;  // (round 5: the round-4 schedule too — k_spmv_cs_il<.., 6> carries the same combine code)
   }
   int cs_pick_split(int kind) const {
     if (!cs_split_enabled() || getenv("SCS_HIP_CS_RPT")) return 1;

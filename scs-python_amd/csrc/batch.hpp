@@ -671,7 +671,10 @@ struct GroupSolve {
         for (int g : pend) { W[(size_t)g]->setup_pending = false; W[(size_t)g]->setup_time += each; }
       }
     }
-    for (int g = 0; g < G; ++g) W[(size_t)g]->begin_solve(sols[(size_t)g], infos[(size_t)g], warm_start);
+    for (int g = 0; g < G; ++g) {
+      W[(size_t)g]->mr_allowed = false;  // the grouped loop drives PCG steps through its own tables (minres.hpp: one workspace at a time)
+      W[(size_t)g]->begin_solve(sols[(size_t)g], infos[(size_t)g], warm_start);
+    }
     for (int g = 0; g < G; ++g) {
       if (dense)
         std::snprintf(infos[(size_t)g]->lin_sys_solver, sizeof(infos[(size_t)g]->lin_sys_solver),

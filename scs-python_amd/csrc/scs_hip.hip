@@ -29,6 +29,7 @@
 #include "normalize_dev.hpp"
 #include "psd.hpp"
 #include "cg_persist.hpp"
+#include "minres.hpp"
 #include "dense.hpp"
 #include "setup_dev.hpp"
 #include "setup_cs_dev.hpp"
@@ -1103,6 +1104,7 @@ struct ScsHipWork {
     if (dense()) { dense_refactor(); return; }
     hipLaunchKernelGGL(k_precond, dim3(vb(n)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, At.val.p, diag_r.p,
                        has_P ? Pdiag.p : (const double *)nullptr, cg_M.p, n);
+    if (mr_ready) mr_precond();
   }
 
   // R_x / R_y as the SpMV epilogues take them: two scalars inside the ADMM workspace (set_diag_r built diag_r), the
@@ -1216,6 +1218,99 @@ struct ScsHipWork {
     process_pending_flags();
   }
 
+  // ---- MINRES on the system with the zero-cone block un-eliminated (minres.hpp): the ADMM iteration's linear solve when the cone has
+  // zero rows and PCG needs many steps (BASELINE config 3: ~330).  SCS_HIP_KRYLOV = cg | minres | auto (default): auto switches a
+  // workspace over, for good, once the third quartile of its last 8 PCG solves exceeds kMrAutoSteps steps and z >= kMrAutoZ.
+  // Cold KKT solves (init, scale updates) stay with PCG.
+  static constexpr int kMrAutoSteps = 96, kMrAutoZ = 256;
+  int krylov = [] { const char *e = getenv("SCS_HIP_KRYLOV"); return !e ? 2 : e[0] == 'c' ? 0 : e[0] == 'm' ? 1 : 2; }();  // 0 cg, 1 minres (whenever z > 0), 2 auto; read when the workspace is made
+  int krylov_mode() const { return krylov; }
+  bool mr_active = false, mr_ready = false, mr_allowed = true;
+  double mr_tolf = [] { const char *e = getenv("SCS_HIP_MR_TOLF"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1.0; }();  // (lab) MINRES stops at mr_tolf x the PCG tolerance
+  long mr_N = 0;
+  int mr_nred = 1;
+  DevBuf<double> mr_B, mr_YP, mr_W, mr_d, mr_rho, mr_Minv, mr_Y, mr_sc, mr_partA, mr_partB, mr_partV, mr_partR, mr_zval;
+  DevBuf<int> mr_zptr, mr_zidx;
+  void mr_precond() {
+    hipLaunchKernelGGL(k_mr_precond_x, dim3(ceil_div(n, kVecThreads)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, At.val.p, rdx(), rdy(),
+                       has_P ? Pdiag.p : (const double *)nullptr, n, cone.z, mr_Minv.p);
+    hipLaunchKernelGGL(k_mr_precond_z, dim3(ceil_div(cone.z, kVecThreads)), dim3(kVecThreads), 0, stream, Ar.rowptr.p, Ar.col.p, Ar.val.p, rdy(), n,
+                       cone.z, mr_Minv.p);
+  }
+  void mr_setup() {  // once per workspace, at the switch (a host round trip for the prefix sums of A_z')
+    if (mr_ready) return;
+    const long N = (long)n + cone.z;
+    mr_N = N;
+    mr_B.alloc_zero((size_t)(3 * N), stream);
+    mr_YP.alloc_zero((size_t)(2 * N), stream);
+    mr_W.alloc_zero((size_t)(3 * N), stream);
+    mr_d.alloc_zero((size_t)N, stream);
+    mr_rho.alloc_zero((size_t)N, stream);
+    mr_Minv.alloc_zero((size_t)N, stream);
+    mr_Y.alloc_zero((size_t)N, stream);
+    mr_sc.alloc_zero(kMrScalars, stream);
+    mr_partA.alloc_zero(part_len, stream);
+    mr_partB.alloc_zero(part_len, stream);
+    mr_partV.alloc_zero(kMaxVecBlocks, stream);
+    mr_partR.alloc_zero(kMaxVecBlocks, stream);
+    mr_nred = std::max(1, std::min(kMaxVecBlocks, ceil_div(n, kVecThreads)));
+    DevBuf<int> cnt;
+    cnt.alloc((size_t)n);
+    hipLaunchKernelGGL(k_mr_azt_count, dim3(ceil_div(n, kVecThreads)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, n, cone.z, cnt.p);
+    std::vector<int> hc((size_t)n), hp((size_t)n + 1, 0);
+    cnt.download(hc.data(), (size_t)n, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int j = 0; j < n; ++j) hp[(size_t)j + 1] = hp[(size_t)j] + hc[(size_t)j];
+    mr_zptr.upload(hp.data(), hp.size(), stream);
+    mr_zidx.alloc((size_t)std::max(hp[(size_t)n], 1));
+    mr_zval.alloc((size_t)std::max(hp[(size_t)n], 1));
+    hipLaunchKernelGGL(k_mr_azt_fill, dim3(ceil_div(n, kVecThreads)), dim3(kVecThreads), 0, stream, At.rowptr.p, At.col.p, At.val.p, n, mr_zptr.p,
+                       mr_zidx.p, mr_zval.p);
+    mr_precond();
+    HIP_CHECK(hipStreamSynchronize(stream));  // hp, hc are locals
+    mr_ready = true;
+  }
+  // decided where an ADMM iteration's linear solve is enqueued (never inside one)
+  void mr_decide() {
+    if (mr_active || !mr_allowed || cone.z <= 0 || dense() || persist_wgs > 0 || k1dot || in_capture) return;
+    const int mode = krylov_mode();
+    if (mode == 0) return;
+    if (mode == 2 && !(cone.z >= kMrAutoZ && recent_cg_q3() > kMrAutoSteps)) return;
+    mr_setup();
+    mr_active = true;
+    graphs_ready = false;  // (captured CG chunks are of no use any more; graphs are not rebuilt for MINRES)
+  }
+  void enqueue_mr_start() {  // behind enqueue_lin_sys_head: cg_r holds r0, the flags and the tolerance are set
+    const long N = mr_N;
+    hipLaunchKernelGGL(k_mr_init, dim3(vb(N)), dim3(kVecThreads), 0, stream, (const double *)cg_r.p, (const double *)mr_Minv.p, n, N, mr_B.p, mr_B.p + N,
+                       mr_YP.p, mr_W.p, mr_W.p + N, mr_d.p, mr_rho.p, mr_partV.p, stall);
+    hipLaunchKernelGGL(k_mr_fin0, dim3(1), dim3(kVecThreads), 0, stream, (const double *)mr_partV.p, vb(N), mr_sc.p, stall);
+  }
+  void enqueue_mr_step(int k) {
+    const long N = mr_N;
+    const int bank = k & 1;
+    double *r1 = mr_B.p + (k % 3) * N, *r2 = mr_B.p + ((k + 1) % 3) * N, *r3 = mr_B.p + ((k + 2) % 3) * N;
+    double *yp = mr_YP.p + (k & 1) * N, *ypn = mr_YP.p + ((k + 1) & 1) * N;
+    double *w1 = mr_W.p + (k % 3) * N, *w2 = mr_W.p + ((k + 1) % 3) * N, *wn = mr_W.p + ((k + 2) % 3) * N;
+    const double *bk = mr_sc.p + kMrBank0 + kMrBankLen * bank;
+    const int *done = fl.p + F_DONE;
+    launch_spmv(Ar.view(), yp, EpiMrU{tmp_m.p, mr_Y.p, yp, r1, bk, rdy(), n, cone.z, mr_partA.p}, done, stream);
+    if (has_P) launch_spmv(Pf.view(), yp, EpiStore{mr_Y.p, 0}, done, stream);
+    launch_spmv(At.view(), tmp_m.p, EpiMrY{mr_Y.p, gp2(), yp, r1, bk, rdx(), has_P ? 1 : 0, mr_partB.p}, done, stream);
+    hipLaunchKernelGGL(k_mr_v1, dim3(vb(N)), dim3(kVecThreads), 0, stream, (const double *)mr_Y.p, (const double *)gp2(), (const double *)r2,
+                       (const double *)mr_Minv.p, n, N, r3, ypn, (const double *)mr_partA.p, Ar.nwg(), (const double *)mr_partB.p, At.nwg(), mr_sc.p, bank,
+                       mr_partV.p, (const int *)fl.p);
+    hipLaunchKernelGGL(k_mr_v2, dim3(vb(N)), dim3(kVecThreads), 0, stream, (const double *)yp, (const double *)w1, (const double *)w2, wn, mr_d.p, mr_rho.p,
+                       (const double *)r3, N, (const double *)mr_partV.p, vb(N), mr_sc.p, bank, (const int *)fl.p);
+    hipLaunchKernelGGL(k_mr_red, dim3(mr_nred), dim3(kVecThreads), 0, stream, (const int *)mr_zptr.p, (const int *)mr_zidx.p, (const double *)mr_zval.p,
+                       (const double *)mr_rho.p, n, rdy(), mr_partR.p, (const int *)fl.p);
+    hipLaunchKernelGGL(k_mr_fin, dim3(1), dim3(kVecThreads), 0, stream, (const double *)mr_partR.p, mr_nred, sc.p, fl.p, mr_tolf);
+  }
+  void enqueue_mr_finish() {  // x = ws + d_x, y = v_y + R_y^{-1} A x.  Idempotent: after a run-ahead stall it simply runs again
+    hipLaunchKernelGGL(k_mr_x, dim3(vb(n)), dim3(kVecThreads), 0, stream, ut.p, (const double *)ws.p, (const double *)mr_d.p, n, (const int *)fl.p, stall);
+    launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, rdy(), v.p + n}, stall, stream);
+  }
+
   // PCG on cg_b (rhs, length n); solution accumulates in xout.  S_TOL / F_DONE must be set on device.
   // Returns CG iterations taken.  `started` = the CG start (and `done_iters` steps) were already enqueued
   // and synced by a captured graph.
@@ -1232,10 +1327,11 @@ struct ScsHipWork {
         last_cg_iters = done_iters;
         if (xout == ut.p) note_cg_iters(done_iters);
         tot_cg_iters += done_iters;
+        if (mr_active && xout == ut.p) enqueue_mr_finish();
         return done_iters;
       }
     }
-    const bool use_graph = started && xout == ut.p && graphs_ready;  // graphs are captured for the ADMM buffers only
+    const bool use_graph = started && xout == ut.p && graphs_ready && !mr_active;  // graphs are captured for the ADMM buffers only (PCG steps)
     double *yacc = (xout == ut.p) ? ut.p + n : nullptr;  // ADMM path carries the y block along the recurrence
     int chunk = started ? std::max(2, std::min(std::max(done_iters / 2, 4), 64)) : std::max(1, std::min(last_cg_iters + 2, 64));  // a host round trip costs ~30 us, an unused CG step four ~1 us launches
     while (true) {
@@ -1248,7 +1344,8 @@ struct ScsHipWork {
       } else {
         const int sample_it = chunk / 2;  // a mid-chunk step: not the one right behind the host sync
         for (int it = 0; it < chunk; ++it) {
-          enqueue_cg_step(xout, yacc, (profile && it == sample_it) ? ev : nullptr);
+          if (mr_active && xout == ut.p) enqueue_mr_step(done_iters + it);
+          else enqueue_cg_step(xout, yacc, (profile && it == sample_it) ? ev : nullptr);
         }
         read_flags();
         if (profile && h_flags[F_ITERS] - iters_before > sample_it) {  // the sampled step really ran
@@ -1266,6 +1363,21 @@ struct ScsHipWork {
     last_cg_iters = done_iters;
     if (xout == ut.p) note_cg_iters(done_iters);  // (not the cold KKT solves of init / scale updates)
     tot_cg_iters += done_iters;
+    if (mr_active && xout == ut.p) {
+      enqueue_mr_finish();
+      static const bool check = getenv("SCS_HIP_MR_CHECK") != nullptr;  // lab: the TRUE reduced residual of the x MINRES returned
+      if (check && !has_P) {
+        launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, rdx(), v.p, ut.p, nullptr, part.p}, nullptr, stream);
+        std::vector<double> hr((size_t)n);
+        double hs[S_COUNT];
+        cg_r.download(hr.data(), (size_t)n, stream);
+        sc.download(hs, S_COUNT, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        double mx = 0;
+        for (double x : hr) mx = std::max(mx, std::fabs(x));
+        std::fprintf(stderr, "[scs-hip] MINRES %d steps: recursion |r_red|_inf %.3e, true %.3e, tol %.3e\n", done_iters, hs[S_RNORM], mx, hs[S_TOL]);
+      }
+    }
     return done_iters;
   }
 
@@ -1323,6 +1435,7 @@ struct ScsHipWork {
                        ut.p, (long)n + m, stall);
     // (k1dot: the first step's alpha needs sum r_x p0^2 of the p0 = M r0 the start has just formed)
     if (k1dot) hipLaunchKernelGGL(k_pp_part, dim3(vb(n)), dim3(kVecThreads), 0, stream, (const double *)cg_p.p, rdx(), n, part_pp.p, stall);
+    if (mr_active) enqueue_mr_start();
   }
   // dense direct variant of the linear solve of an iteration: rhs = R_x v_x - A' v_y;  u~_x = G^{-1} rhs;  u~_y = v_y + R_y^{-1} A u~_x.
   // Three dependent launches behind k_prep, no convergence flag: nothing here (or behind it) waits for the device.
@@ -1405,6 +1518,7 @@ struct ScsHipWork {
     const int slot = iter & 1;
     set_iter_params(iter, slot);
     ensure_v_norm();
+    mr_decide();
     stall = fl.p + F_STALL;
     stall_fl = fl.p;
     enqueue_lin_sys_head();
@@ -1414,7 +1528,9 @@ struct ScsHipWork {
     if (pipe_chunk_override > 0) chunk = pipe_chunk_override;
     prof_step[slot] = -1;
     for (int k = 0; k < chunk; ++k) {
-      if (profile && k == chunk / 2) {  // one CG step of the queued iteration bracketed by events: nothing waits for them here
+      if (mr_active) {
+        enqueue_mr_step(k);
+      } else if (profile && k == chunk / 2) {  // one CG step of the queued iteration bracketed by events: nothing waits for them here
         for (auto &e : ev_prof[slot]) if (!e) HIP_CHECK(hipEventCreate(&e));
         enqueue_cg_step(ut.p, ut.p + n, ev_prof[slot]);
         prof_step[slot] = k;
@@ -1422,6 +1538,7 @@ struct ScsHipWork {
         enqueue_cg_step(ut.p, ut.p + n);
       }
     }
+    if (mr_active) enqueue_mr_finish();
     enqueue_lin_sys_tail();
     cone_sampled[slot] = false;
     if (profile) {  // the nonlinear cone projections of this queued iteration between two events (read when it is finished)
@@ -1564,6 +1681,7 @@ struct ScsHipWork {
     // more, when the residual-tied level is switched off (psd_tol2_for): wait before overwriting it.  (Run-ahead
     // iterations alternate between two slots instead: enqueue_plain_iteration.)
     if (n_psd + n_cs > 0 && psd_tol2_for(iter) != h_params_base[P_PSD_TOL2]) HIP_CHECK(hipStreamSynchronize(stream));
+    mr_decide();
     set_iter_params(iter);
     ensure_v_norm();
     if (dense()) {
@@ -1577,7 +1695,7 @@ struct ScsHipWork {
       finish_lin_sys_persist();
       return;
     }
-    if (graph) {
+    if (graph && !mr_active) {
       int gi = 0;
       const int want = std::max(1, std::min(last_cg_iters + 2, kGraphSteps[kNumGraphs - 1]));
       while (gi + 1 < kNumGraphs && kGraphSteps[gi] < want) ++gi;  // smallest captured chunk that covers `want`
@@ -1850,6 +1968,7 @@ struct ScsHipWork {
   // ---- the two ends of a solve, shared by scs_solve and the grouped solve (batch.hpp) ----
   // per-solve state, info header and the initial iterate (cold: v = [0; 0; 1]; warm: from sol)
   void begin_solve(ScsSolution *sol, ScsInfo *info, int warm_start) {
+    if (krylov_mode() == 1) mr_decide();  // (forced: from the first iteration, and named in the banner)
     std::memset(info, 0, sizeof(*info));
     info->setup_time = setup_time;
     if (dense())
@@ -1862,9 +1981,10 @@ struct ScsHipWork {
       // peeled off and summed from the plain CSR by the side launch
       const bool pieces = (Ar.cs.ok && Ar.cs.npieces > 0) || (At.cs.ok && At.cs.npieces > 0) || (has_P && Pf.cs.ok && Pf.cs.npieces > 0);
       const bool peeled = !pieces && ((Ar.cs.ok && Ar.npeel > 0) || (At.cs.ok && At.npeel > 0) || (has_P && Pf.cs.ok && Pf.npeel > 0));
-      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV%s, PCG)",
+      std::snprintf(info->lin_sys_solver, sizeof(info->lin_sys_solver), "sparse-indirect HIP gfx950 (%s SpMV%s, %s)",
                     At.cs.ok ? "column-sorted pass" : At.has_slab ? "L2-blocked slab" : "CSR-stream",
-                    pieces ? ", long rows in pieces" : peeled ? ", long rows peeled" : "");
+                    pieces ? ", long rows in pieces" : peeled ? ", long rows peeled" : "",
+                    mr_active ? "MINRES, zero-cone block un-eliminated" : "PCG");
     }
     // per-solve state
     sum_log_scale_factor = 0; n_log_scale_factor = 0; last_scale_update_iter = 0; scale_updates = 0;
@@ -1912,6 +2032,10 @@ struct ScsHipWork {
   // the verdict of the last convergence check (SCS_UNFINISHED: none fired).
   void finish_solve(ScsSolution *sol, ScsInfo *info, int i, double t_start, double t_lin, double t_cone, double t_acc,
                     bool grouped = false) {
+    if (mr_active && !std::strstr(info->lin_sys_solver, "MINRES")) {  // the auto mode switched inside this solve
+      char *at = std::strstr(info->lin_sys_solver, "PCG)");
+      if (at) std::snprintf(at, sizeof(info->lin_sys_solver) - (size_t)(at - info->lin_sys_solver), "PCG, then MINRES)");
+    }
     // ---- finalize ----
     const int max_iters = stgs.max_iters;
     if (!grouped) {  // (the grouped solve has read this problem's flags and residuals already)

@@ -1,0 +1,142 @@
+"""MINRES on the KKT system with the zero-cone block un-eliminated (csrc/minres.hpp) — the second Krylov method of the indirect
+linear solve (north_star "CG/MINRES over A and A'"; the reference's indirect backends: R:meson.build:261,303-304).
+
+Checked against the oracle's direct LDL' solve of the same problems (entry-wise where the solution is unique), against the PCG
+path of the same library, and for the properties the reference's tests pin: determinism
+(R:test/test_scs_coverage.py:2283-2301), warm start / update (R:test/test_scs_object.py:68-88)."""
+import numpy as np
+import pytest
+
+import helpers
+import problem_gen as pg
+
+pytestmark = pytest.mark.gpu
+
+STG = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from scs import _scs_hip
+    assert _scs_hip.device_count() > 0, "GPU tests need a HIP device (no CPU fallback exists)"
+    return _scs_hip
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import scs_oracle
+    return scs_oracle
+
+
+def _xys(got, ref, rtol=1e-4):
+    for key in ("x", "y", "s"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=rtol, atol=rtol * np.abs(ref[key]).max(), err_msg=key)
+
+
+CASES = {
+    # zero-cone heavy LP + SOC: 30 % equality rows
+    "z_lp_soc": ({"z": 120, "l": 200, "q": [12, 7, 30]}, 150, 8, False),
+    # every cone family behind a zero cone (the shape of BASELINE config 3, oracle-friendly size)
+    "z_mixed": ({"z": 60, "l": 150, "bu": [1.0, 2.0, 0.5, 4.0], "bl": [-1.0, 0.0, -3.0, -0.1], "q": [9, 5], "s": [6, 4], "ep": 7, "ed": 5,
+                 "p": [0.3, -0.6, 0.5]}, 110, 7, False),
+    # strictly convex QP (P != 0: the (1,1) block carries P), unique x, y, s
+    "z_qp": ({"z": 80, "l": 100, "q": [10, 6]}, 260, 6, True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_minres_solves_match_the_oracle_and_pcg(hip, oracle, monkeypatch, case):
+    K, n, k, qp = CASES[case]
+    proj = lambda z, K: oracle.proj_cone(z, K, dual=True)
+    if qp:
+        data, p_star, (x0, y0, s0) = pg.gen_feasible_qp(K, n, k, 31, proj)
+    else:
+        data, p_star, (x0, y0, s0) = pg.gen_feasible(K, n, k, 31, proj)
+    args = helpers.raw_args(data, K)
+    sols = {}
+    for mode in ("cg", "minres"):
+        monkeypatch.setenv("SCS_HIP_KRYLOV", mode)
+        sols[mode] = hip.SCS(*args, **STG).solve(False, None, None, None)
+        assert sols[mode]["info"]["status"] == "solved", (mode, sols[mode]["info"])
+        assert abs(sols[mode]["info"]["pobj"] - p_star) < 1e-6 * max(1.0, abs(p_star)), mode
+    assert "MINRES" in sols["minres"]["info"]["lin_sys_solver"] and "MINRES" not in sols["cg"]["info"]["lin_sys_solver"]
+    ref = oracle.OracleSCS(*args, indirect=False, **STG).solve(False)
+    assert ref["info"]["status"] == "solved"
+    if qp:  # unique: entry-wise against the oracle's direct solve and against the constructed optimum
+        _xys(sols["minres"], ref)
+        _xys(sols["minres"], {"x": x0, "y": y0, "s": s0})
+    pri, dual, gap = helpers.kkt_certificate(data, sols["minres"], P=data.get("P"))
+    assert pri < 1e-6 and dual < 1e-6 and gap < 1e-6
+    # the two Krylov methods solve the same linear systems to the same tolerance: same ADMM path up to that tolerance
+    assert abs(sols["minres"]["info"]["iter"] - sols["cg"]["info"]["iter"]) <= max(50, sols["cg"]["info"]["iter"] // 5)
+    _xys(sols["minres"], sols["cg"], rtol=1e-5 if qp else 1e-3)
+
+
+def test_minres_certificates_of_infeasible_and_unbounded_problems(hip, oracle, monkeypatch):
+    """problems with a zero cone whose iterates diverge towards a certificate: the linear solves must stay accurate relative to
+    a growing iterate (the reference's statuses: R:test/test_scs_coverage.py:862-904)"""
+    monkeypatch.setenv("SCS_HIP_KRYLOV", "minres")
+    from scipy import sparse
+    rng = np.random.RandomState(4)
+    # infeasible: x1 + x2 = 1 (z), x <= -1 componentwise (l)
+    A = sparse.csc_matrix(np.vstack([np.ones((1, 2)), np.eye(2)]))
+    data = {"A": A, "b": np.array([1.0, -1.0, -1.0]), "c": rng.randn(2)}
+    sol = hip.SCS(*helpers.raw_args(data, {"z": 1, "l": 2}), eps_abs=1e-7, eps_rel=1e-7, eps_infeas=1e-8, verbose=False).solve(False, None, None, None)
+    assert sol["info"]["status"] == "infeasible", sol["info"]
+    # unbounded: minimise -x1 subject to x1 - x2 = 0 (z), x2 >= 0
+    A = sparse.csc_matrix(np.array([[1.0, -1.0], [0.0, -1.0]]))
+    data = {"A": A, "b": np.zeros(2), "c": np.array([-1.0, 0.0])}
+    sol = hip.SCS(*helpers.raw_args(data, {"z": 1, "l": 1}), eps_abs=1e-7, eps_rel=1e-7, eps_infeas=1e-8, verbose=False).solve(False, None, None, None)
+    assert sol["info"]["status"] == "unbounded", sol["info"]
+
+
+def test_minres_is_deterministic_and_the_run_ahead_loop_keeps_its_bits(hip, oracle, monkeypatch):
+    K, n, k, _ = CASES["z_lp_soc"]
+    data, _, _ = pg.gen_feasible(K, n, k, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    monkeypatch.setenv("SCS_HIP_KRYLOV", "minres")
+    stg = dict(STG)
+    stg.update(eps_abs=1e-7, eps_rel=1e-7)
+    a = hip.SCS(*args, **stg).solve(False, None, None, None)
+    b = hip.SCS(*args, **stg).solve(False, None, None, None)
+    monkeypatch.setenv("SCS_HIP_PIPELINE", "0")  # one host look per iteration instead of whole iterations queued ahead
+    c = hip.SCS(*args, **stg).solve(False, None, None, None)
+    monkeypatch.setenv("SCS_HIP_PIPELINE", "1")
+    monkeypatch.setenv("SCS_HIP_PIPE_CHUNK", "3")  # chunks too short on purpose: every iteration stalls and is finished synchronously
+    d = hip.SCS(*args, **stg).solve(False, None, None, None)
+    for other in (b, c, d):
+        assert other["info"]["iter"] == a["info"]["iter"] and other["info"]["cg_iters"] == a["info"]["cg_iters"]
+        for key in ("x", "y", "s"):
+            np.testing.assert_array_equal(other[key], a[key], err_msg=key)
+
+
+def test_minres_warm_start_and_update(hip, oracle, monkeypatch):
+    monkeypatch.setenv("SCS_HIP_KRYLOV", "minres")
+    K, n, k, _ = CASES["z_qp"]
+    data, p_star, _ = pg.gen_feasible_qp(K, n, k, 8, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    s = hip.SCS(*helpers.raw_args(data, K), **STG)
+    cold = s.solve(False, None, None, None)
+    assert cold["info"]["status"] == "solved"
+    warm = s.solve(True, cold["x"], cold["y"], cold["s"])
+    assert warm["info"]["status"] == "solved" and warm["info"]["iter"] <= max(25, cold["info"]["iter"] // 4)
+    b2 = data["b"] * 1.01
+    s.update(b2, None)
+    upd = s.solve(True, None, None, None)
+    ref = oracle.OracleSCS(*helpers.raw_args(dict(data, b=b2), K), indirect=False, **STG).solve(False)
+    assert upd["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
+    _xys(upd, ref)
+
+
+def test_auto_mode_switches_only_where_pcg_is_slow(hip, oracle, monkeypatch):
+    """SCS_HIP_KRYLOV unset: PCG unless the cone has >= 256 zero rows and PCG needed ~100 steps per solve; a problem without a zero
+    cone never sees MINRES"""
+    monkeypatch.delenv("SCS_HIP_KRYLOV", raising=False)
+    K, n, k, _ = CASES["z_lp_soc"]
+    data, _, _ = pg.gen_feasible(K, n, k, 5, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    sol = hip.SCS(*helpers.raw_args(data, K), **STG).solve(False, None, None, None)
+    assert "MINRES" not in sol["info"]["lin_sys_solver"]  # 120 zero rows: below the threshold
+    K2 = {"z": 3000, "l": 9000}
+    data2, p2, _ = pg.gen_feasible(K2, 6000, 8, 6, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    sol2 = hip.SCS(*helpers.raw_args(data2, K2), eps_abs=1e-6, eps_rel=1e-6, verbose=False).solve(False, None, None, None)
+    assert sol2["info"]["status"] == "solved"
+    assert abs(sol2["info"]["pobj"] - p2) < 1e-4 * max(1.0, abs(p2))

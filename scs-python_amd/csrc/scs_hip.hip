@@ -1218,12 +1218,16 @@ struct ScsHipWork {
     process_pending_flags();
   }
 
-  // ---- MINRES on the system with the zero-cone block un-eliminated (minres.hpp): the ADMM iteration's linear solve when the cone has
-  // zero rows and PCG needs many steps (BASELINE config 3: ~330).  SCS_HIP_KRYLOV = cg | minres | auto (default): auto switches a
-  // workspace over, for good, once the third quartile of its last 8 PCG solves exceeds kMrAutoSteps steps and z >= kMrAutoZ.
-  // Cold KKT solves (init, scale updates) stay with PCG.
+  // ---- MINRES on the system with the zero-cone block un-eliminated (minres.hpp), the second Krylov method of the indirect solve.
+  // SCS_HIP_KRYLOV = cg (default) | minres (whenever the cone has zero rows) | auto (switches a workspace over, for good, once the third
+  // quartile of its last 8 PCG solves exceeds kMrAutoSteps steps and z >= kMrAutoZ).  Cold KKT solves (init, scale updates) stay with PCG.
+  // NOT the default, by measurement (round 5, profiles/r05_config3_minres.txt): on BASELINE config 3 — the case it was built for, 10 % zero-cone
+  // rows, PCG at 170 steps per ADMM iteration over a whole solve — MINRES needs 241 steps per iteration at the same stopping rule and
+  // 825 instead of 700 ADMM iterations: 29.1 s against 13.9 s.  The round-4 prototype compared the two from a RANDOM warm start (1.7 x
+  // fewer steps); inside the ADMM loop the warm start is the previous iterate, the residual has to fall by a modest factor only, and the
+  // reduced residual — which MINRES does not minimise — first rises.  The recursion's residual equals the true one (SCS_HIP_MR_CHECK).
   static constexpr int kMrAutoSteps = 96, kMrAutoZ = 256;
-  int krylov = [] { const char *e = getenv("SCS_HIP_KRYLOV"); return !e ? 2 : e[0] == 'c' ? 0 : e[0] == 'm' ? 1 : 2; }();  // 0 cg, 1 minres (whenever z > 0), 2 auto; read when the workspace is made
+  int krylov = [] { const char *e = getenv("SCS_HIP_KRYLOV"); return !e ? 0 : e[0] == 'c' ? 0 : e[0] == 'm' ? 1 : e[0] == 'a' ? 2 : 0; }();  // 0 cg, 1 minres (whenever z > 0), 2 auto; read when the workspace is made
   int krylov_mode() const { return krylov; }
   bool mr_active = false, mr_ready = false, mr_allowed = true;
   double mr_tolf = [] { const char *e = getenv("SCS_HIP_MR_TOLF"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1.0; }();  // (lab) MINRES stops at mr_tolf x the PCG tolerance

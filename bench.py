@@ -370,7 +370,7 @@ def main():
             spmv_roofline = roofline
             roofline = {"bound": "mfma", "achieved": round(tf, 4), "peak": MFMA_F64_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK, 5),
                         "traffic": None, "traffic_source": None,
-                        "kernel": "K9 batched PSD projection (k_proj_psd + k_psd_gemm + k_psd_apply_v), %d matrices of order <= %d, "
+                        "kernel": "K9 batched PSD projection (k_psd_sweep_mc + k_psd_gemm + k_psd_apply_v / _q), %d matrices of order <= %d, "
                         "warm-started" % (psd_t["matrices"], psd_t["max_order"]),
                         "algorithmic_flops_per_launch": psd_t["ref_flops"], "avg_launch_ms": round(psd_t["ms"], 4),
                         "samples": kt["cone_n"], "ms_reprojecting_the_same_vector": psd_t.get("ms_same_vector"),
@@ -479,6 +479,7 @@ def main():
             line, d4, K4 = measure(wl, st, wu, steady=(wl == "config4_psd"), gather=False)
             if wl == "config4_psd":
                 ws4 = scs.SCS(d4, K4, verbose=False, acceleration_lookback=10, linear_solver=scs.LinearSolver.HIP_INDIRECT)
+                ws4._solver._set_profiling(True)  # in-situ events around the cone kernels of the queued iterations (as in the timed window)
                 torch.cuda.synchronize()
                 time.sleep(0.4)
                 tw = time.perf_counter()
@@ -489,15 +490,47 @@ def main():
                                        "iterations": sol4["info"]["iter"], "wall_s": round(tw, 3),
                                        "value": round(sol4["info"]["iter"] / tw, 1), "unit": "ADMM iters/s over the whole solve",
                                        "cg_steps_per_admm_iter": round(sol4["info"]["cg_iters"] / max(sol4["info"]["iter"], 1), 2)}
+                # K9 over the WHOLE solve (the window above is the cold start, where the sweeps dominate): average of the in-situ samples
+                kt4 = ws4._solver._kernel_times()
+                if kt4["cone_n"] > 0:
+                    k9_ms = kt4["cone_ms"] / kt4["cone_n"]
+                    ref_fl = sum((16. / 3. + 2.) * float(k_) ** 3 for k_ in K4.get("s", []))
+                    line["whole_solve"]["k9"] = {"ms_per_projection": round(k9_ms, 4), "samples": kt4["cone_n"],
+                                                 "achieved_tflops": round(ref_fl / (k9_ms * 1e-3) / 1e12, 3),
+                                                 "frac_of_fp64_mfma_peak": round(ref_fl / (k9_ms * 1e-3) / 1e12 / MFMA_F64_PEAK, 4),
+                                                 "what": "cone kernels of the queued iterations between two HIP events (K9 is all of it but the one-launch l kernel); "
+                                                         "flops = the reference count of the roofline entry above"}
+                # K9's refinement stage (round 5, csrc/psd.hpp psd_stop_test): how many of the solve's projections took it, per matrix
+                st4 = ws4._solver._psd_refine_stats()
+                line["whole_solve"]["psd_refinement"] = {
+                    "projections_refined_per_matrix_mean_min_max": [round(float(st4[:, 0].mean()), 1), int(st4[:, 0].min()), int(st4[:, 0].max())],
+                    "refinements_sent_back_to_the_sweeps_per_matrix_mean": round(float(st4[:, 1].mean()), 2),
+                    "what": "GEMM-only removal of the mixed-sign part of V'AV behind the Jacobi sweeps; SCS_HIP_PSD_REFINE=0 restores the strict sweeps"}
                 del ws4, sol4
             else:
                 line.pop("steady_window", None)
-            del d4, K4
             if wl == "config3_mixed":
+                # the 20-step window above is a cold start (333 CG steps per iteration); a WHOLE solve averages half that (round 5)
+                ws3 = scs.SCS(d4, K4, verbose=False, acceleration_lookback=10, linear_solver=scs.LinearSolver.HIP_INDIRECT, max_iters=2000)
+                torch.cuda.synchronize()
+                time.sleep(0.4)
+                tw = time.perf_counter()
+                sol3 = ws3.solve(warm_start=False)
+                torch.cuda.synchronize()
+                tw = time.perf_counter() - tw
+                line["whole_solve"] = {"settings": "defaults (eps_abs = eps_rel = 1e-4)", "status": sol3["info"]["status"],
+                                       "iterations": sol3["info"]["iter"], "wall_s": round(tw, 3),
+                                       "value": round(sol3["info"]["iter"] / tw, 1), "unit": "ADMM iters/s over the whole solve",
+                                       "cg_steps_per_admm_iter": round(sol3["info"]["cg_iters"] / max(sol3["info"]["iter"], 1), 2),
+                                       "krylov": sol3["info"]["lin_sys_solver"],
+                                       "minres": "built (csrc/minres.hpp, SCS_HIP_KRYLOV=minres) and measured on this solve: 241 steps per iteration and "
+                                                 "825 iterations against PCG's 170 and 700 — 2.1 x slower, not the default (profiles/r05_config3_minres.txt)"}
+                del ws3, sol3
                 line["config"]["why_so_many_cg_steps"] = (
                     "conditioning, not cone kernels: R_y weighs the 100,000 zero-cone rows 1000 x heavier than the others "
                     "(1/(1000 scale) vs 1/scale), the reduced system's condition number is ~1e3 and Jacobi-preconditioned CG needs "
                     "~330 steps per solve; with the same rows declared `l` it needs 13 (profiles/r03_config3_cg_study.txt)")
+            del d4, K4
             if wl == "powerlaw_lp":
                 line["config"]["why_this_line"] = (
                     "not a BASELINE config: the metric workload's size with Pareto(1.3) row lengths (up to 20 000 nonzeros per row) — "

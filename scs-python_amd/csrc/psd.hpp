@@ -102,7 +102,7 @@ __host__ __device__ inline long psd_np(long n) {  // padded order: even number o
 // Rotation log entry: W row-major (ld 16), so that the MFMA operand fetch W[4 kk + lk][li] of a wavefront is 64 consecutive
 // doubles (4 lines per instruction; the column-major stride-17 LDS layout read from global memory costs 17)
 __host__ __device__ inline int psd_log_at(int row, int col) { return col + 16 * row; }
-constexpr int kPsdLogSweeps = 4;  // split mode: sweeps whose pivot rotations fit in the log of one round
+constexpr int kPsdLogSweeps = 6;  // split mode: sweeps whose pivot rotations fit in the log of one round (round 5: 6 x 2 rounds instead of 4 x 3 — two launches fewer per projection; same rotations in the same order: same bits)
 __host__ __device__ inline long psd_log_doubles(long n) {  // rotation log: sweeps x steps x pivots x 16x17
   const long np = psd_np(n), nb = np / kPsdB;
   return (long)kPsdLogSweeps * (nb - 1) * (nb / 2) * kPsdWsz;

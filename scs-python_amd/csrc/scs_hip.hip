@@ -756,7 +756,7 @@ struct ScsHipWork {
   DevBuf<double> psd_scratch;
   int n_psd = 0, n_psd_big = 0;
   // split mode of the block kernel (psd.hpp): worth it when the large matrices alone leave most CUs idle
-  static constexpr int kPsdSplitRounds = 3;  // x kPsdLogSweeps sweeps: a cold start needs ~9
+  static constexpr int kPsdSplitRounds = 2;  // x kPsdLogSweeps = 6 sweeps: a cold start needs ~9; the LAST round is the one behind the refinement stage
   bool psd_split = false;
   int psd_max_np = 0, psd_max_tiles = 0;
   // complex PSD cones: projected through the packed 2k x 2k real embedding held in cs_stage (psd.hpp)

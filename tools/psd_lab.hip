@@ -72,8 +72,8 @@ int main(int argc, char **argv) {
                          psd_refine_default(false), 0);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
       hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
-      for (int round = 0; round < 3; ++round) {
-        int post = (R.on && round == 2) ? 1 : 0;
+      for (int round = 0; round < 2; ++round) {
+        int post = (R.on && round == 1) ? 1 : 0;
         if (post) {
           hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);
           hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, 0, d_x, B, d_scr, 1, nullptr, gper);

@@ -446,7 +446,7 @@ def main():
                     "wall_s": round(tb_max, 3), "iterations_min_median_max": [iters_sorted[0], iters_sorted[len(iters_sorted) // 2], iters_sorted[-1]],
                     "rank0_phases_s": {k_: round(v_, 3) for k_, v_ in timing.items()}, "linear_solver": batch_ls.value}
 
-        # the line's `value` is the leg with --batch-linsys (default: the dense direct solver, csrc/dense.hpp, n = 1350 <= 4096); the OTHER
+        # the line's `value` is the leg with --batch-linsys (default: the dense direct solver, csrc/dense.hpp, n = 1350 <= 8192); the OTHER
         # linear solver — the indirect PCG path this repository is about — runs right behind it and rides along
         first = run_batch(args.batch_linsys)
         other_ls = "hip_indirect" if args.batch_linsys == "hip_dense" else "hip_dense"

@@ -99,12 +99,12 @@ int scs_hip_kkt_solve(const ScsMatrix *A, const ScsMatrix *P, const scs_float *d
                       scs_float tol, scs_int *cg_iters);
 
 /* Same system solved with the DENSE DIRECT linsys (csrc/dense.hpp): G = R_x + P + A' R_y^{-1} A is formed and inverted on
- * the device (blocked Gauss-Jordan on the fp64 MFMA), x = G^{-1}(rhs_x + A' R_y^{-1} rhs_y), y = R_y^{-1}(A x - rhs_y).  n <= 4096.
+ * the device (blocked Gauss-Jordan on the fp64 MFMA), x = G^{-1}(rhs_x + A' R_y^{-1} rhs_y), y = R_y^{-1}(A x - rhs_y).  n <= 8192.
  * Plays the role of the reference's direct backends (QDLDL / cuDSS / the LAPACK dense module: R:meson.build:241-262,374-391). */
 int scs_hip_kkt_solve_dense(const ScsMatrix *A, const ScsMatrix *P, const scs_float *diag_r, scs_float *rhs);
 
 /* scs_init with an explicit choice of the linear-system solver: 1 = sparse indirect (PCG; what scs_init builds unless the
- * environment says SCS_HIP_LINSYS=dense), 2 = dense direct (n <= 4096: the explicit inverse of the reduced KKT matrix lives in
+ * environment says SCS_HIP_LINSYS=dense), 2 = dense direct (n <= 8192: the explicit inverse of the reduced KKT matrix lives in
  * HBM, the linear solve of an ADMM iteration is three dependent launches and never waits for the host), 0 = the default.
  * The reference selects its linear solver by MODULE (R:scs/py/__init__.py:40-66: _scs_direct, _scs_indirect, _scs_gpu, ...);
  * scs._scs_hip binds 1, scs._scs_hip_dense binds 2.  Everything else is scs_init's contract. */

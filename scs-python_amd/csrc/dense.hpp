@@ -29,9 +29,9 @@
 namespace scship {
 
 constexpr int kDenseB = 64;        // block size of the Gauss-Jordan sweep = tile edge of the update
-constexpr int kDenseMaxN = 4096;   // G^{-1} of order 4096 is 134 MB; beyond that the indirect path is the product
+constexpr int kDenseMaxN = 8192;   // G^{-1} of order 8192 is 537 MB (round 5; 4096 until round 4); the build kernel's two LDS columns are 128 KiB there
 constexpr int kDenseThreads = 256;
-constexpr int kDenseBuildThreads = 128;  // two wavefronts = two columns of G per workgroup, NP doubles of LDS each (<= 64 KiB)
+constexpr int kDenseBuildThreads = 128;  // two wavefronts = two columns of G per workgroup, NP doubles of LDS each (<= 128 KiB of the CU's 160)
 inline int dense_np(int n) { return (n + kDenseB - 1) / kDenseB * kDenseB; }
 
 struct DenseMat {

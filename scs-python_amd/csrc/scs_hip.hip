@@ -1092,6 +1092,16 @@ struct ScsHipWork {
     HIP_CHECK(hipStreamSynchronize(stream));
     setup_pending = false;
     setup_time += now_ms() - t0;
+    if (dense()) {
+      //  the Gauss-Jordan sweep of the dense path does not pivot and checks nothing on the way: at least the solve it has just
+      // been used for, g = KKT^-1 [c; -b], must be finite (g' R g is on the device already: one double)
+      double gg = 0.;
+      HIP_CHECK(hipMemcpyAsync(&gg, sc.p + S_GG, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (!std::isfinite(gg))
+        throw std::runtime_error("hip_dense: the inverse of the reduced KKT matrix is not finite (a vanishing pivot block — column-rank-deficient A "
+                                 "with a tiny rho_x?); use LinearSolver.HIP_INDIRECT for this problem");
+    }
   }
   void dense_refactor() {  // diag_r must be current on the stream
     dense_factor(dense_src(), dense_mat(), stream);

@@ -51,7 +51,7 @@ class LinearSolver(enum.Enum):
   GPU_INDIRECT = "gpu_indirect"
   CUDSS = "cudss"
   HIP_INDIRECT = "hip_indirect"  # MI355X (gfx950): device-resident indirect solver
-  HIP_DENSE = "hip_dense"  # MI355X (gfx950): device dense direct solver for small problems (n <= 4096)
+  HIP_DENSE = "hip_dense"  # MI355X (gfx950): device dense direct solver for small problems (n <= 8192)
 
 
 # enum member -> extension-module name under the `scs` package

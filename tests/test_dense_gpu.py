@@ -50,7 +50,8 @@ def _rand_csc(m, n, density, seed):
     (4050, 1350, 0.03, False),   # a config-5 member's shape: 22 block steps of the Gauss-Jordan sweep
     (300, 64, 0.1, False), (300, 65, 0.1, True), (20, 1, 0.9, False),
     (30, 2, 0.9, False), (40, 3, 0.8, True), (400, 127, 0.1, False), (400, 129, 0.1, True), (500, 130, 0.08, False),   # GEMV: 4 columns per wavefront, row pairs
-    (6000, 4096, 0.001, False),  # the largest order the backend takes: 64 block steps, 64 KiB of LDS per build workgroup
+    (6000, 4096, 0.001, False),  # 64 block steps, 64 KiB of LDS per build workgroup (the cap of round 4)
+    (12000, 8192, 0.0004, False),  # the largest order the backend takes (round 5): 128 block steps, 128 KiB of LDS per build workgroup, G^-1 = 537 MB
 ])
 def test_kkt_solve_dense_vs_direct_ldl(hip, oracle, m, n, density, with_P):
     A = _rand_csc(m, n, density, 21 + n)
@@ -228,9 +229,9 @@ def test_dense_through_the_front_end_and_its_limit():
     sol = scs.SCS({"A": A, "b": np.array([1.0, 0.0]), "c": np.array([-1.0])}, {"l": 2},
                   linear_solver=scs.LinearSolver.HIP_DENSE, verbose=False, eps_abs=1e-9, eps_rel=1e-9).solve()
     assert sol["info"]["status"] == "solved" and abs(sol["x"][0] - 1.0) < 1e-6
-    n = 4097
+    n = 8193
     big = sparse.eye(n, format="csc")
-    with pytest.raises(ValueError, match="hip_dense: n = 4097 exceeds 4096"):
+    with pytest.raises(ValueError, match="hip_dense: n = 8193 exceeds 8192"):
         scs.SCS({"A": big, "b": np.ones(n), "c": np.ones(n)}, {"l": n}, linear_solver="hip_dense", verbose=False)
 
 

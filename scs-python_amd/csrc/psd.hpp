@@ -433,6 +433,8 @@ __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_sto
 // (padding included), is written while the gate's sums are formed — speculatively: whether the matrix IS refinable is known a
 // reduction later, and a matrix that is not simply never reads it.  a_ij = a_ji exactly and the reciprocal estimate is odd in its
 // argument: K1 is exactly antisymmetric.
+// (ONE call site per kernel — k_psd_sweep_mc sits at its 128-register cap with spills — and inlined: as a real function it needs a dynamic stack,
+//  which a cooperative launch aborts on)
 template <bool AGENT>
 __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, double *diag, double *red, double *bc, double offtol2, int mode,
                                              const PsdRefineCfg &R, double *state, bool lead, double *K1 = nullptr, bool first = false) {
@@ -452,30 +454,45 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
   }
   double off = 0., tot = 0., mix = 0., kf = 0., om = 0.;
   if (mode != PSD_STOP_STRICT) {
-    // column by column (wavefront w: columns w, w + 16, ...; lanes down the rows): no index arithmetic, coalesced loads and K1 stores.
-    // (The strict test below keeps the element order of rounds 1-4 — the bits of the one-launch kernel's decision.)
+    // Column by column (wavefront w: columns w, w + 16, ...; lanes down the rows), the LOWER triangle only — the matrix is exactly symmetric, every
+    // off-diagonal term counts twice —, the same-sign terms through a table of 1 / d_i, the mixed-sign ones through ONE fp32 reciprocal estimate
+    // (a gate, and K1 only enters the second-order term; the estimate is odd in its argument: K1 stays exactly antisymmetric).  Round 5: the test is
+    // what a projection that needs no sweep still pays twice (before and behind the refinement); the first version (all n^2 elements, two fp64
+    // reciprocals each) took 32 us of a 377 us projection per call.  (The strict test below keeps the element order of rounds 1-4 — the bits of the
+    // one-launch kernel's decision.)
     const int wave = tid >> 6, lane = tid & 63;
+    const bool tab = 2 * n <= kPsdWaves * kPsdWaveLds;  // 1 / d_i behind the diagonal in LDS (orders beyond 4352: reciprocals on the fly)
+    if (tab) {
+      for (int j = tid; j < n; j += kPsdThreads) diag[n + j] = 1. / diag[j];
+      __syncthreads();
+    }
     for (int j = wave; j < n; j += kPsdWaves) {
       const double dj = diag[j];
       const bool pj = dj > 0.;
-      for (int i = lane; i < n; i += 64) {
+      const double ij = tab ? diag[n + j] : 1. / dj;
+      for (int i = j + lane; i < n; i += 64) {
         const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
         const double a2 = a * a;
-        tot += a2;
-        double k1 = 0.;
-        if (i != j) {
-          off += a2;
-          const double di = diag[i];
-          if ((di > 0.) != pj) {
-            const double r = __builtin_amdgcn_rcp(dj - di);  // (a hardware estimate is enough for a gate, and K1 only enters the second-order term)
-            k1 = a * r;
-            mix += a2;
-            kf += k1 * k1;
-          } else if (a2 > 0.) {
-            om += a2 * __builtin_amdgcn_rcp(di * dj);  // same sign: positive; a zero diagonal entry under a nonzero row: inf, no refinement
-          }
+        if (i == j) {
+          tot += a2;
+          if (wk) K1[i + (size_t)ld * j] = 0.;
+          continue;
         }
-        if (wk) K1[i + (size_t)ld * j] = k1;
+        tot += 2. * a2;
+        off += 2. * a2;
+        const double di = diag[i];
+        double k1 = 0.;  // K1[i][j] = a / (d_j - d_i)
+        if ((di > 0.) != pj) {
+          k1 = a * (double)__builtin_amdgcn_rcpf((float)(dj - di));
+          mix += 2. * a2;
+          kf += 2. * k1 * k1;
+        } else if (a2 > 0.) {
+          om += 2. * a2 * ((tab ? diag[n + i] : 1. / di) * ij);  // same sign: positive; a zero diagonal entry under a nonzero row: inf, no refinement
+        }
+        if (wk) {
+          K1[i + (size_t)ld * j] = k1;
+          K1[j + (size_t)ld * i] = -k1;
+        }
       }
     }
   } else
@@ -1039,18 +1056,6 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   // ADMM — or refined to the relaxed level) leaves without a barrier.  Every member decides on the same data: the same decision.
   const int stop_mode = R.on ? (refined ? PSD_STOP_RELAXED : (post ? PSD_STOP_STRICT : PSD_STOP_GATE)) : PSD_STOP_STRICT;
   double *Vt = A + 3 * (size_t)NP * NP;  // free between the warm-start GEMMs and k_psd_fmap: K1 / Q' of the refinement stage
-  const int code_first = psd_stop_test<false>(A, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt, round == 0);  // (plain loads: written by earlier kernels)
-  if (code_first != 0) {
-    if (g == 0) {
-      if (tid == 0) {
-        state[1] = 1.;
-        if (code_first == 2) state[7] = 1.;
-      }
-      if (code_first == 2)
-        for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;  // the diagonal the gate saw (k_psd_plan)
-    }
-    return;
-  }
   double *Sw = lds + wave * kPsdWaveLds, *Ww = Sw + kPsdWsz;
   const int nblk = H * (H + 1) / 2;
   unsigned bar_target = 0;
@@ -1075,25 +1080,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
     }
   };
 
-  // one XCD for the whole group?  (state[6]: OR of the members' XCD bits, zeroed by the front kernel)
-  bool wt = false;  // write-through (sc1) stores
-  if (G > 1) {
-    unsigned *xmask = reinterpret_cast<unsigned *>(state + 6);
-    if (tid == 0) __hip_atomic_fetch_or(xmask, 1u << psd_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gbar();
-    if (tid == 0) bc[1] = (double)__popc(__hip_atomic_load(xmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    __syncthreads();
-    wt = bc[1] != 1.;
-#ifdef PSD_MC_FORCE_WT
-    wt = true;
-#endif
-  }
-  // (behind the group's first barrier: every member has read state[] by now — a member that starts late must not see this)
-  if (refined && g == 0 && tid == 0) {  // the refinement left too much: back to the sweeps
-    state[1] = 0.;
-    state[7] = 2.;
-    state[10] += 1.;
-  }
+  bool wt = false;  // write-through (sc1) stores: set behind the first stopping test (below)
   auto st_shared = [&](double *p, double v) {
     if (wt) st_agent(p, v);
     else *p = v;
@@ -1226,7 +1213,9 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
   for (int sweep = 0; sweep < kPsdMaxSweeps; ++sweep) {
     PSD_TICK(t_n0);
     // every member evaluates the stopping test on the same data in the same order: the same decision everywhere
-    const int code = sweep == 0 ? 0 : psd_stop_test<true>(Acur, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt);
+    // (the first test comes before anything spins: a matrix with nothing to do — refinable as it arrives, the steady state of ADMM, or refined to
+    //  the relaxed level — leaves without a barrier)
+    const int code = psd_stop_test<true>(Acur, ld, n, lds, red, bc, offtol2, stop_mode, R, state, g == 0, Vt, round == 0 && sweep == 0);
     PSD_TICK(t_n1);
     PSD_ACC(1, t_n0, t_n1);
     if (code != 0) {
@@ -1236,9 +1225,29 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
           if (code == 2) state[7] = 1.;
         }
         if (code == 2)
-          for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;
+          for (int j = tid; j < NP; j += kPsdThreads) lam[j] = j < n ? lds[j] : 0.;  // the diagonal the gate saw (COMM's epilogue)
       }
       break;
+    }
+    if (sweep == 0) {
+      // one XCD for the whole group?  (state[6]: OR of the members' XCD bits, zeroed by the front kernel)
+      if (G > 1) {
+        unsigned *xmask = reinterpret_cast<unsigned *>(state + 6);
+        if (tid == 0) __hip_atomic_fetch_or(xmask, 1u << psd_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gbar();
+        if (tid == 0) bc[1] = (double)__popc(__hip_atomic_load(xmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        wt = bc[1] != 1.;
+#ifdef PSD_MC_FORCE_WT
+        wt = true;
+#endif
+      }
+      // (behind the group's first barrier: every member has read state[] by now — a member that starts late must not see this)
+      if (refined && g == 0 && tid == 0) {  // the refinement left too much: back to the sweeps
+        state[1] = 0.;
+        state[7] = 2.;
+        state[10] += 1.;
+      }
     }
     if (sweep >= kPsdLogSweeps) break;  // log full: the next round continues
 

@@ -781,7 +781,7 @@ struct ScsHipWork {
                            psd_refine_default(false), 0);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
         hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
-        int mc = in_capture ? 1 : psd_mc_members(big);
+        int mc = (in_capture || !fl.p) ? 1 : psd_mc_members(big);  // (the multi-CU kernel polls the workspace's error flag at its barriers)
         PsdRefineCfg R = psd_refine;
         if ((size_t)32 * psd_max_np * sizeof(double) > 160 * 1024) R.on = 0;  // k_psd_apply_q keeps two 16-row strips in LDS
         std::unique_ptr<SpinLink> link;
@@ -3427,6 +3427,7 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
     w.m = m;
     w.psd_warm = 0;
     upload_cone_meta(&w);
+    w.fl.alloc_zero(F_COUNT, ts.s);  // (k_psd_sweep_mc polls its error flag while it waits at a barrier)
     w.sc.alloc_zero(S_COUNT, ts.s);
     const double one = 1.0;
     HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, ts.s));
@@ -3458,6 +3459,7 @@ int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, 
     w.m = m;
     w.psd_warm = 1;  // as inside the ADMM loop: the eigenvectors (and every other cone's warm-start state) carry over
     upload_cone_meta(&w);
+    w.fl.alloc_zero(F_COUNT, ts.s);  // (k_psd_sweep_mc polls its error flag while it waits at a barrier)
     w.sc.alloc_zero(S_COUNT, ts.s);
     const double one = 1.0;
     HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, ts.s));

@@ -1566,6 +1566,9 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
       for (int j = 0; j < NJ2; ++j) pb2[j] = reinterpret_cast<const f64x2 *>(Bo + tj0 * 16 + 32 * j + 2 * li + (size_t)ld * lk);
       f64x2 a0[kPsdPf], b0[kPsdPf][NJ2], a1[kPsdPf], b1[kPsdPf][NJ2];
       auto load = [&](f64x2 (&as)[kPsdPf], f64x2 (&bs)[kPsdPf][NJ2], int trip) {
+#if defined(PSD_GEMM_ABL) && PSD_GEMM_ABL == 2  // (lab) MFMAs only: the operands of the first trip, fetched once
+        if (trip > 0) return;
+#endif
 #pragma unroll
         for (int st = 0; st < kPsdPf; ++st) {
           const size_t at = (size_t)ldh * (4 * (kPsdPf * trip + st));
@@ -1576,6 +1579,15 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
         }
       };
       auto use = [&](const f64x2 (&as)[kPsdPf], const f64x2 (&bs)[kPsdPf][NJ2]) {
+#if defined(PSD_GEMM_ABL) && PSD_GEMM_ABL == 1  // (lab, tools/psd_lab.hip: profiles/r05_psd_gemm_ablation.txt) loads only: one cheap use per loaded value
+#pragma unroll
+        for (int st = 0; st < kPsdPf; ++st) {
+          acc[0][0][0] += as[st].x + as[st].y;
+#pragma unroll
+          for (int j = 0; j < NJ2; ++j) acc[0][0][1] += bs[st][j].x + bs[st][j].y;
+        }
+        return;
+#endif
 #pragma unroll
         for (int st = 0; st < kPsdPf; ++st) {
           const double a[kPsdRT] = {as[st].x, as[st].y};
@@ -1610,6 +1622,17 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
     else product(integral_constant<int, 1>{}, integral_constant<int, 4>{});
   }
   // acc[r][j][t] = C[row 2 (lk + 4t) + r of the tile pair (single row tile: row lk + 4t)][column 2 li + (j & 1) of column pair j >> 1]
+#if defined(PSD_GEMM_ABL) && PSD_GEMM_ABL == 3  // (lab) no epilogue: a store that never happens keeps the accumulators alive
+  {
+    double t = 0.;
+#pragma unroll
+    for (int j = 0; j < 2 * kPsdNJ2max; ++j)
+#pragma unroll
+      for (int r = 0; r < kPsdRT; ++r) t += acc[r][j][0] + acc[r][j][1] + acc[r][j][2] + acc[r][j][3];
+    if (t == 1.2345e-300) Tm[lane] = t;
+    return;
+  }
+#endif
 #pragma unroll
   for (int jp = 0; jp < kPsdNJ2max; ++jp) {
     if (tj0 + 2 * jp >= tj1) break;  // (uniform: nothing of this column pair is wanted)

@@ -1636,6 +1636,34 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
 #pragma unroll
   for (int jp = 0; jp < kPsdNJ2max; ++jp) {
     if (tj0 + 2 * jp >= tj1) break;  // (uniform: nothing of this column pair is wanted)
+    // COMM / KK: what the epilogues of this column pair's (up to four) tiles read from memory — S and the eigenvalues, K2 at the entry
+    // and at its mirror — is requested HERE, in front of the LDS re-layout, instead of tile by tile in front of its use (round 5, late:
+    // these two kinds ran 10 us longer than the others with the same products; the values are the same, so are the bits)
+    double pf_a[kPsdRT][2][4], pf_b[kPsdRT][2][4], pf_l[2];
+    if constexpr (KIND == PSD_KK || KIND == PSD_COMM) {
+#pragma unroll
+      for (int r = 0; r < kPsdRT; ++r) {
+        const int ti = ti0 + r;
+        if (r >= rows) break;
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+          const int tj = tj0 + 2 * jp + cq;
+          if (tj >= tj1 || (lower && tj > ti)) break;
+          if constexpr (KIND == PSD_COMM) pf_l[cq] = lam[tj * 16 + li];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if constexpr (KIND == PSD_KK) {
+              pf_a[r][cq][t] = ti != tj ? Tm[(tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t)] : 0.;
+              pf_b[r][cq][t] = Tm[(ti * 16 + li) + (size_t)ld * (tj * 16 + lk + 4 * t)];
+            } else {
+              const int i = ti * 16 + lk + 4 * t;
+              pf_a[r][cq][t] = A[i + (size_t)ld * (tj * 16 + li)];
+              pf_b[r][cq][t] = lam[i];
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < kPsdRT; ++r)
 #pragma unroll
@@ -1671,9 +1699,8 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
             double val[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              const int i = ti * 16 + lk + 4 * t, jc = tj * 16 + li;
-              const double di = lam[i], dj = lam[jc];
-              const double sij = A[i + (size_t)ld * jc];
+              const double di = pf_b[r][cq][t], dj = pf_l[cq];
+              const double sij = pf_a[r][cq][t];
               val[t] = ((di > 0.) != (dj > 0.)) ? (2. * sij - c[t]) / (dj - di) : 0.;
             }
             if (ti != tj) {
@@ -1696,7 +1723,7 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
 #pragma unroll
               for (int t = 0; t < 4; ++t) {  // the mirror entry (jc, i): its own K2 entry is read where it lies (coalesced)
                 const size_t at = (tj * 16 + li) + (size_t)ld * (ti * 16 + lk + 4 * t);
-                Ko[at] = -Tm[at] - 0.5 * c[t];
+                Ko[at] = -pf_a[r][cq][t] - 0.5 * c[t];
               }
             }
 #pragma unroll
@@ -1708,7 +1735,7 @@ __global__ __launch_bounds__(kPsdGemmThreads) void k_psd_gemm(double *x, PsdBatc
               double v = Sw[rr + 17 * cc];
               if (ti == tj) v = 0.5 * (v + Sw[cc + 17 * rr]);
               const size_t at = (ti * 16 + rr) + (size_t)ld * (tj * 16 + cc);
-              Ko[at] = ((ti == tj && rr == cc) ? 1. : 0.) - Tm[at] - 0.5 * v;
+              Ko[at] = ((ti == tj && rr == cc) ? 1. : 0.) - pf_b[r][cq][t] - 0.5 * v;
             }
             wave_sync();
           } else if (KIND == PSD_G2 || KIND == PSD_S1) {  // mirrored; diagonal tiles symmetrised (average of the two triangles): A0 exactly symmetric

@@ -77,6 +77,9 @@ def test_single_gpu_line_has_every_leg():
     assert mc["cores"] in [t for t, _ in mc["thread_sweep_iters_per_s"]]
     assert mc["value"] == max(v for _, v in mc["thread_sweep_iters_per_s"]) or abs(mc["value"] - max(v for _, v in mc["thread_sweep_iters_per_s"])) < 1e-2
     assert out["config5_batch"]["linear_solver"] == "hip_dense"
+    # every member's objective against the optimum its generator constructed (default settings: residuals at 1e-4, the objective ~1e-3)
+    assert out["config5_batch"]["objective_checked"] == 8 and out["config5_batch"]["objective_max_rel_err_vs_constructed_optimum"] < 5e-3
+    assert out["config5_batch"]["other_linear_solver"]["objective_max_rel_err_vs_constructed_optimum"] < 5e-3
     assert rf["traffic"] is None and rf["traffic_source"] is None  # (no committed counter pass for this workload)
     assert out["config"]["cg_steps_per_s"] > 0 and out["config"]["ms_per_cg_step"] > 0
     assert out["steady_window"]["aa_accepted_in_window"] >= 0

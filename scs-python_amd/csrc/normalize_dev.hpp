@@ -145,6 +145,66 @@ __global__ __launch_bounds__(kVecThreads) void k_invsqrt_acc(double *t, double *
   }
 }
 
+// One launch for what follows the norms of a pass (round 5, late: scs_init of a small problem is bound by the NUMBER of runtime calls — 134 launches
+// of an equilibration, 16 setup threads of a batch contending for the runtime): [the square roots of the l2 pass,] the block rule of
+// k_enforce_blocks and both k_invsqrt_acc sweeps.  Workgroups [0, nbD): rows in front of the first cone block, element by element;
+// [nbD, nbD + nbE): the columns; the rest: one wavefront per cone block (EVERY block behind the separable rows, the one-row ones too — for
+// those the block rule is the identity), which reduces the block exactly like k_enforce_blocks and finishes its rows itself.
+// Same operations on the same values in the same order: D and E keep their bits.
+__device__ __forceinline__ double d_invsqrt_limit(double x) {
+  x = x < 1e-4 ? 1.0 : x;
+  x = x > 1e4 ? 1e4 : x;
+  const double s = sqrt(x);
+  return s < 1e-18 ? 1.0 / 1e-18 : 1.0 / s;
+}
+__global__ __launch_bounds__(kVecThreads) void k_pass_finish(double *Dt, double *D, int prefix, double *Et, double *E, int n, const int *__restrict__ boff,
+                                                             const int *__restrict__ blen, int nblocks, int l2, int nbD, int nbE) {
+  const int b = blockIdx.x;
+  if (b < nbD + nbE) {
+    const bool rows = b < nbD;
+    double *t = rows ? Dt : Et, *acc = rows ? D : E;
+    const int cnt = rows ? prefix : n, nb = rows ? nbD : nbE, bb = rows ? b : b - nbD;
+    for (long i = (long)bb * kVecThreads + threadIdx.x; i < cnt; i += (long)nb * kVecThreads) {
+      double x = t[i];
+      if (l2) x = sqrt(x);
+      const double f = d_invsqrt_limit(x);
+      t[i] = f;
+      acc[i] *= f;
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int blk = (b - nbD - nbE) * (kVecThreads / 64) + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;
+  const int len = blen[blk];
+  if (len <= 0) return;
+  double *d = Dt + boff[blk], *a = D + boff[blk];
+  double w = 0.;
+  if (len <= 64) {
+    if (lane == 0) {
+      for (int j = 0; j < len; ++j) {
+        const double v = l2 ? sqrt(d[j]) : d[j];
+        w = l2 ? w + v : fmax(w, fabs(v));
+      }
+      if (l2) w /= (double)len;
+    }
+    w = __shfl(w, 0, 64);
+  } else {
+    for (int j = lane; j < len; j += 64) {
+      const double v = l2 ? sqrt(d[j]) : d[j];
+      w = l2 ? w + v : fmax(w, fabs(v));
+    }
+    w = l2 ? wave_sum(w) : wave_max(w);
+    w = __shfl(w, 0, 64);
+    if (l2) w /= (double)len;
+  }
+  const double f = d_invsqrt_limit(w);
+  for (int j = lane; j < len; j += 64) {
+    d[j] = f;
+    a[j] *= f;
+  }
+}
+
 // val[p] *= rs[row] * cs[col[p]]
 __global__ __launch_bounds__(kVecThreads) void k_rescale(const int *__restrict__ rowptr, const int *__restrict__ col, double *val,
                                                          int rows, const double *__restrict__ rs, const double *__restrict__ cs) {

@@ -520,12 +520,15 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
   hipLaunchKernelGGL(k_fill, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, D.p, 1.0, (long)m);
   hipLaunchKernelGGL(k_fill, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, E.p, 1.0, (long)n);
   // non-separable cone blocks (everything after the z/l/box rows)
+  // (every block behind the separable rows, the one-row ones too: normalize_dev.hpp k_pass_finish)
   std::vector<int> boff, blen;
+  const int prefix = (int)std::min<long>(cone.boundaries[0], m);
   long count = cone.boundaries[0];
   for (size_t i = 1; i < cone.boundaries.size(); ++i) {
-    if (cone.boundaries[i] > 1) { boff.push_back((int)count); blen.push_back(cone.boundaries[i]); }
+    if (cone.boundaries[i] >= 1) { boff.push_back((int)count); blen.push_back(cone.boundaries[i]); }
     count += cone.boundaries[i];
   }
+  const bool fused_finish = [] { const char *e = getenv("SCS_HIP_NORM_FUSE"); return !(e && e[0] == '0'); }();  // =0: the four launches of rounds 1-4 (A/B; same bits)
   DevBuf<int> dboff, dblen;
   const int nblocks = (int)boff.size();
   if (nblocks) { dboff.upload(boff.data(), boff.size(), s); dblen.upload(blen.data(), blen.size(), s); }
@@ -544,15 +547,21 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
     const int l2 = pass >= 25 ? 1 : 0;
     const int l2_next = pass + 1 >= 26 ? -1 : (pass + 1 >= 25 ? 1 : 0);
     if (Pf) hipLaunchKernelGGL(k_combine, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, Ep.p, n, l2);
-    if (l2) {
-      hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, m);
-      hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, n);
+    if (fused_finish) {
+      const int nbD = prefix > 0 ? vec_blocks(prefix) : 0, nbE = vec_blocks(n), nbB = ceil_div(nblocks, kVecThreads / 64);
+      hipLaunchKernelGGL(k_pass_finish, dim3(nbD + nbE + nbB), dim3(kVecThreads), 0, s, Dt.p, D.p, prefix, Et.p, E.p, n, (const int *)dboff.p,
+                         (const int *)dblen.p, nblocks, l2, nbD, nbE);
+    } else {
+      if (l2) {
+        hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, m);
+        hipLaunchKernelGGL(k_sqrt_inplace, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, n);
+      }
+      if (nblocks)
+        hipLaunchKernelGGL(k_enforce_blocks, dim3(ceil_div(nblocks, kVecThreads / 64)), dim3(kVecThreads), 0, s, Dt.p, dboff.p,
+                           dblen.p, nblocks, l2);
+      hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, D.p, m);
+      hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, E.p, n);
     }
-    if (nblocks)
-      hipLaunchKernelGGL(k_enforce_blocks, dim3(ceil_div(nblocks, kVecThreads / 64)), dim3(kVecThreads), 0, s, Dt.p, dboff.p,
-                         dblen.p, nblocks, l2);
-    hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, D.p, m);
-    hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, E.p, n);
     sweep(Ar, Dt.p, Et.p, l2_next, Dn.p);
     sweep(At, Et.p, Dt.p, l2_next, En.p);
     if (Pf) sweep(*Pf, Et.p, Et.p, l2_next, Ep.p);

@@ -437,6 +437,37 @@ def test_equilibration_matches_oracle(hip, oracle, with_P):
     assert abs(got[6] - ref[6]) <= 1e-13 * ref[6]
 
 
+def test_equilibration_fused_pass_finish_bit_identical(hip, oracle, monkeypatch):
+    """round 5: the square roots of the l2 pass, the cone-block rule and both 1/sqrt sweeps of an equilibration pass are ONE launch
+    (normalize_dev.hpp k_pass_finish; scs_init of a small problem is bound by the number of runtime calls).  Same operations on the same
+    values in the same order: every output must keep its bits — on a cone with one-row blocks (SOC of size 1, PSD of order 1), blocks
+    beyond one wavefront's 64 rows (reduced by the shuffle tree), exp / power triples and a box"""
+    rng = np.random.RandomState(11)
+    K = {"z": 3, "l": 40, "bu": [1.0, 2.0, 0.5], "bl": [-1.0, 0.0, -0.5], "q": [1, 7, 100, 1, 65], "s": [1, 12, 3], "ep": 2, "ed": 1, "p": [0.3, -0.6]}
+    m = pg.cone_dims(K)
+    n = 60
+    A = sparse.rand(m, n, 0.15, format="csc", random_state=rng)
+    A.data = rng.randn(A.nnz)
+    A.sort_indices()
+    B = sparse.rand(n, n, 0.05, format="csc", random_state=rng)
+    P = sparse.triu(B.T @ B + sparse.eye(n), format="csc")
+    P.sort_indices()
+    b, c = rng.randn(m), rng.randn(n)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_NORM_FUSE", mode)
+        outs[mode] = (hip.normalize(A, None, b, c, K), hip.normalize(A, P, b, c, K))
+    for u, v in zip(outs["0"], outs["1"]):
+        for x, y in zip(u, v):
+            if x is None:
+                assert y is None
+            else:
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    ref = oracle.normalize(A, P, b, c, K)
+    for name, g, r in zip(["A", "P", "b", "c", "D", "E"], outs["1"][1][:6], ref[:6]):
+        np.testing.assert_allclose(g, r, rtol=1e-12, atol=0, err_msg=name)
+
+
 def _random_cone(rng):
     """small random mixed cone (every cone type of the path can appear)"""
     K = {}

@@ -39,12 +39,10 @@ __global__ __launch_bounds__(kVecThreads) void k_row_norm(const int *__restrict_
 // Fusing the norm of the next pass into the rescale of this one halves the passes over the matrices; per-row
 // order is ascending p as in k_row_norm / k_rescale, so D and E keep their bits (rows longer than a block:
 // workgroup reduction, ~1 ulp in the l2 pass).
-__global__ __launch_bounds__(kSpmvThreads) void k_rescale_norm(CsrView A, double *val, const double *__restrict__ rs,
-                                                               const double *__restrict__ cs, int l2, double *out) {
-  __shared__ double buf[kNnzPerWg];
-  __shared__ double red[kSpmvThreads / 64];
+__device__ __forceinline__ void d_rescale_norm(const CsrView &A, double *val, const double *__restrict__ rs, const double *__restrict__ cs, int l2,
+                                               double *out, int blk, double *buf, double *red) {
   const int tid = threadIdx.x;
-  const int4 bi = A.blk[blockIdx.x];
+  const int4 bi = A.blk[blk];
   const int r0 = bi.x, r1 = bi.y, p0 = bi.z, p1 = bi.w, nnz = p1 - p0;
   if (nnz <= kNnzPerWg) {
     int ra[kRowsPerLane], re[kRowsPerLane];
@@ -95,6 +93,26 @@ __global__ __launch_bounds__(kSpmvThreads) void k_rescale_norm(CsrView A, double
     acc = l2 > 0 ? block_sum<kSpmvThreads>(acc, red) : block_max<kSpmvThreads>(acc, red);
     if (tid == 0) out[r0] = acc;
   }
+}
+__global__ __launch_bounds__(kSpmvThreads) void k_rescale_norm(CsrView A, double *val, const double *__restrict__ rs,
+                                                               const double *__restrict__ cs, int l2, double *out) {
+  __shared__ double buf[kNnzPerWg];
+  __shared__ double red[kSpmvThreads / 64];
+  d_rescale_norm(A, val, rs, cs, l2, out, (int)blockIdx.x, buf, red);
+}
+// the sweeps of a pass over A (rows -> next D norms) and A' (columns -> next E norms) [and P] do not depend on each other: one launch,
+// the workgroups [0, n1) on the first matrix, [n1, n1 + n2) on the second, the rest on the third (round 5, late: a small problem's
+// scs_init is a chain of dependent dispatches)
+__global__ __launch_bounds__(kSpmvThreads) void k_rescale_norm3(CsrView A1, double *v1, const double *__restrict__ rs1, const double *__restrict__ cs1,
+                                                                double *o1, int n1, CsrView A2, double *v2, const double *__restrict__ rs2,
+                                                                const double *__restrict__ cs2, double *o2, int n2, CsrView A3, double *v3,
+                                                                const double *__restrict__ rs3, const double *__restrict__ cs3, double *o3, int l2) {
+  __shared__ double buf[kNnzPerWg];
+  __shared__ double red[kSpmvThreads / 64];
+  const int b = (int)blockIdx.x;
+  if (b < n1) d_rescale_norm(A1, v1, rs1, cs1, l2, o1, b, buf, red);
+  else if (b < n1 + n2) d_rescale_norm(A2, v2, rs2, cs2, l2, o2, b - n1, buf, red);
+  else d_rescale_norm(A3, v3, rs3, cs3, l2, o3, b - n1 - n2, buf, red);
 }
 
 // Et = combine(Et_A, Et_P): max for the inf passes, sum of squares for the l2 pass (before the sqrt)

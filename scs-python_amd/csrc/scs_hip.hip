@@ -540,9 +540,21 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
     if (M.nblk > 0)
       hipLaunchKernelGGL(k_rescale_norm, dim3(M.nblk), dim3(kSpmvThreads), 0, s, M.view().csr, M.val.p, rs, cs, l2, out);
   };
-  sweep(Ar, nullptr, nullptr, 0, Dt.p);
-  sweep(At, nullptr, nullptr, 0, Et.p);
-  if (Pf) sweep(*Pf, nullptr, nullptr, 0, Ep.p);
+  // (the sweeps of a pass are independent of each other: one launch for all of them, normalize_dev.hpp k_rescale_norm3)
+  auto sweeps = [&](const double *Dfac, const double *Efac, int l2, double *Dout, double *Eout, double *Pout) {
+    if (!fused_finish) {
+      sweep(Ar, Dfac, Efac, l2, Dout);
+      sweep(At, Efac, Dfac, l2, Eout);
+      if (Pf) sweep(*Pf, Efac, Efac, l2, Pout);
+      return;
+    }
+    const int n1 = Ar.nblk, n2 = At.nblk, n3 = Pf ? Pf->nblk : 0;
+    if (n1 + n2 + n3 <= 0) return;
+    const CsrView v1 = Ar.view().csr, v2 = At.view().csr, v3 = Pf ? Pf->view().csr : v1;
+    hipLaunchKernelGGL(k_rescale_norm3, dim3(n1 + n2 + n3), dim3(kSpmvThreads), 0, s, v1, Ar.val.p, Dfac, Efac, Dout, n1, v2, At.val.p, Efac, Dfac, Eout, n2,
+                       v3, Pf ? Pf->val.p : (double *)nullptr, Efac, Efac, Pout, l2);
+  };
+  sweeps(nullptr, nullptr, 0, Dt.p, Et.p, Pf ? Ep.p : nullptr);
   for (int pass = 0; pass < 26; ++pass) {
     const int l2 = pass >= 25 ? 1 : 0;
     const int l2_next = pass + 1 >= 26 ? -1 : (pass + 1 >= 25 ? 1 : 0);
@@ -562,9 +574,7 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
       hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(m)), dim3(kVecThreads), 0, s, Dt.p, D.p, m);
       hipLaunchKernelGGL(k_invsqrt_acc, dim3(vec_blocks(n)), dim3(kVecThreads), 0, s, Et.p, E.p, n);
     }
-    sweep(Ar, Dt.p, Et.p, l2_next, Dn.p);
-    sweep(At, Et.p, Dt.p, l2_next, En.p);
-    if (Pf) sweep(*Pf, Et.p, Et.p, l2_next, Ep.p);
+    sweeps(Dt.p, Et.p, l2_next, Dn.p, En.p, Pf ? Ep.p : nullptr);
     std::swap(Dt.p, Dn.p);
     std::swap(Et.p, En.p);
   }

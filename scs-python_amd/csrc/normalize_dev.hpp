@@ -199,14 +199,15 @@ __global__ __launch_bounds__(kVecThreads) void k_pass_finish(double *Dt, double 
   double *d = Dt + boff[blk], *a = D + boff[blk];
   double w = 0.;
   if (len <= 64) {
-    if (lane == 0) {
-      for (int j = 0; j < len; ++j) {
-        const double v = l2 ? sqrt(d[j]) : d[j];
-        w = l2 ? w + v : fmax(w, fabs(v));
-      }
-      if (l2) w /= (double)len;
+    // every lane fetches one entry, then the entries are added in index order (the oracle's order, as lane 0's loop over memory did in
+    // k_enforce_blocks — 50 dependent round trips for a 50-row cone, 15 us per launch: the longest link in the chain of a small scs_init)
+    double v = lane < len ? d[lane] : 0.;
+    if (l2) v = sqrt(v);
+    for (int j = 0; j < len; ++j) {
+      const double vj = __shfl(v, j, 64);
+      w = l2 ? w + vj : fmax(w, fabs(vj));
     }
-    w = __shfl(w, 0, 64);
+    if (l2) w /= (double)len;
   } else {
     for (int j = lane; j < len; j += 64) {
       const double v = l2 ? sqrt(d[j]) : d[j];

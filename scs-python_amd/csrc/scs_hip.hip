@@ -424,9 +424,19 @@ struct DeviceCsr {
     if (nnz > 0) hipLaunchKernelGGL(k_count_index, dim3(vec_blocks(nnz)), dim3(kVecThreads), 0, s, src.col.p, nnz, cursor.p);
     device_exclusive_scan(cursor.p, rowptr.p, rows, tmp.p, s);
     HIP_CHECK(hipMemcpyAsync(cursor.p, rowptr.p, sizeof(int) * rows, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_transpose_scatter, dim3(vec_blocks(src.rows)), dim3(kVecThreads), 0, s, src.rowptr.p, src.col.p, src.rows,
-                       cursor.p, col.p, perm.p);
-    hipLaunchKernelGGL(k_sort_rows, dim3(vec_blocks(rows)), dim3(kVecThreads), 0, s, rowptr.p, col.p, perm.p, rows, flag.p);
+    // small matrices: a wavefront per row (setup_dev.hpp; the same result, a shorter link in the dispatch chain of a small scs_init)
+    const bool per_wave = std::max(rows, src.rows) <= kTransposeWaveRows;
+    if (per_wave) {
+      const int wpb = kVecThreads / 64;
+      hipLaunchKernelGGL(k_transpose_scatter_w, dim3(std::max(1, std::min(ceil_div(src.rows, wpb), kMaxVecBlocks))), dim3(kVecThreads), 0, s, src.rowptr.p,
+                         src.col.p, src.rows, cursor.p, col.p, perm.p);
+      hipLaunchKernelGGL(k_sort_rows_w, dim3(std::max(1, std::min(ceil_div(rows, wpb), kMaxVecBlocks))), dim3(kVecThreads), 0, s, rowptr.p, col.p, perm.p, rows,
+                         flag.p);
+    } else {
+      hipLaunchKernelGGL(k_transpose_scatter, dim3(vec_blocks(src.rows)), dim3(kVecThreads), 0, s, src.rowptr.p, src.col.p, src.rows,
+                         cursor.p, col.p, perm.p);
+      hipLaunchKernelGGL(k_sort_rows, dim3(vec_blocks(rows)), dim3(kVecThreads), 0, s, rowptr.p, col.p, perm.p, rows, flag.p);
+    }
     if (nnz > 0) hipLaunchKernelGGL(k_gather_f64, dim3(vec_blocks(nnz)), dim3(kVecThreads), 0, s, val.p, src.val.p, perm.p, nnz);
     int too_long = 0;
     std::vector<int> rp((size_t)rows + 1);

@@ -20,6 +20,7 @@ constexpr int kScanThreads = 1024;
 constexpr int kScanPerThread = 4;
 constexpr int kScanTile = kScanThreads * kScanPerThread;
 constexpr int kSortMaxLen = 512;  // rows longer than this send the matrix down the host path
+constexpr int kTransposeWaveRows = 32768;  // up to this many rows / columns: one wavefront per row in the transposition kernels
 
 // ---- exclusive scan of int arrays (three launches; tile sums scanned by one workgroup: n <= 4096^2) ----
 __device__ __forceinline__ int block_excl_scan(int v, int *sm, int &total) {  // kScanThreads lanes, result per lane
@@ -121,6 +122,56 @@ __global__ __launch_bounds__(kVecThreads) void k_sort_rows(const int *__restrict
       }
       col[k + 1] = c;
       src[k + 1] = s;
+    }
+  }
+}
+// Small matrices (round 5, late: the transposition of a config-5 member was two launches of ~100 and ~140 us — 40 dependent atomics per lane,
+// an insertion sort in global memory per lane — in a chain of dependent dispatches whose length is what a batch's scs_init costs): ONE WAVEFRONT
+// per source row / result row.  The result is the same: the scatter's order inside a row is arbitrary either way and the sort's order is
+// total ((column, source index) is unique).
+__global__ __launch_bounds__(kVecThreads) void k_transpose_scatter_w(const int *__restrict__ sptr, const int *__restrict__ sidx, int srows,
+                                                                     int *cursor, int *out_col, int *out_src) {
+  const int lane = threadIdx.x & 63;
+  for (long j = (long)blockIdx.x * (kVecThreads / 64) + (threadIdx.x >> 6); j < srows; j += (long)gridDim.x * (kVecThreads / 64))
+    for (int p = sptr[j] + lane; p < sptr[j + 1]; p += 64) {
+      const int q = atomicAdd(&cursor[sidx[p]], 1);
+      out_col[q] = (int)j;
+      out_src[q] = p;
+    }
+}
+// rank sort: lane i of the row's wavefront holds entry i and counts the entries that sort in front of it (rows up to 64 entries; longer
+// ones: lane 0's insertion sort, as k_sort_rows)
+__global__ __launch_bounds__(kVecThreads) void k_sort_rows_w(const int *__restrict__ rowptr, int *col, int *src, int rows, int *too_long) {
+  const int lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * (kVecThreads / 64) + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * (kVecThreads / 64)) {
+    const int a = rowptr[r], e = rowptr[r + 1], len = e - a;
+    if (len > kSortMaxLen) {
+      if (lane == 0) atomicExch(too_long, 1);
+      continue;
+    }
+    if (len <= 64) {
+      const int c = lane < len ? col[a + lane] : 0x7fffffff, sv = lane < len ? src[a + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int k = 0; k < len; ++k) {
+        const int ck = __shfl(c, k, 64), sk = __shfl(sv, k, 64);
+        rank += (ck < c || (ck == c && sk < sv)) ? 1 : 0;
+      }
+      if (lane < len) {
+        col[a + rank] = c;
+        src[a + rank] = sv;
+      }
+    } else if (lane == 0) {
+      for (int i = a + 1; i < e; ++i) {
+        const int c = col[i], sv = src[i];
+        int k = i - 1;
+        while (k >= a && (col[k] > c || (col[k] == c && src[k] > sv))) {
+          col[k + 1] = col[k];
+          src[k + 1] = src[k];
+          --k;
+        }
+        col[k + 1] = c;
+        src[k + 1] = sv;
+      }
     }
   }
 }

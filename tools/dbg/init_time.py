@@ -20,4 +20,5 @@ for i, d in enumerate(datas):
     el = time.perf_counter() - t
     keep.append(s)
     print("init %d: %.2f ms" % (i, el * 1e3), flush=True)
-t = time.perf_counter(); r = keep[0].solve(); print("first solve (incl. lazy dense setup): %.2f ms, %d iterations" % ((time.perf_counter() - t) * 1e3, r["info"]["iter"]))
+if not os.environ.get("INIT_ONLY"):
+    t = time.perf_counter(); r = keep[0].solve(); print("first solve (incl. lazy dense setup): %.2f ms, %d iterations" % ((time.perf_counter() - t) * 1e3, r["info"]["iter"]))

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/inittrace; mkdir -p $O
-timeout 200 rocprofv3 --kernel-trace --memory-copy-trace -d $O/trace -o run -- python3 tools/dbg/init_time.py ${1:-dense} 6 > $O/log.txt 2>&1
+INIT_ONLY=1 timeout 200 rocprofv3 --kernel-trace --memory-copy-trace -d $O/trace -o run -- python3 tools/dbg/init_time.py ${1:-dense} 6 > $O/log.txt 2>&1
 grep "init " $O/log.txt | tail -3
 python3 - <<'PY'
 import sqlite3, glob, re, collections
@@ -28,7 +28,7 @@ print("one scs_init: %d GPU operations, first start to last end %.1f us, busy %.
 agg = collections.OrderedDict()
 for s, e, n in w:
     a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
-for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print("  %-46s x%3d  %8.1f us" % (n, c, d))
 PY
 find $O -name "*.db" -delete

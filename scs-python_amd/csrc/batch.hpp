@@ -651,6 +651,7 @@ struct GroupSolve {
     go(t_copy_g, ld, cnt);
     go(t_gg, ld, cnt);
     go(t_fin_gg, ld, cnt);
+    if (first_setup) return;
     for (int g : su) W[(size_t)g]->aa.reset();
     go(t_v_rescale, ld, cnt);
     for (int g : su) W[(size_t)g]->v_norm_fresh = false;
@@ -659,7 +660,7 @@ struct GroupSolve {
   // ---- the lock-step loop ----
   void run(int warm_start) {
     t_start = now_ms();
-    if (dense) {  // members fresh from scs_init: R, G^{-1} and g for all of them in one batched sweep
+    {  // members fresh from scs_init: R, G^{-1} (dense) or the preconditioner (indirect) and g for all of them in one grouped pass
       std::vector<int> pend;
       for (int g = 0; g < G; ++g)
         if (W[(size_t)g]->setup_pending) pend.push_back(g);

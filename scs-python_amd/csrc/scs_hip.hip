@@ -2593,8 +2593,13 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   }
   w->decide_k1dot(s);
   {
-    const char *el = getenv("SCS_HIP_DENSE_LAZY");
-    w->setup_pending = w->dense() && !(el && el[0] == '0');
+    // Round 5, late: the indirect path defers it too (SCS_HIP_LAZY_SETUP=0: inside scs_init) — its cold PCG for g is ~50 steps = 150 dependent
+    // launches, three quarters of the dispatch chain of a small problem's scs_init; a batch runs it as ONE grouped cold solve (batch.hpp
+    // apply_scale_updates, the path of an adaptive-scale update: bit-identical to the solo one), a lone workspace at its first solve.
+    const char *el = getenv("SCS_HIP_DENSE_LAZY"), *ea = getenv("SCS_HIP_LAZY_SETUP");
+    // (small problems only, n + m <= 32768: there the chain is what scs_init costs; a large problem keeps its cold solve out of scs_solve)
+    const bool small_indirect = !w->dense() && (long)n + m <= 32768;
+    w->setup_pending = w->dense() ? !(el && el[0] == '0') && !(ea && ea[0] == '0') : small_indirect && !(ea && ea[0] == '0');
   }
   if (!w->setup_pending) {
     w->set_diag_r();
@@ -3037,7 +3042,7 @@ scs_int scs_update(ScsWork *w, scs_float *b, scs_float *c) {
       w->Einv.upload(ei.data(), n, w->stream);
     }
     HIP_CHECK(hipStreamSynchronize(w->stream));
-    if (w->setup_pending) w->finish_pending_setup();  // (dense workspace that has not solved yet: R, G^{-1} and g in one go)
+    if (w->setup_pending) w->finish_pending_setup();  // (a workspace that has not solved yet: R, the preconditioner or G^{-1}, and g in one go)
     else w->update_work_cache();
     HIP_CHECK(hipStreamSynchronize(w->stream));
     return 0;
@@ -3113,6 +3118,7 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     HIP_CHECK(hipSetDevice(w->device));
     hipStream_t s = w->stream;
     const int n = w->n;
+    w->finish_pending_setup();  // (R lives in the products)
     // the two products exactly as the CG step of this workspace launches them (k1dot: cg_k1dot.hpp)
     for (int i = 0; i < 2; ++i) { if (w->k1dot) w->matvec_k1dot(w->cg_p.p, nullptr, nullptr); else w->matvec(w->cg_p.p, nullptr); }
     HIP_CHECK(hipEventRecord(w->ev[0], s));

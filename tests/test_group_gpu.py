@@ -149,6 +149,30 @@ def test_group_argument_checks():
     assert one[0]["info"]["status"] == "solved"
 
 
+def test_deferred_first_setup_bit_identical(monkeypatch):
+    """round 5: a small problem's first R / preconditioner / cold PCG for g = KKT^-1 h happen at its first solve instead of inside scs_init —
+    alone (ScsHipWork::finish_pending_setup) or, for the members of a batch, as ONE grouped pass (batch.hpp apply_scale_updates, first_setup).
+    Same launches in the same order on the same data: with the switch off (SCS_HIP_LAZY_SETUP=0: everything inside scs_init) every result
+    keeps its bits — solo and grouped, a QP included, and through update() + a warm second solve"""
+    import scs
+    K = {"z": 4, "l": 200, "q": [12] * 5, "s": [6] * 3, "ep": 2}
+    probs = _small_batch(5, K, 90, 9, 4700) + _small_batch(3, K, 90, 9, 4800, qp=True)   # (two groups: the QPs carry P)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_HIP_LAZY_SETUP", mode)
+        solo, grp, _ = _solo_and_group(probs, dict(verbose=False, linear_solver="hip_indirect"))
+        sv = scs.SCS(*probs[0], verbose=False, linear_solver="hip_indirect")
+        sv.update(b=probs[0][0]["b"] * 1.02)   # (update() before any solve: the deferred setup runs there)
+        first = sv.solve(warm_start=False)
+        again = sv.solve()
+        out[mode] = (solo, grp, first, again)
+    for a, b in zip(out["0"][0] + out["0"][1] + [out["0"][2], out["0"][3]], out["1"][0] + out["1"][1] + [out["1"][2], out["1"][3]]):
+        assert a["info"]["status"] == "solved"
+        _assert_same(a, b, "deferred first setup")
+    for a, b in zip(out["1"][0], out["1"][1]):
+        _assert_same(a, b, "solo vs grouped, deferred")
+
+
 def test_config5_workload_matches_oracle_ldl():
     """BASELINE.json configs[4]: the exact per-problem workload of the 512-problem batch (seeds 1000..1007), grouped
     on the GPU, against the oracle's sparse-LDL' direct solve: p*, x, y, s at rtol 1e-4 (north_star's bar)."""

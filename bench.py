@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the lines of BASELINE configs 2-4")
     ap.add_argument("--batch-problems", type=int, default=512)
     ap.add_argument("--batch-threads", type=int, default=0,
-                    help="workspaces set up concurrently (scs_init) per rank; 0 = max(2, CPU quota of the box / ranks)")
+                    help="workspaces set up concurrently (scs_init) per rank; 0 = max(1, CPU quota of the box // ranks)")
     ap.add_argument("--batch-one-linsys", action="store_true", help="config-5 leg: only the --batch-linsys solver, not both")
     ap.add_argument("--batch-linsys", default="hip_dense", choices=["hip_dense", "hip_indirect"],
                     help="linear solver of the config-5 members: dense direct (explicit inverse of the reduced KKT matrix, n = 1350) or the indirect PCG path")
@@ -235,7 +235,10 @@ def main():
         """one bench line: exactly `steps` ADMM iterations of `workload` from a cold start, timed as the contract says"""
         K, n, k, seed = pg.workload(workload)
         t0 = time.perf_counter()
-        data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, proj, pattern=pg.workload_pattern(workload))
+        if pg.workload_qp(workload):  # K3: a random PSD-by-construction P rides along (R:scs/py/__init__.py:163-166 hands over triu(P))
+            data, p_star, _ = pg.gen_feasible_qp(K, n, k, seed + rank, proj, b_per_col=pg.workload_qp(workload))
+        else:
+            data, p_star, _ = pg.gen_feasible(K, n, k, seed + rank, proj, pattern=pg.workload_pattern(workload))
         m = data["A"].shape[0]
         nnz = int(data["A"].nnz)
         t_gen = time.perf_counter() - t0
@@ -365,6 +368,21 @@ def main():
             "k2": {"bytes": int(b2), "avg_ms": round(k2_avg, 5), "GBps": round(gb2, 1), "frac": round(gb2 / HBM_PEAK, 4),
                    "in_situ_event_ms": round(k2_situ, 5)},
         }
+        if "P" in data:
+            # K3 (QP path): Gp = P p.  Algorithmic bytes per SURVEY §2.1 K3 — the caller hands over triu(P) and "each stored entry
+            # contributes twice": 12 B per STORED entry + row pointers + p in + Gp out.  The kernel streams the full symmetric CSR
+            # (csrc/scs_hip.hip Pf: 2 nnz - n entries) — an atomics-free, order-fixed product needs every value in row order of both
+            # triangles (profiles/r06_k3.txt), so `frac` against the algorithmic bytes is about half of `frac_streamed`.
+            nnz_pu = int(data["P"].nnz)
+            nnz_pf = 2 * nnz_pu - n
+            b3 = 12 * nnz_pu + 4 * (n + 1) + 8 * n + 8 * n
+            b3s = 12 * nnz_pf + 4 * (n + 1) + 8 * n + 8 * n
+            k3_avg = kb["k3_ms"]
+            gb3 = b3 / (k3_avg * 1e-3) / 1e9 if k3_avg > 0 else 0.0
+            roofline["k3"] = {"kernel": "K3 %s<EpiStore> (Gp = P p) on the full symmetric CSR of P" % kname, "nnz_triu_P": nnz_pu,
+                              "bytes": int(b3), "avg_ms": round(k3_avg, 5), "GBps": round(gb3, 1), "frac": round(gb3 / HBM_PEAK, 4),
+                              "streamed_bytes": int(b3s), "frac_streamed": round(b3s / (k3_avg * 1e-3) / 1e9 / HBM_PEAK, 4) if k3_avg > 0 else 0.0,
+                              "launches_per_cg_step": "K1 + K3 + K2 (K2's epilogue adds P p)"}
         if psd_t is not None:
             # PSD-heavy workloads: the batched eigen-solve (K9) is the dominant kernel and the matrix cores bound it.
             # achieved = reference flop count of a LAPACK-style symmetric eigensolve + reconstruction of the same matrices
@@ -429,14 +447,15 @@ def main():
         dims = [(nb_, mb)] * NB
         # setup threads of this rank: the ranks of a node share the box's CPU quota (bench boxes: 16 CPUs under a cgroup, bench.py
         # cpu_quota) — 8 ranks x 16 setup threads + 8 host loops would fight over them
-        bthreads = args.batch_threads if args.batch_threads > 0 else max(2, cpu_quota() // max(world, 1))
+        bthreads = args.batch_threads if args.batch_threads > 0 else max(1, cpu_quota() // max(world, 1))
 
         def run_batch(ls_name):
             """one sharded batch solve with the members' linear solver `ls_name`; returns the leg's record on rank 0"""
             batch_ls = scs.LinearSolver(ls_name)
             problems = [(datas[i], Kb, dict(verbose=False, linear_solver=batch_ls)) if i in mine else None for i in range(NB)]
             # warm the kernels of this shape once (code objects, allocator)
-            scs.SCS(problems[min(mine)][0], Kb, verbose=False, max_iters=50, linear_solver=batch_ls).solve()
+            if mine:
+                scs.SCS(problems[min(mine)][0], Kb, verbose=False, max_iters=50, linear_solver=batch_ls).solve()
             timing = {}
             barrier()
             tb = time.perf_counter()
@@ -453,7 +472,7 @@ def main():
             iters_sorted = sorted(r["info"]["iter"] for r in res)
             # every problem rank 0 generated (all of them at N = 1) against the optimum its generator constructed: |pobj - p*| / max(1, |p*|)
             # (default settings stop at 1e-4 on the residuals; the objective is then ~1e-3 off — tests/test_group_gpu.py pins x, y, s at 1e-10)
-            obj_err = max(abs(res[i]["info"]["pobj"] - pstars[i]) / max(1.0, abs(pstars[i])) for i in mine)
+            obj_err = max([abs(res[i]["info"]["pobj"] - pstars[i]) / max(1.0, abs(pstars[i])) for i in mine] or [0.0])
             return {"value": round(its / tb_max, 1), "objective_max_rel_err_vs_constructed_optimum": float("%.2e" % obj_err),
                     "objective_checked": len(mine), "problems_per_s": round(NB / tb_max, 2), "solved": int(ok), "total_iters": int(its),
                     "wall_s": round(tb_max, 3), "iterations_min_median_max": [iters_sorted[0], iters_sorted[len(iters_sorted) // 2], iters_sorted[-1]],
@@ -475,16 +494,23 @@ def main():
                 "problems": NB, "gen_s_rank0": round(tgen, 2), "n_gpus": world, "setup_threads_per_rank": bthreads,
             }
             batch_leg.update(first)
+            batch_leg["value_is"] = ("members solved with LinearSolver.%s" % args.batch_linsys.upper() +
+                                     (" — the dense DIRECT solver (SURVEY §8 f4), not north_star's indirect path: that figure is "
+                                      "`value_north_star_path`" if args.batch_linsys == "hip_dense" else " — north_star's indirect PCG path"))
+            if args.batch_linsys == "hip_indirect":
+                batch_leg["value_north_star_path"] = first["value"]
             if second is not None:
                 batch_leg["value_" + other_ls] = second["value"]
                 batch_leg["other_linear_solver"] = second
+                if other_ls == "hip_indirect":
+                    batch_leg["value_north_star_path"] = second["value"]   # the indirect PCG path (csrc/batch.hpp grouped PCG)
 
     # ---------------- other BASELINE configs: one line each (N = 1) ----------------
     other = None
     if world == 1 and not args.no_other_configs:
         other = []
-        for wl, st, wu in (("config2_lp_soc", 100, 10), ("config3_mixed", 20, 3), ("config4_psd", 100, 5), ("powerlaw_lp", 20, 2),
-                           ("banded_lp", 20, 2)):
+        for wl, st, wu in (("config2_lp_soc", 100, 10), ("config3_mixed", 20, 3), ("config4_psd", 100, 5), ("target_qp", 20, 2),
+                           ("powerlaw_lp", 20, 2), ("banded_lp", 20, 2)):
             if wl == args.workload or (os.environ.get("BENCH_OTHER") and wl not in os.environ["BENCH_OTHER"].split(",")):
                 continue
             # config 4: the first 100 iterations run with the residual-tied PSD sweep level, later ones do not — the
@@ -544,6 +570,10 @@ def main():
                     "(1/(1000 scale) vs 1/scale), the reduced system's condition number is ~1e3 and Jacobi-preconditioned CG needs "
                     "~330 steps per solve; with the same rows declared `l` it needs 13 (profiles/r03_config3_cg_study.txt)")
             del d4, K4
+            if wl == "target_qp":
+                line["config"]["why_this_line"] = (
+                    "not a BASELINE config: the metric workload's A with a quadratic objective, P = I + B'B (PSD by construction, "
+                    "nnz(triu P) ~ 8.5e6) — the QP path: one more product per CG step (K3), roofline.k3 (VERDICT r05 item 4)")
             if wl == "powerlaw_lp":
                 line["config"]["why_this_line"] = (
                     "not a BASELINE config: the metric workload's size with Pareto(1.3) row lengths (up to 20 000 nonzeros per row) — "

@@ -59,6 +59,10 @@ int scs_hip_device_count(void);
  * may drive several GPUs. */
 int scs_hip_set_device(int dev);
 int scs_hip_set_thread_device(int dev);
+/* free and total HBM bytes of the device subsequent scs_init calls would use, plus the bytes this library's block pool holds for
+ * reuse (they count as free for a new workspace).  What the Python layer's `LinearSolver.AUTO` asks before it picks the dense direct
+ * solver (R:scs/py/__init__.py:45-54 resolves AUTO to the best DIRECT backend that is usable).  0 on success, -1 without a device. */
+int scs_hip_mem_info(size_t *free_bytes, size_t *total_bytes);
 
 /* y (+)= A x or A' x through the hot-path SpMV kernels (row a3; plays the role
  * of scs_source/linsys/scs_matrix.c accum_by_a / accum_by_atrans, R:meson.build:199-202).
@@ -148,9 +152,9 @@ scs_int scs_hip_solve_batch(ScsWork **w, ScsSolution **sol, ScsInfo **info, scs_
  * recorded (out[0] < 0: the solve ended before that iteration); iter < 0 switches it off. */
 void scs_hip_set_mark(ScsWork *w, int iter);
 void scs_hip_get_mark(const ScsWork *w, double *out);
-/* `reps` back-to-back launches of K1 and then of K2 on the solver's own stream and HBM-resident
+/* `reps` back-to-back launches of K1, then of K2 and — problems with P — of K3 on the solver's own stream and HBM-resident
  * data, one HIP event pair per batch (the ~10-20 us per-event overhead is amortised).
- * out[2] = {K1 avg ms, K2 avg ms}.  Returns 0 on success. */
+ * out[3] = {K1 avg ms, K2 avg ms, K3 avg ms (0 without P)}.  Returns 0 on success. */
 int scs_hip_time_matvec(ScsWork *w, int reps, double *out);
 
 /* Anderson acceleration as a standalone object on host vectors (row a6): the interface of scs_source/src/aa.c

@@ -107,6 +107,8 @@ def workload(name):
         return {"l": 1000000, "q": [10] * 100000}, 1000000, 20, 5
     if name == "target_lp":
         return {"l": 2000000}, 1000000, 20, 5
+    if name == "target_qp":       # the metric workload with a quadratic objective: P = I + B'B, nnz(triu P) ~ 1e7 (K3)
+        return {"l": 1000000, "q": [10] * 100000}, 1000000, 20, 6
     if name == "powerlaw_lp":     # layout robustness: metric size, heavy-tailed row lengths (pattern: workload_pattern)
         return {"l": 2000000}, 1000000, 20, 11
     if name == "banded_lp":       # layout robustness: metric size, banded
@@ -130,7 +132,12 @@ def workload_pattern(name):
     return {"powerlaw_lp": "powerlaw", "banded_lp": "banded"}.get(name, "uniform")
 
 
-def gen_feasible_qp(K, n, nnz_per_col, seed, proj_dual, p_diag=1.0):
+def workload_qp(name):
+    """None, or gen_feasible_qp's `b_per_col` for the named QP workload (rows of B = n / 4: nnz(triu P) ~ (2 b_per_col^2 + 0.5) n)"""
+    return {"target_qp": 2}.get(name)
+
+
+def gen_feasible_qp(K, n, nnz_per_col, seed, proj_dual, p_diag=1.0, b_per_col=3):
     """Strictly convex QP over the cone K: P = p_diag*I + B'B (sparse, PD) makes x — hence s — unique,
     and with n >= #active rows the dual y is unique too, so x, y, s can all be compared entry-wise.
     Returns (data with P upper-triangular CSC, p_star, (x, y, s))."""
@@ -140,7 +147,7 @@ def gen_feasible_qp(K, n, nnz_per_col, seed, proj_dual, p_diag=1.0):
     y = np.asarray(proj_dual(z, K), dtype=np.float64)
     s = y - z
     A = random_sparse(m, n, nnz_per_col, rng)
-    B = random_sparse(max(n // 4, 1), n, 3, rng)
+    B = random_sparse(max(n // 4, 1), n, b_per_col, rng)
     P = (B.T @ B + p_diag * sparse.eye(n)).tocsc()
     P.sort_indices()
     x = rng.standard_normal(n)

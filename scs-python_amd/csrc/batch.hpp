@@ -132,6 +132,7 @@ struct GroupSolve {
   long l = 0;
   hipStream_t s = nullptr;
   bool has_P = false;
+  std::vector<char> mr_allowed_saved;
 
   // tables (one per kernel of the path; names follow the kernels)
   SCS_GTABLE(kVecThreads, d_sumsq) t_sumsq;
@@ -659,21 +660,42 @@ struct GroupSolve {
 
   // ---- the lock-step loop ----
   void run(int warm_start) {
-    t_start = now_ms();
     {  // members fresh from scs_init: R, G^{-1} (dense) or the preconditioner (indirect) and g for all of them in one grouped pass
       std::vector<int> pend;
-      for (int g = 0; g < G; ++g)
+      for (int g = 0; g < G; ++g) {
+        if (W[(size_t)g]->setup_failed) throw std::runtime_error(W[(size_t)g]->setup_failed_msg(g));
         if (W[(size_t)g]->setup_pending) pend.push_back(g);
+      }
       if (!pend.empty()) {
         const double t0 = now_ms();
         apply_scale_updates(pend, /*first_setup=*/true);
+        std::vector<double> gg(pend.size(), 0.);
+        if (dense)  //  the unpivoted Gauss-Jordan sweep checks nothing on the way: g' R g of every member must be finite,
+                    // exactly as ScsHipWork::finish_pending_setup asks of a member that finishes its setup alone
+          for (size_t k = 0; k < pend.size(); ++k)
+            HIP_CHECK(hipMemcpyAsync(&gg[k], W[(size_t)pend[k]]->sc.p + S_GG, sizeof(double), hipMemcpyDeviceToHost, s));
         sync();
         const double each = (now_ms() - t0) / (double)pend.size();
-        for (int g : pend) { W[(size_t)g]->setup_pending = false; W[(size_t)g]->setup_time += each; }
+        int bad = -1;
+        for (size_t k = 0; k < pend.size(); ++k) {
+          ScsHipWork *w = W[(size_t)pend[k]];
+          w->setup_time += each;  // (the deferred part of scs_init: counted as setup, not as solve time)
+          if (dense && !std::isfinite(gg[k])) {
+            w->setup_failed = true;  // stays pending + failed: any later solve of this workspace reports the same error
+            if (bad < 0) bad = pend[k];
+          } else {
+            w->setup_pending = false;
+          }
+        }
+        if (bad >= 0) throw std::runtime_error(W[(size_t)bad]->setup_failed_msg(bad));
       }
     }
+    t_start = now_ms();  // behind the deferred setup: solve_time is the solve (ScsInfo as the reference fills it)
+    mr_allowed_saved.assign((size_t)G, 0);
     for (int g = 0; g < G; ++g) {
+      mr_allowed_saved[(size_t)g] = W[(size_t)g]->mr_allowed ? 1 : 0;
       W[(size_t)g]->mr_allowed = false;  // the grouped loop drives PCG steps through its own tables (minres.hpp: one workspace at a time)
+      W[(size_t)g]->mr_active = false;   // (a member that had switched to MINRES in a solve of its own runs PCG here, and may switch again later)
       W[(size_t)g]->begin_solve(sols[(size_t)g], infos[(size_t)g], warm_start);
     }
     for (int g = 0; g < G; ++g) {
@@ -916,6 +938,11 @@ struct GroupSolve {
       }
     }
     HIP_CHECK(hipStreamSynchronize(s));
+    for (int g = 0; g < G; ++g) {  //  what the group took from its members' Krylov state goes back
+      ScsHipWork *w = W[(size_t)g];
+      w->mr_allowed = mr_allowed_saved[(size_t)g] != 0;
+      if (w->mr_ready) w->mr_precond_stale = true;  // scale updates inside the group went through t_set_diag_r / t_precond only
+    }
     if (getenv("SCS_HIP_GROUP_STATS"))
       std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %.1f ms (%.1f ms of it finishing members: un-scaling, s'y, downloads)\n",
                    G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, now_ms() - t_start, t_finish);

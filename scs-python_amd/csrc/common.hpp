@@ -84,6 +84,10 @@ struct DevPool {
     cached += bytes;
     return true;
   }
+  size_t held_bytes() {
+    std::lock_guard<std::mutex> lk(m);
+    return cached;
+  }
   void trim() {
     std::lock_guard<std::mutex> lk(m);
     for (auto &b : blocks) (void)hipFree(b.second);  // (blocks of other devices: hipFree takes any device's pointer)

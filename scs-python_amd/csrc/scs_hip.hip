@@ -1112,8 +1112,14 @@ struct ScsHipWork {
   // Dense workspaces finish their setup — R, G^{-1}, g = KKT^{-1} [c; -b] — at the first solve (or update) instead of inside scs_init:
   // a batch of them then forms and inverts all its matrices in ONE batched sweep (GroupSolve::run), 66 launches for the whole group
   // instead of 66 launch-bound ones per member (SCS_HIP_DENSE_LAZY=0: inside scs_init).
-  bool setup_pending = false;
+  bool setup_pending = false, setup_failed = false;
+  std::string setup_failed_msg(int member = -1) const {
+    return std::string("hip_dense: the inverse of the reduced KKT matrix is not finite") +
+           (member >= 0 ? " (member " + std::to_string(member) + " of the batch)" : "") +
+           " (a vanishing pivot block — column-rank-deficient A with a tiny rho_x?); use LinearSolver.HIP_INDIRECT for this problem";
+  }
   void finish_pending_setup() {
+    if (setup_failed) throw std::runtime_error(setup_failed_msg());  //  a failed setup stays failed: no solve on a non-finite inverse
     if (!setup_pending) return;
     const double t0 = now_ms();
     set_diag_r();
@@ -1127,9 +1133,10 @@ struct ScsHipWork {
       double gg = 0.;
       HIP_CHECK(hipMemcpyAsync(&gg, sc.p + S_GG, sizeof(double), hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
-      if (!std::isfinite(gg))
-        throw std::runtime_error("hip_dense: the inverse of the reduced KKT matrix is not finite (a vanishing pivot block — column-rank-deficient A "
-                                 "with a tiny rho_x?); use LinearSolver.HIP_INDIRECT for this problem");
+      if (!std::isfinite(gg)) {
+        setup_failed = true;
+        throw std::runtime_error(setup_failed_msg());
+      }
     }
   }
   void dense_refactor() {  // diag_r must be current on the stream
@@ -1314,7 +1321,9 @@ struct ScsHipWork {
     mr_ready = true;
   }
   // decided where an ADMM iteration's linear solve is enqueued (never inside one)
+  bool mr_precond_stale = false;  // a grouped solve changed the scale behind MINRES's back (batch.hpp): refreshed at the next decision
   void mr_decide() {
+    if (mr_ready && mr_precond_stale && mr_allowed) { mr_precond(); mr_precond_stale = false; }
     if (mr_active || !mr_allowed || cone.z <= 0 || dense() || persist_wgs > 0 || k1dot || in_capture) return;
     const int mode = krylov_mode();
     if (mode == 0) return;
@@ -1557,11 +1566,14 @@ struct ScsHipWork {
 
   // ---- run-ahead mode: one whole plain iteration (no convergence check, no AA, no logging) in the queue ----
   // head + CG chunk + tau/cones/v update + flag copy + event; nothing here waits for the device.
-  void enqueue_plain_iteration(int iter) {
+  // queue_empty: nothing of an earlier iteration is still in the queue.  Only then may the Krylov method change: a
+  // stalled iteration i is finished by run_cg(mode 2) with the method of the workspace, and a switch made while i + 1 was being
+  // enqueued would continue i's PCG recurrence with MINRES steps that never had their start.
+  void enqueue_plain_iteration(int iter, bool queue_empty) {
     const int slot = iter & 1;
     set_iter_params(iter, slot);
     ensure_v_norm();
-    mr_decide();
+    if (queue_empty) mr_decide();
     stall = fl.p + F_STALL;
     stall_fl = fl.p;
     enqueue_lin_sys_head();
@@ -2657,11 +2669,11 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   std::lock_guard<std::mutex> lock(w->mtx);
   InterruptListener ctrlc;
   HIP_CHECK(hipSetDevice(w->device));
-  const double t_start = now_ms();
   const int n = w->n, m = w->m;
   const long l = w->l;
   hipStream_t s = w->stream;
-  w->finish_pending_setup();
+  w->finish_pending_setup();  // the deferred end of scs_init: counted in setup_time, so the clock of the solve starts behind it
+  const double t_start = now_ms();
   w->begin_solve(sol, info, warm_start);
   double t_lin = 0, t_cone = 0, t_acc = 0;
   FILE *csv = nullptr;
@@ -2729,8 +2741,8 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
     }
     if (run_ahead && (enq_upto >= i || is_plain(i))) {  // (already queued: is_plain may have changed its mind since)
       double t = now_ms();
-      if (enq_upto < i) { w->enqueue_plain_iteration(i); enq_upto = i; }
-      if (is_plain(i + 1) && enq_upto < i + 1) { w->enqueue_plain_iteration(i + 1); enq_upto = i + 1; }
+      if (enq_upto < i) { w->enqueue_plain_iteration(i, true); enq_upto = i; }
+      if (is_plain(i + 1) && enq_upto < i + 1) { w->enqueue_plain_iteration(i + 1, false); enq_upto = i + 1; }
       if (!w->finish_plain_iteration(i)) {
         w->recover_stalled_iteration(i);
         enq_upto = i;  // whatever was queued behind the stall did nothing
@@ -3107,19 +3119,26 @@ int scs_hip_set_thread_device(int dev) {
   t_device = dev;
   return 0;
 }
+int scs_hip_mem_info(size_t *free_bytes, size_t *total_bytes) {
+  if (scs_hip_device_count() <= 0) return -1;
+  size_t f = 0, t = 0;
+  if (hipSetDevice(current_device()) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+  if (free_bytes) *free_bytes = f + DevPool::inst().held_bytes();
+  if (total_bytes) *total_bytes = t;
+  return 0;
+}
 const char *scs_hip_last_error(void) { return g_last_error.c_str(); }
 
-/* reps back-to-back launches of K1 and of K2 on the solver's own stream and resident data, one HIP event
- * pair around each batch (event overhead amortised); out = {K1 avg ms, K2 avg ms} */
+/* reps back-to-back launches of K1, of K2 and (QPs) of K3 on the solver's own stream and resident data, one HIP event
+ * pair around each batch (event overhead amortised); out = {K1 avg ms, K2 avg ms, K3 avg ms (0 without P)} */
 int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
   if (!w || !out || reps <= 0) return -1;
   try {
     std::lock_guard<std::mutex> lock(w->mtx);
     HIP_CHECK(hipSetDevice(w->device));
     hipStream_t s = w->stream;
-    const int n = w->n;
     w->finish_pending_setup();  // (R lives in the products)
-    // the two products exactly as the CG step of this workspace launches them (k1dot: cg_k1dot.hpp)
+    // the products exactly as the CG step of this workspace launches them (k1dot: cg_k1dot.hpp)
     for (int i = 0; i < 2; ++i) { if (w->k1dot) w->matvec_k1dot(w->cg_p.p, nullptr, nullptr); else w->matvec(w->cg_p.p, nullptr); }
     HIP_CHECK(hipEventRecord(w->ev[0], s));
     for (int i = 0; i < reps; ++i) {
@@ -3129,15 +3148,23 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     HIP_CHECK(hipEventRecord(w->ev[1], s));
     for (int i = 0; i < reps; ++i) {
       if (w->k1dot) launch_spmv(w->At.view(), w->tmp_m.p, EpiAtRaw{w->cg_Gp.p, w->gp2()}, nullptr, s);
-      else launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), 0, w->part.p, w->gp2()}, nullptr, s);
+      else launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), w->has_P ? 1 : 0, w->part.p, w->gp2()}, nullptr, s);
     }
     HIP_CHECK(hipEventRecord(w->ev[2], s));
     HIP_CHECK(hipEventSynchronize(w->ev[2]));
-    float a = 0, b = 0;
+    float a = 0, b = 0, c = 0;
     HIP_CHECK(hipEventElapsedTime(&a, w->ev[0], w->ev[1]));
     HIP_CHECK(hipEventElapsedTime(&b, w->ev[1], w->ev[2]));
+    if (w->has_P) {  // K3: Gp = P p (csrc/spmv*.hpp on the full symmetric CSR of P, epilogue EpiStore)
+      HIP_CHECK(hipEventRecord(w->ev[0], s));
+      for (int i = 0; i < reps; ++i) launch_spmv(w->Pf.view(), w->cg_p.p, EpiStore{w->cg_Gp.p, 0}, nullptr, s);
+      HIP_CHECK(hipEventRecord(w->ev[1], s));
+      HIP_CHECK(hipEventSynchronize(w->ev[1]));
+      HIP_CHECK(hipEventElapsedTime(&c, w->ev[0], w->ev[1]));
+    }
     out[0] = a / reps;
     out[1] = b / reps;
+    out[2] = c / reps;
     return 0;
   } catch (const std::exception &e) {
     set_last_error(e.what());
@@ -3451,31 +3478,58 @@ double scs_hip_spmv_bench(const ScsMatrix *A, int transpose, int reps) {
   }
 }
 
+// One-shot projections (tests, generators): a temporary workspace on the CURRENT device.  The multi-CU PSD sweep kernel may run here
+// (fl is allocated), so its error flag is read behind every synchronisation: a barrier that timed out — another process holds part
+// of the GPU — opened every barrier of the launch and left garbage; the call is then repeated from its inputs with one workgroup per
+// matrix, the path a solve takes after a SpinTimeout.
+static void oneshot_cone_work(ScsHipWork &w, const ScsCone *k, scs_int m, int warm, hipStream_t s, bool no_spin) {
+  if (!build_cone(k, w.cone) || w.cone.m != m) throw std::runtime_error("invalid cone");
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  w.device = dev;  // (spin_chain(), the occupancy query of psd_mc_members)
+  w.stream = s;
+  w.owns_stream = false;
+  w.m = m;
+  w.psd_warm = warm;
+  if (no_spin) w.psd_mc_cap = 0;
+  upload_cone_meta(&w);
+  w.fl.alloc_zero(F_COUNT, s);  // (k_psd_sweep_mc polls its error flag while it waits at a barrier)
+  w.sc.alloc_zero(S_COUNT, s);
+  const double one = 1.0;
+  HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, s));
+}
+static bool oneshot_spin_error(ScsHipWork &w, hipStream_t s) {  // the stream is idle
+  int err = 0;
+  HIP_CHECK(hipMemcpyAsync(&err, w.fl.p + F_PERSIST_ERR, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  return err != 0;
+}
+
 int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
   try {
     set_last_error("");
-    ScsHipWork w;
-    if (!build_cone(k, w.cone) || w.cone.m != m) throw std::runtime_error("invalid cone");
-    TmpStream ts;
-    w.stream = ts.s;
-    w.owns_stream = false;
-    w.m = m;
-    w.psd_warm = 0;
-    upload_cone_meta(&w);
-    w.fl.alloc_zero(F_COUNT, ts.s);  // (k_psd_sweep_mc polls its error flag while it waits at a barrier)
-    w.sc.alloc_zero(S_COUNT, ts.s);
-    const double one = 1.0;
-    HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, ts.s));
-    DevBuf<double> dx;
-    dx.upload(x, m, ts.s);
-    if (w.cone.z + w.cone.l > 0)
-      hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
-                         w.cone.z, w.cone.l, dual);
-    w.project_nonlinear_cones(dx.p, dual);
-    HIP_CHECK(hipGetLastError());
-    dx.download(x, m, ts.s);
-    HIP_CHECK(hipStreamSynchronize(ts.s));
-    return 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      ScsHipWork w;
+      TmpStream ts;
+      oneshot_cone_work(w, k, m, /*warm=*/0, ts.s, attempt > 0);
+      DevBuf<double> dx;
+      dx.upload(x, m, ts.s);
+      if (w.cone.z + w.cone.l > 0)
+        hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
+                           w.cone.z, w.cone.l, dual);
+      w.project_nonlinear_cones(dx.p, dual);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(ts.s));
+      if (oneshot_spin_error(w, ts.s)) {
+        if (attempt > 0) throw std::runtime_error("cone projection: a device-side barrier timed out");
+        g_spin_fallbacks.fetch_add(1);
+        continue;  // x is untouched: again, without the spinning kernel
+      }
+      dx.download(x, m, ts.s);
+      HIP_CHECK(hipStreamSynchronize(ts.s));
+      return 0;
+    }
+    return -1;
   } catch (const std::exception &e) {
     set_last_error(e.what());
     return -1;
@@ -3486,42 +3540,46 @@ int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, 
   try {
     set_last_error("");
     if (count < 0 || !xs) throw std::runtime_error("invalid sequence");
-    ScsHipWork w;
-    if (!build_cone(k, w.cone) || w.cone.m != m) throw std::runtime_error("invalid cone");
-    TmpStream ts;
-    w.stream = ts.s;
-    w.owns_stream = false;
-    w.m = m;
-    w.psd_warm = 1;  // as inside the ADMM loop: the eigenvectors (and every other cone's warm-start state) carry over
-    upload_cone_meta(&w);
-    w.fl.alloc_zero(F_COUNT, ts.s);  // (k_psd_sweep_mc polls its error flag while it waits at a barrier)
-    w.sc.alloc_zero(S_COUNT, ts.s);
-    const double one = 1.0;
-    HIP_CHECK(hipMemcpyAsync(w.sc.p + S_BOX_T, &one, sizeof(double), hipMemcpyHostToDevice, ts.s));
-    DevBuf<double> dx;
-    dx.alloc((size_t)std::max(m, 1));
-    for (int c = 0; c < count; ++c) {
-      HIP_CHECK(hipMemcpyAsync(dx.p, xs + (size_t)c * m, sizeof(double) * m, hipMemcpyHostToDevice, ts.s));
-      if (w.cone.z + w.cone.l > 0)
-        hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
-                           w.cone.z, w.cone.l, dual);
-      w.project_nonlinear_cones(dx.p, dual);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpyAsync(xs + (size_t)c * m, dx.p, sizeof(double) * m, hipMemcpyDeviceToHost, ts.s));
-      HIP_CHECK(hipStreamSynchronize(ts.s));
-    }
-    int nst = 0;
-    if (stats && stats_cap > 0) {
-      nst = std::min(stats_cap, w.n_psd_big);
-      for (int c = 0; c < nst; ++c) {
-        double st[kPsdStateDoubles];
-        const long at = w.psd_woff_h[(size_t)c] + psd_scratch_doubles(w.psd_order_h[(size_t)c]) - kPsdStateDoubles;
-        HIP_CHECK(hipMemcpy(st, w.psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
-        stats[8 * c + 0] = st[9]; stats[8 * c + 1] = st[10]; stats[8 * c + 2] = st[8]; stats[8 * c + 3] = st[11]; stats[8 * c + 4] = st[7];
-        stats[8 * c + 5] = st[12]; stats[8 * c + 6] = st[13]; stats[8 * c + 7] = st[14];
+    std::vector<double> out((size_t)count * (size_t)std::max(m, 0));  // the inputs stay intact until the whole sequence went through
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      ScsHipWork w;
+      TmpStream ts;
+      // warm = 1: as inside the ADMM loop, the eigenvectors (and every other cone's warm-start state) carry over from call to call
+      oneshot_cone_work(w, k, m, /*warm=*/1, ts.s, attempt > 0);
+      DevBuf<double> dx;
+      dx.alloc((size_t)std::max(m, 1));
+      bool spin_err = false;
+      for (int c = 0; c < count && !spin_err; ++c) {
+        HIP_CHECK(hipMemcpyAsync(dx.p, xs + (size_t)c * m, sizeof(double) * m, hipMemcpyHostToDevice, ts.s));
+        if (w.cone.z + w.cone.l > 0)
+          hipLaunchKernelGGL(k_proj_zl, dim3(ceil_div(w.cone.z + w.cone.l, kConeThreads)), dim3(kConeThreads), 0, ts.s, dx.p,
+                             w.cone.z, w.cone.l, dual);
+        w.project_nonlinear_cones(dx.p, dual);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out.data() + (size_t)c * m, dx.p, sizeof(double) * m, hipMemcpyDeviceToHost, ts.s));
+        HIP_CHECK(hipStreamSynchronize(ts.s));
+        spin_err = oneshot_spin_error(w, ts.s);
       }
+      if (spin_err) {  // the warm-start state behind the failed projection is garbage: the whole sequence again, without the spinning kernel
+        if (attempt > 0) throw std::runtime_error("cone projection: a device-side barrier timed out");
+        g_spin_fallbacks.fetch_add(1);
+        continue;
+      }
+      int nst = 0;
+      if (stats && stats_cap > 0) {
+        nst = std::min(stats_cap, w.n_psd_big);
+        for (int c = 0; c < nst; ++c) {
+          double st[kPsdStateDoubles];
+          const long at = w.psd_woff_h[(size_t)c] + psd_scratch_doubles(w.psd_order_h[(size_t)c]) - kPsdStateDoubles;
+          HIP_CHECK(hipMemcpy(st, w.psd_scratch.p + at, sizeof st, hipMemcpyDeviceToHost));
+          stats[8 * c + 0] = st[9]; stats[8 * c + 1] = st[10]; stats[8 * c + 2] = st[8]; stats[8 * c + 3] = st[11]; stats[8 * c + 4] = st[7];
+          stats[8 * c + 5] = st[12]; stats[8 * c + 6] = st[13]; stats[8 * c + 7] = st[14];
+        }
+      }
+      if (!out.empty()) std::memcpy(xs, out.data(), out.size() * sizeof(double));
+      return nst;
     }
-    return nst;
+    return -1;
   } catch (const std::exception &e) {
     set_last_error(e.what());
     return -1;

@@ -9,10 +9,13 @@ checks and their messages, CSC coercion with a warning, never mutating the
 caller's matrices, upper-triangular extraction of P, `linear_solver` popped
 before the backend sees the settings.
 
-What differs: the only backend module shipped here is `scs._scs_hip`
-(`LinearSolver.HIP_INDIRECT`), so `AUTO` resolves to it and the CPU/CUDA
-members raise ImportError exactly like an un-built optional backend of the
-reference does (R:test/test_solve_random_cone_prob.py:24-30).
+What differs: the backend modules shipped here are `scs._scs_hip`
+(`LinearSolver.HIP_INDIRECT`) and `scs._scs_hip_dense` (`LinearSolver.HIP_DENSE`);
+`AUTO` resolves — as the reference's does (R:scs/py/__init__.py:45-54: "the best
+available direct solver") — to the direct one when it can take the problem and to
+the indirect one otherwise (`_resolve_auto`); the CPU/CUDA members raise ImportError
+exactly like an un-built optional backend of the reference does
+(R:test/test_solve_random_cone_prob.py:24-30).
 """
 import enum
 import warnings
@@ -72,18 +75,51 @@ def _load_module(name):
   return import_module("scs." + name)
 
 
-def _resolve_auto():
-  """AUTO picks the best backend present in this build: the HIP one."""
+# AUTO's view of the dense direct solver (csrc/dense.hpp): the order it accepts, the share of the free HBM its inverse may take and
+# the work of forming G = R_x + P + A' R_y^-1 A (one product per pair of nonzeros of a row of A) it is worth paying at every
+# adaptive-scale update.  Measured crossover against the indirect path: DESIGN.md §4 "AUTO".
+_AUTO_DENSE_MAX_N = 8192
+_AUTO_DENSE_HBM_SHARE = 0.25
+_AUTO_DENSE_MAX_BUILD_PRODUCTS = 2e9
+
+
+def _dense_direct_fits(m, n, A):
+  """True when the device's direct solver can take an m x n problem with the CSC matrix A."""
+  if n > _AUTO_DENSE_MAX_N:
+    return False
+  info = _scs_hip.mem_info()
+  if info is None:  # no device: let the indirect module report it ("ScsWork allocation error! (no HIP device ...)")
+    return False
+  npad = -(-n // 64) * 64
+  if 8.0 * npad * npad > _AUTO_DENSE_HBM_SHARE * info[0]:
+    return False
+  if A is not None and A.nnz:
+    try:
+      row_len = np.bincount(A.indices, minlength=m).astype(np.float64)
+    except ValueError:  # negative row indices: the backend's own validation reports them
+      return False
+    if float(row_len @ row_len) > _AUTO_DENSE_MAX_BUILD_PRODUCTS:
+      return False
+  return True
+
+
+def _resolve_auto(m=None, n=None, A=None):
+  """AUTO = the best DIRECT solver that is usable, as in the reference (R:scs/py/__init__.py:45-54: MKL Pardiso, else the
+  bundled QDLDL).  Here: the dense direct solver of the device when the problem fits it (n <= 8192, the n x n inverse within a
+  quarter of the free HBM, G cheap to form), else the indirect solver — a sparse factorisation of the BASELINE patterns fills to
+  0.06 N^2 and does not exist on the device."""
+  if n is not None and _dense_direct_fits(m, n, A):
+    return _load_module("_scs_hip_dense")
   return _scs_hip
 
 
-def _select_scs_module(stgs):
+def _select_scs_module(stgs, m=None, n=None, A=None):
   """Pop `linear_solver` (enum member or its string value) and load that backend."""
   choice = stgs.pop("linear_solver", LinearSolver.AUTO)
   if isinstance(choice, str):
     choice = LinearSolver(choice)
   if choice is LinearSolver.AUTO:
-    return _resolve_auto()
+    return _resolve_auto(m, n, A)
   if choice is LinearSolver.HIP_INDIRECT:
     return _scs_hip
   return _load_module(_BACKEND_MODULES[choice])
@@ -154,7 +190,7 @@ class SCS(object):
         P = sparse.triu(P, format="csc")
       Px, Pi, Pp = P.data, P.indices, P.indptr
 
-    backend = _select_scs_module(self._settings)
+    backend = _select_scs_module(self._settings, m, n, A)
     self._solver = backend.SCS((m, n), A.data, A.indices, A.indptr, Px, Pi, Pp, b, c, cone,
                                **self._settings)
 

@@ -158,6 +158,8 @@ def _load():
     lib.scs_hip_device_count.restype = c_int
     lib.scs_hip_set_device.restype = c_int
     lib.scs_hip_set_device.argtypes = [c_int]
+    lib.scs_hip_mem_info.restype = c_int
+    lib.scs_hip_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.scs_hip_set_thread_device.restype = c_int
     lib.scs_hip_set_thread_device.argtypes = [c_int]
     lib.scs_hip_last_error.restype = C.c_char_p
@@ -232,6 +234,14 @@ def sizeof_float():
 
 def device_count():
     return int(_lib.scs_hip_device_count())
+
+
+def mem_info():
+    """(free, total) HBM bytes of the device the next SCS(...) would use (blocks this library caches count as free); None without a device"""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    if _lib.scs_hip_mem_info(C.byref(f), C.byref(t)) != 0:
+        return None
+    return int(f.value), int(t.value)
 
 
 def set_device(dev):
@@ -649,12 +659,12 @@ class SCS(object):
         return out[:8 * cnt].reshape(cnt, 8)
 
     def _time_matvec(self, reps=20):
-        out = np.zeros(2)
+        out = np.zeros(3)
         with self._lock:
             rc = _lib.scs_hip_time_matvec(self._work, int(reps), _pd(out))
         if rc != 0:
             raise RuntimeError("libscs_hip: " + last_error())
-        return {"k1_ms": float(out[0]), "k2_ms": float(out[1])}
+        return {"k1_ms": float(out[0]), "k2_ms": float(out[1]), "k3_ms": float(out[2])}
 
     def __del__(self):
         lock = getattr(self, "_lock", None)

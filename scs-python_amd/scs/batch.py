@@ -88,6 +88,10 @@ def _grouped_local_solve(local_problems, threads, timing=None):
     then ONE scs.solve_batch call.  Returns (solvers, results)."""
     import time
     import scs
+    if not local_problems:  # more ranks than problems: this rank only takes part in the gather
+        if timing is not None:
+            timing["init_s"] = timing["solve_s"] = 0.0
+        return [], []
     t0 = time.perf_counter()
 
     def make(p):

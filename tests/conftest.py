@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "scs-python_amd"), os.path.join(ROOT, "tests"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "auto_resolution: the test exercises LinearSolver.AUTO's own choice (direct when it fits)")
+    config.addinivalue_line("markers", "labs: exercises an opt-in experiment of the -DSCS_HIP_LABS build (not in the default -m gpu run)")
 
 
 def _have_gpu():
@@ -42,3 +44,15 @@ def _require_gpu():
 @pytest.fixture(scope="session")
 def gpu_available():
     return _have_gpu()
+
+
+@pytest.fixture(autouse=True)
+def _auto_selects_indirect(request, monkeypatch):
+    """Since round 6 `LinearSolver.AUTO` resolves like the reference's — to the DIRECT solver when the problem fits it
+    (scs/__init__.py `_resolve_auto`, R:scs/py/__init__.py:45-54).  The parity tests written before that exercise the INDIRECT
+    path (north_star's hot path) through calls that name no solver: for them AUTO is pinned to `scs._scs_hip` here, in one
+    place; tests marked `auto_resolution` (tests/test_auto_gpu.py) see the real policy."""
+    if request.node.get_closest_marker("auto_resolution"):
+        return
+    import scs
+    monkeypatch.setattr(scs, "_resolve_auto", lambda m=None, n=None, A=None: scs._scs_hip)

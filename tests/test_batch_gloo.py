@@ -1,6 +1,7 @@
-"""world_size-2 CPU test (gloo) of the N>1 path: problems sharded round-robin over ranks, no
+"""CPU tests (gloo) of the N>1 path at world size 2 and at the node's 8: problems sharded round-robin over ranks, no
 data-path collective, one gather to rank 0 (scs/batch.py).  The solver is injected (the oracle)
-because the product backend needs a GPU; the distributed logic under test is identical."""
+because the product backend needs a GPU; the distributed logic under test is identical.  The batches are ragged on purpose
+(different sizes; 11 problems over 8 ranks = shards of 2 and 1; 5 over 8 = three ranks with nothing but the gather)."""
 import os
 import socket
 import subprocess
@@ -8,6 +9,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,7 +25,8 @@ WORKER = textwrap.dedent('''
     rank, world = dist.get_rank(), dist.get_world_size()
     proj = lambda z, K: scs_oracle.proj_cone(z, K, dual=True)
     problems = []
-    for i in range(5):   # ragged on purpose: 5 problems over 2 ranks, different sizes
+    NPROB = int(os.environ["SCS_TEST_NPROB"])
+    for i in range(NPROB):   # ragged on purpose: different sizes, a count the world size does not divide
         K = {"l": 30 + 7 * i, "q": [4, 3 + i]}
         data, p_star, _ = pg.gen_feasible(K, 20 + 3 * i, 6, 100 + i, proj)
         problems.append((data, K, dict(eps_abs=1e-5, eps_rel=1e-5, verbose=False)))
@@ -32,7 +35,7 @@ WORKER = textwrap.dedent('''
         calls.append(len(data["c"]))
         return scs_oracle.solve(data, cone, indirect=True, **settings)
     res = batch.solve_sharded(problems, solve_fn=solve_fn)
-    assert len(calls) == len(batch.shard_indices(5, rank, world))
+    assert len(calls) == len(batch.shard_indices(NPROB, rank, world)) and calls == [len(problems[i][0]["c"]) for i in batch.shard_indices(NPROB, rank, world)]
     if rank == 0:
         ok = True
         for i, (data, K, st) in enumerate(problems):
@@ -57,16 +60,19 @@ def _free_port():
     return p
 
 
-def test_sharded_batch_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world,nprob", [(2, 5), (8, 11), (8, 5)])
+def test_sharded_batch_gloo(tmp_path, world, nprob):
+    """(8, 11): the shape of the driver's 8-GPU run in miniature — ragged shards of 2 and 1; (8, 5): ranks 5-7 own no problem and
+    still take part in the one gather (BASELINE config 5)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, OMP_NUM_THREADS="1", SCS_TEST_NPROB=str(nprob))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
-    assert line and '"ok": true' in line[0] and '"n": 5' in line[0], out.stdout[-2000:]
+    assert line and '"ok": true' in line[0] and '"n": %d' % nprob in line[0], out.stdout[-2000:]
 
 
 def test_shard_indices_cover_everything():

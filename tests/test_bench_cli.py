@@ -55,6 +55,31 @@ def test_gpus_2_spawns_two_ranks_on_one_gpu_box():
 
 
 @pytest.mark.gpu
+def test_gpus_8_dry_run_on_one_gpu_box():
+    """the plumbing of the driver's 8-GPU run, dry — 8 ranks (torch.distributed.run, gloo) on the ONE GPU of the
+    box: the line says n_gpus = world size = 8, every problem of the batch is solved exactly once across the ranks (24 = 3 per
+    rank), the gather happened, and a rank sets up CPU quota // 8 (>= 1) workspaces at a time (SURVEY 8e; BASELINE config 5)."""
+    cmd = [sys.executable, BENCH, "--gpus", "8", "--steps", "10", "--warmup", "1", "--workload", "small_lp_soc", "--no-steady",
+           "--dist-backend", "gloo", "--force-device", "0", "--batch-problems", "24", "--no-other-configs"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 8 and out["config"]["world_size_seen"] == 8 and out["config"]["backend"] == "gloo"
+    assert out["steps"] == 10 and out["scaling"] == "weak" and out["value"] > 0
+    assert abs(out["value"] - 8 * 10 / (out["ms_per_step"] * 10 * 1e-3)) < 1e-2 * out["value"]   # whole-job rate: 8 instances
+    assert out["config"]["gather_ms"] is not None and out["cpu_baseline"] is None
+    b = out["config5_batch"]
+    assert b["n_gpus"] == 8 and b["problems"] == 24 and b["solved"] == 24
+    assert len(b["iterations_min_median_max"]) == 3 and b["total_iters"] >= 24 * b["iterations_min_median_max"][0]
+    sys.path.insert(0, ROOT)
+    import bench
+    assert b["setup_threads_per_rank"] == max(1, bench.cpu_quota() // 8) >= 1
+    assert b["linear_solver"] == "hip_dense" and "value_north_star_path" in b and b["value_north_star_path"] == b["value_hip_indirect"]
+    assert "not north_star's indirect path" in b["value_is"]
+    assert b["other_linear_solver"]["solved"] == 24
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_has_every_leg():
     cmd = [sys.executable, BENCH, "--steps", "20", "--warmup", "2", "--workload", "config2_lp_soc", "--cpu-iters", "3",
            "--batch-problems", "8", "--batch-threads", "4", "--cpu-cap-s", "12", "--no-other-configs"]
@@ -77,6 +102,7 @@ def test_single_gpu_line_has_every_leg():
     assert mc["cores"] in [t for t, _ in mc["thread_sweep_iters_per_s"]]
     assert mc["value"] == max(v for _, v in mc["thread_sweep_iters_per_s"]) or abs(mc["value"] - max(v for _, v in mc["thread_sweep_iters_per_s"])) < 1e-2
     assert out["config5_batch"]["linear_solver"] == "hip_dense"
+    assert out["config5_batch"]["value_north_star_path"] == out["config5_batch"]["value_hip_indirect"] > 0   # the indirect PCG figure, labelled
     # every member's objective against the optimum its generator constructed (default settings: residuals at 1e-4, the objective ~1e-3)
     assert out["config5_batch"]["objective_checked"] == 8 and out["config5_batch"]["objective_max_rel_err_vs_constructed_optimum"] < 5e-3
     assert out["config5_batch"]["other_linear_solver"]["objective_max_rel_err_vs_constructed_optimum"] < 5e-3
@@ -97,10 +123,12 @@ def test_other_configs_lines_and_ungrouped_batch_leg():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     oc = out["other_configs"]
-    assert [o["config"]["workload"].split(":")[0] for o in oc] == ["config2_lp_soc", "config3_mixed", "config4_psd", "powerlaw_lp", "banded_lp"]
+    assert [o["config"]["workload"].split(":")[0] for o in oc] == ["config2_lp_soc", "config3_mixed", "config4_psd", "target_qp", "powerlaw_lp", "banded_lp"]
+    k3 = oc[3]["roofline"]["k3"]   # the QP path on the bench: K3 = P p, priced against the STORED (upper) entries
+    assert k3["avg_ms"] > 0 and 0 < k3["frac"] < k3["frac_streamed"] < 1 and k3["bytes"] < k3["streamed_bytes"] and k3["nnz_triu_P"] > 8e6
     assert "'bu': '99999 values'" in oc[1]["config"]["workload"] and "m=999999" in oc[1]["config"]["workload"]
     assert oc[2]["roofline"]["bound"] == "mfma" and oc[2]["roofline"]["frac"] > 0 and oc[0]["roofline"]["bound"] == "hbm"
     assert all(o["value"] > 0 and o["steps"] == o["config"]["admm_iters_timed"] for o in oc)
     assert oc[-1]["roofline"]["frac"] > oc[0]["roofline"]["frac"]  # gathers with locality: the ceiling of the decomposition
-    assert oc[3]["roofline"]["bound"] == "hbm" and "row lengths" in oc[3]["config"]["why_this_line"]  # power-law rows: the pass layout is kept
+    assert oc[4]["roofline"]["bound"] == "hbm" and "row lengths" in oc[4]["config"]["why_this_line"]  # power-law rows: the pass layout is kept
     assert out["config5_batch"]["solved"] == 6 and "one problem per stream" in out["config5_batch"]["workload"]

@@ -413,6 +413,32 @@ def test_determinism_bit_exact(hip):
     assert a["info"]["iter"] == b["info"]["iter"]
 
 
+@pytest.mark.parametrize("n", [400, 40000])
+def test_determinism_bit_exact_with_P(hip, oracle, n):
+    """the QP path (K3: Gp = P p on the full symmetric CSR of P, csrc/scs_hip.hip Pf) under the same rule
+    (R:test/test_scs_coverage.py:2283-2301): no float atomics, fixed summation order — two fresh instances give identical bits.
+    n = 40000: nnz(Pf) > 2^20, so K3 runs on the column-sorted pass layout the large-matrix kernels read; and the product P x of
+    the solver's layout is checked entry for entry against scipy through the kernel-level entry point."""
+    K = {"l": n, "q": [10] * (n // 10)}
+    data, p_star, _ = pg.gen_feasible_qp(K, n, 8, 17, lambda z, K: oracle.proj_cone(z, K, dual=True), b_per_col=4 if n > 1000 else 3)
+    args = helpers.raw_args(data, K)
+    stg = dict(verbose=False, max_iters=60 if n > 1000 else 2000)
+    a = hip.SCS(*args, **stg).solve(False, None, None, None)
+    b = hip.SCS(*args, **stg).solve(False, None, None, None)
+    for key in ("x", "y", "s"):
+        np.testing.assert_array_equal(a[key], b[key])
+    assert a["info"]["iter"] == b["info"]["iter"] and a["info"]["cg_iters"] == b["info"]["cg_iters"]
+    if n <= 1000:
+        assert a["info"]["status"] == "solved" and abs(a["info"]["pobj"] - p_star) <= 1e-3 * max(1.0, abs(p_star))
+    Pu = data["P"]
+    Pf = (Pu + sparse.triu(Pu, 1).T).tocsc()
+    Pf.sort_indices()
+    x = np.random.RandomState(3).randn(n)
+    got = hip.spmv(Pf, x)
+    np.testing.assert_allclose(got, Pf @ x, rtol=1e-12, atol=1e-12 * np.abs(Pf @ x).max())
+    np.testing.assert_array_equal(got, hip.spmv(Pf, x))
+
+
 @pytest.mark.parametrize("with_P", [False, True])
 def test_equilibration_matches_oracle(hip, oracle, with_P):
     """K12 runs on the device; D, E, sigma and the scaled data must match the oracle's restatement to a

@@ -75,10 +75,12 @@ def _load_module(name):
   return import_module("scs." + name)
 
 
-# AUTO's view of the dense direct solver (csrc/dense.hpp): the order it accepts, the share of the free HBM its inverse may take and
-# the work of forming G = R_x + P + A' R_y^-1 A (one product per pair of nonzeros of a row of A) it is worth paying at every
-# adaptive-scale update.  Measured crossover against the indirect path: DESIGN.md §4 "AUTO".
-_AUTO_DENSE_MAX_N = 8192
+# AUTO's view of the dense direct solver (csrc/dense.hpp): the order up to which it wins a whole solve against the indirect path
+# (measured: profiles/r06_auto_crossover.txt — 2.4 x at n = 1350, 1.3 x at 4096, 0.6-0.7 x at 6144 / 8192, where the 2 n^3-flop
+# re-inversions at every adaptive-scale update and the 8 n^2-byte product per iteration cost more than ~10 launch-bound PCG steps;
+# `LinearSolver.HIP_DENSE` by name accepts n <= 8192), the share of the free HBM its inverse may take and the work of forming
+# G = R_x + P + A' R_y^-1 A (one product per pair of nonzeros of a row of A) it is worth paying at every scale update.
+_AUTO_DENSE_MAX_N = 4096
 _AUTO_DENSE_HBM_SHARE = 0.25
 _AUTO_DENSE_MAX_BUILD_PRODUCTS = 2e9
 
@@ -105,7 +107,7 @@ def _dense_direct_fits(m, n, A):
 
 def _resolve_auto(m=None, n=None, A=None):
   """AUTO = the best DIRECT solver that is usable, as in the reference (R:scs/py/__init__.py:45-54: MKL Pardiso, else the
-  bundled QDLDL).  Here: the dense direct solver of the device when the problem fits it (n <= 8192, the n x n inverse within a
+  bundled QDLDL).  Here: the dense direct solver of the device when the problem fits it (n <= 4096, the n x n inverse within a
   quarter of the free HBM, G cheap to form), else the indirect solver — a sparse factorisation of the BASELINE patterns fills to
   0.06 N^2 and does not exist on the device."""
   if n is not None and _dense_direct_fits(m, n, A):

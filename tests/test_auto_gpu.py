@@ -45,12 +45,12 @@ def test_auto_policy_falls_back_to_indirect(monkeypatch):
     import scs
     from scs import _scs_hip, _scs_hip_dense
     _stub_mem(monkeypatch, 200e9)
-    big = sp.random(20000, 8193, density=1e-4, format="csc", random_state=2)
-    assert scs._resolve_auto(20000, 8193, big) is _scs_hip                      # beyond the order the dense solver accepts
-    edge = sp.random(20000, 8192, density=1e-4, format="csc", random_state=2)
-    assert scs._resolve_auto(20000, 8192, edge) is _scs_hip_dense
-    _stub_mem(monkeypatch, 1e9)                                                   # 8 n^2 = 537 MB > a quarter of 1 GB free
-    assert scs._resolve_auto(20000, 8192, edge) is _scs_hip
+    big = sp.random(20000, 4097, density=1e-4, format="csc", random_state=2)
+    assert scs._resolve_auto(20000, 4097, big) is _scs_hip                      # beyond the measured crossover (profiles/r06_auto_crossover.txt)
+    edge = sp.random(20000, 4096, density=1e-4, format="csc", random_state=2)
+    assert scs._resolve_auto(20000, 4096, edge) is _scs_hip_dense
+    _stub_mem(monkeypatch, 0.5e9)                                                 # 8 n^2 = 134 MB > a quarter of 0.5 GB free
+    assert scs._resolve_auto(20000, 4096, edge) is _scs_hip
     _stub_mem(monkeypatch, 200e9)
     rows = sp.csc_matrix(np.ones((300, 3000)))                                   # 300 full rows: 2.7e9 products per G
     assert scs._resolve_auto(300, 3000, rows) is _scs_hip

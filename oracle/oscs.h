@@ -161,6 +161,7 @@ scs_int o_solve_lin_sys(OLinSys *p, scs_float *b, const scs_float *s, scs_float 
 void o_free_lin_sys(OLinSys *p);
 long o_lin_sys_cg_iters(const OLinSys *p);
 long o_lin_sys_nnz_l(const OLinSys *p);
+long o_lin_sys_symbolic(const ScsMatrix *A, const ScsMatrix *P, long *etree_height);
 
 /* ---- anderson acceleration ---- */
 typedef struct OAa OAa;

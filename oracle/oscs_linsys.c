@@ -494,6 +494,52 @@ OLinSys *o_init_lin_sys(const ScsMatrix *A, const ScsMatrix *P, const scs_float 
   return w;
 }
 
+/* symbolic phase only (no values, no numeric factorisation): nnz(L) of the LDL' factor of the KKT pattern under the ordering above, and the
+ * HEIGHT of its elimination tree — the length of the dependency chain any factorisation (CPU or device) has to walk column after column.
+ * What DESIGN.md §7 prices a sparse direct solver on the device with (tools/ldl_fill_table.py). */
+long o_lin_sys_symbolic(const ScsMatrix *A, const ScsMatrix *P, long *etree_height) {
+  OLinSys *w = (OLinSys *)calloc(1, sizeof(OLinSys));
+  long lnz;
+  scs_int N, k;
+  w->n = A->n; w->m = A->m; w->N = A->n + A->m;
+  w->A = A; w->P = P;
+  build_kkt(w);
+  N = w->N;
+  w->Lp = (scs_int *)calloc(N + 1, sizeof(scs_int));
+  w->Parent = (scs_int *)calloc(N, sizeof(scs_int));
+  w->Lnz = (scs_int *)calloc(N, sizeof(scs_int));
+  w->Flag = (scs_int *)calloc(N, sizeof(scs_int));
+  {  /* column counts in long arithmetic: nnz(L) of the larger replicas does not fit scs_int */
+    scs_int i, p;
+    lnz = 0;
+    for (k = 0; k < N; k++) {
+      w->Parent[k] = -1;
+      w->Flag[k] = k;
+      for (p = w->Kp[k]; p < w->Kp[k + 1]; p++) {
+        i = w->Ki[p];
+        if (i < k)
+          for (; w->Flag[i] != k; i = w->Parent[i]) {
+            if (w->Parent[i] == -1) w->Parent[i] = k;
+            lnz++;
+            w->Flag[i] = k;
+          }
+      }
+    }
+  }
+  if (etree_height) {  /* Parent[k] > k: depth by one backward pass */
+    long h = 0;
+    scs_int *depth = (scs_int *)calloc(N, sizeof(scs_int));
+    for (k = N - 1; k >= 0; --k) {
+      depth[k] = w->Parent[k] >= 0 ? depth[w->Parent[k]] + 1 : 1;
+      if (depth[k] > h) h = depth[k];
+    }
+    free(depth);
+    *etree_height = h;
+  }
+  o_free_lin_sys(w);
+  return lnz;
+}
+
 void o_update_lin_sys_diag_r(OLinSys *w, const scs_float *diag_r) {
   w->diag_r = diag_r;
   if (w->indirect) set_preconditioner(w);

@@ -107,6 +107,8 @@ def lib():
                                      c_dbl, PI]
         L.oscs_spmv.restype = None
         L.oscs_spmv.argtypes = [C.POINTER(ScsMatrix), PD, PD, c_int]
+        L.o_lin_sys_symbolic.restype = C.c_long
+        L.o_lin_sys_symbolic.argtypes = [C.POINTER(ScsMatrix), C.POINTER(ScsMatrix), C.POINTER(C.c_long)]
         L.o_aa_init.restype = C.c_void_p
         L.o_aa_init.argtypes = [c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl]
         L.o_aa_apply.restype = c_dbl
@@ -313,6 +315,17 @@ def kkt_solve(A, P, diag_r, rhs, indirect=False, tol=1e-12):
     if rc != 0:
         raise ValueError("factorisation failed")
     return r, its.value
+
+
+def ldl_symbolic(A, P=None):
+    """(nnz(L), height of the elimination tree) of the LDL' factor of the KKT pattern [[P + I, A'], [A, -I]] under the oracle's
+    fill-reducing ordering — the symbolic phase only, no values (oscs_linsys.c o_lin_sys_symbolic)"""
+    m, n = A.shape
+    Am = make_matrix(A.data, A.indices, A.indptr, m, n)
+    Pm = make_matrix(P.data, P.indices, P.indptr, n, n) if P is not None else None
+    h = C.c_long(0)
+    lnz = lib().o_lin_sys_symbolic(C.byref(Am.mat), C.byref(Pm.mat) if Pm else None, C.byref(h))
+    return int(lnz), int(h.value)
 
 
 def spmv(A, x, trans=False):

@@ -59,6 +59,9 @@ int scs_hip_device_count(void);
  * may drive several GPUs. */
 int scs_hip_set_device(int dev);
 int scs_hip_set_thread_device(int dev);
+/* 1 when this library is the -DSCS_HIP_LABS build (scs-python_amd/Makefile `make labs`: the experiments that lost their measurement and
+ * the lab switches of the kernels compiled in and readable from the environment — csrc/options.hpp), 0 for the product. */
+int scs_hip_labs_build(void);
 /* free and total HBM bytes of the device subsequent scs_init calls would use, plus the bytes this library's block pool holds for
  * reuse (they count as free for a new workspace).  What the Python layer's `LinearSolver.AUTO` asks before it picks the dense direct
  * solver (R:scs/py/__init__.py:45-54 resolves AUTO to the best DIRECT backend that is usable).  0 on success, -1 without a device. */

@@ -634,10 +634,7 @@ struct DeviceAa {
   DeviceAa &operator=(const DeviceAa &) = delete;
   ~DeviceAa() { if (h_pin && owns_pin) (void)hipHostFree(h_pin); }
 
-  static bool tsqr_default() {  // SCS_HIP_AA=gram: incremental Gram update + host solve (A/B, tests)
-    const char *e = getenv("SCS_HIP_AA");
-    return !(e && e[0] == 'g');
-  }
+  static bool tsqr_default() { return !opts().aa_gram; }  // SCS_HIP_AA=gram: incremental Gram update + host solve (A/B, tests)
   int nbl() const { return vec_blocks(dim); }
 
   void init(long dim_, int mem_, int type1_, double regularization_, double relaxation_, double safeguard_factor_,
@@ -678,8 +675,8 @@ struct DeviceAa {
   // chains of the register-tile level-1 kernel: enough wavefronts to put 2-3 on every SIMD of the chip (SCS_HIP_AA_WAVES1: lab)
   static constexpr int kTsqrWavesFast = 4096;
   static int fast_waves() {
-    static const int v = [] { const char *e = getenv("SCS_HIP_AA_WAVES1"); const int t = e ? atoi(e) : 0; return t > 0 && t <= kTsqrWavesFast ? t : 2048; }();
-    return v;
+    const int t = opts().aa_waves1;  // (labs knob)
+    return t > 0 && t <= kTsqrWavesFast ? t : 2048;
   }
 
   // One launch of the TSQR reduction: the tall matrix it reads, its geometry and where its stacked triangles go
@@ -700,7 +697,7 @@ struct DeviceAa {
     W.ld = dim; W.rows = dim; W.nL = len; W.nY = type1 ? len : 0; W.c = W.nL + W.nY + 1; W.npiv = len;
     const int c = W.c, rho = aa_pick_rho(c);
     const size_t lds = aa_tsqr_lds(c, len, rho);
-    static const bool fast_on = [] { const char *e = getenv("SCS_HIP_AA_FAST"); return !(e && e[0] == '0'); }();  // A/B
+    const bool fast_on = opts().aa_fast;  // (labs switch: the LDS kernel of round 2)
     int level = 0, dst = 0;
     while (true) {
       const int fast = fast_on ? aa_tsqr_fast_kind(c, len) : 0;  // (every level: the stacked triangles have the same c columns and pivots)

@@ -218,7 +218,7 @@ struct GroupSolve {
   int list_slot = 0, lists_since_sync = 0;
   bool soc_psd_fused = false;     // short SOCs and small PSD matrices of a member in one launch
   const int *active_d = nullptr;  // device copy of `active`
-  double t_finish = 0.;           // host time inside finish_solve (SCS_HIP_GROUP_STATS)
+  double t_finish = 0.;           // host time inside finish_solve (SCS_HIP_DEBUG=group)
   std::vector<int> active;
 
   // per-member host state of this solve
@@ -226,7 +226,7 @@ struct GroupSolve {
   std::vector<int> aa_mode, aa_len;
   int mem = 0, interval = 1;
   double t_start = 0, t_lin = 0, t_cone = 0, t_acc = 0;
-  long launches = 0;  // grouped launches issued (diagnostics: SCS_HIP_GROUP_STATS)
+  long launches = 0;  // grouped launches issued (diagnostics: SCS_HIP_DEBUG=group)
   int syncs = 0, lockstep_iters = 0;
 
   ~GroupSolve() {
@@ -693,9 +693,11 @@ struct GroupSolve {
     t_start = now_ms();  // behind the deferred setup: solve_time is the solve (ScsInfo as the reference fills it)
     mr_allowed_saved.assign((size_t)G, 0);
     for (int g = 0; g < G; ++g) {
+#ifdef SCS_HIP_LABS
       mr_allowed_saved[(size_t)g] = W[(size_t)g]->mr_allowed ? 1 : 0;
       W[(size_t)g]->mr_allowed = false;  // the grouped loop drives PCG steps through its own tables (minres.hpp: one workspace at a time)
       W[(size_t)g]->mr_active = false;   // (a member that had switched to MINRES in a solve of its own runs PCG here, and may switch again later)
+#endif
       W[(size_t)g]->begin_solve(sols[(size_t)g], infos[(size_t)g], warm_start);
     }
     for (int g = 0; g < G; ++g) {
@@ -712,7 +714,7 @@ struct GroupSolve {
     std::iota(active.begin(), active.end(), 0);
     upload_active();
     std::vector<int> tmp_list;
-    const bool stats = getenv("SCS_HIP_GROUP_STATS") != nullptr;
+    const bool stats = (opts().debug & DBG_GROUP) != 0;  // SCS_HIP_DEBUG=group
     InterruptListener ctrlc;  // (scs_hip.hip: Ctrl-C ends every member that is still running with SCS_SIGINT)
     for (int i = 0; !active.empty(); ++i) {
       if (InterruptListener::interrupted()) {
@@ -828,7 +830,7 @@ struct GroupSolve {
       if (has_P) go(t_spmv_pws, active_d, na);
       go(t_spmv_r0, active_d, na);
       go(t_fin_head, active_d, na);
-      static const int pred_mode = [] { const char *e = getenv("SCS_HIP_GROUP_PREDICT"); return e ? atoi(e) : 1; }();  // 0: max + 1 (lab)
+      const int pred_mode = opts().group_predict;  // (labs) 0: max + 1
       finish_cg(active, active_d, 0, [&](int g) { return pred_mode ? W[(size_t)g]->recent_cg_q3() : W[(size_t)g]->recent_cg_max() + 1; }, deferred_host_work);
       iters_since_sync = 0;
       for (int g : active) {
@@ -938,12 +940,14 @@ struct GroupSolve {
       }
     }
     HIP_CHECK(hipStreamSynchronize(s));
+#ifdef SCS_HIP_LABS
     for (int g = 0; g < G; ++g) {  //  what the group took from its members' Krylov state goes back
       ScsHipWork *w = W[(size_t)g];
       w->mr_allowed = mr_allowed_saved[(size_t)g] != 0;
       if (w->mr_ready) w->mr_precond_stale = true;  // scale updates inside the group went through t_set_diag_r / t_precond only
     }
-    if (getenv("SCS_HIP_GROUP_STATS"))
+#endif
+    if (opts().debug & DBG_GROUP)
       std::fprintf(stderr, "[scs-hip group] members %d, lock-step iterations %d, grouped launches %ld (%.1f per iteration), host syncs %d, %.1f ms (%.1f ms of it finishing members: un-scaling, s'y, downloads)\n",
                    G, lockstep_iters, launches, (double)launches / std::max(lockstep_iters, 1), syncs, now_ms() - t_start, t_finish);
   }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/scs_hip.h"
+#include "options.hpp"
 
 namespace scship {
 
@@ -48,7 +49,7 @@ struct DevPool {
   bool cap_read = false;
   static DevPool &inst() { static DevPool p; return p; }
   size_t capacity() {
-    if (!cap_read) { const char *e = getenv("SCS_HIP_POOL_MB"); cap = (size_t)(e ? atol(e) : 1024) << 20; cap_read = true; }
+    if (!cap_read) { const char *e = getenv("SCS_HIP_POOL_MB"); cap = (size_t)(e ? atol(e) : 1024) << 20; cap_read = true; }  // (process-wide: read once)
     return cap;
   }
   void *get(size_t bytes) {
@@ -60,8 +61,7 @@ struct DevPool {
         void *p = blocks[i].second;
         blocks.erase(blocks.begin() + (long)i);
         cached -= bytes;
-        static const bool poison = [] { const char *e = getenv("SCS_HIP_POOL_POISON"); return e && e[0] == '1'; }();
-        if (poison) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
+        if (opts().pool_poison)  // (labs: recycled blocks arrive poisoned) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }
         return p;
       }
     return nullptr;

@@ -22,20 +22,25 @@
 #include <mutex>
 #include <thread>
 
+#include "options.hpp"
 #include "aa.hpp"
 #include "common.hpp"
 #include "cones.hpp"
 #include "host_setup.hpp"
 #include "normalize_dev.hpp"
 #include "psd.hpp"
+#ifdef SCS_HIP_LABS  // experiments that lost their measurement (options.hpp): compiled into libscs_hip_labs.so only
 #include "cg_persist.hpp"
 #include "minres.hpp"
+#endif
 #include "dense.hpp"
 #include "setup_dev.hpp"
 #include "setup_cs_dev.hpp"
 #include "spmv.hpp"
 #include "vec.hpp"
+#ifdef SCS_HIP_LABS
 #include "cg_k1dot.hpp"
+#endif
 
 namespace scship {
 
@@ -85,7 +90,7 @@ struct StreamPool {
   std::mutex mtx;
   std::vector<Dev> devs;
   static int cap() {
-    static const int c = [] { const char *e = getenv("SCS_HIP_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();
+    static const int c = [] { const char *e = getenv("SCS_HIP_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();  // (process-wide: read once)
     return c;
   }
   hipStream_t acquire(int device, bool *shared) {
@@ -153,10 +158,7 @@ struct DeviceCsr {
   int s_nchunks = 0, s_S = 0, s_R = 0, s_max_seg = 0;
   // optional column-sorted pass copy (spmv_cs.hpp); preferred over the slab copy when both could be built
   DeviceCs cs;
-  static bool cs_enabled() {  // SCS_HIP_CS=0: keep the slab kernel (A/B measurements)
-    const char *e = getenv("SCS_HIP_CS");
-    return !(e && e[0] == '0');
-  }
+  static bool cs_enabled() { return opts().cs; }  // SCS_HIP_CS=0: keep the slab kernel (A/B measurements)
   // rows too long for the layout's count fields are peeled off it (spmv_cs.hpp CsView::peel) and done over the plain CSR
   DevBuf<unsigned> peel_mask;
   DevBuf<int4> peel_blk;
@@ -165,7 +167,7 @@ struct DeviceCsr {
   // host: mark rows longer than `thresh`; one row block {row, row + 1, first nonzero, end} each.  false: nothing to peel
   bool make_peel(const int *rp_host, int thresh, hipStream_t s) {
     peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0; peel_nnz = 0;
-    if (getenv("SCS_HIP_CS_PEEL") && getenv("SCS_HIP_CS_PEEL")[0] == '0') return false;  // A/B: reject such patterns as round 1 did
+    if (!opts().cs_peel) return false;  // (labs) A/B: reject such patterns as round 1 did
     std::vector<int4> blk;
     std::vector<unsigned> mask;
     for (int r = 0; r < rows; ++r)
@@ -188,10 +190,7 @@ struct DeviceCsr {
   }
   // ---- virtual rows (spmv_cs.hpp CsView::Rr): long rows cut into pieces that ride in the passes ----
   using VirtPlan = CsVirtPlan;
-  static bool virt_enabled() {  // SCS_HIP_CS_VIRT=0: long rows go to the CSR-stream side launch whole (round 2)
-    const char *e = getenv("SCS_HIP_CS_VIRT");
-    return !(e && e[0] == '0');
-  }
+  static bool virt_enabled() { return opts().cs_virt; }  // (labs) SCS_HIP_CS_VIRT=0: long rows go to the CSR-stream side launch whole (round 2)
   // rows longer than max(lp, what a count field holds) nonzeros -> ceil(len / lp) pieces (rows a field holds stay whole and keep
   // the oracle's summation order; a piece's run is added by ONE lane, so pieces are short whatever the field would hold);
   // fills the peel mask / row blocks {row, row + 1, first piece, end}
@@ -222,7 +221,7 @@ struct DeviceCsr {
                        d_info.p, P.Rr, P.Rp, P.R, vslot.p);
     HIP_CHECK(hipStreamSynchronize(s));  // (P.rowinfo is read by the upload)
     const bool built = cs.build_from_transpose(P.nchunks * P.R, cols, T.rowptr.p, vslot.p, T.val.p, nnz, s, 1, nullptr, P.R, P.rpt);
-    if (getenv("SCS_HIP_SETUP_TIMING"))
+    if (opts().debug & DBG_SETUP)
       std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d: rows longer than %d in pieces of <= %d (%d rows, %ld of %ld nonzeros, %d pieces; chunks of %d + %d slots, %d rows per lane): %s\n",
                    rows, cols, std::max(lp, peel_threshold(1)), lp, npeel, peel_nnz, (long)nnz, P.V, P.Rr, P.Rp, P.rpt, built ? "built" : "a count field overflowed");
     if (!built) { clear_peel(); return false; }
@@ -244,9 +243,8 @@ struct DeviceCsr {
     for (int per_pass : {24, 12, 6}) out.push_back((int)std::min<long>(per_pass * npass_est, 1L << 20));
     return out;
   }
-  static std::vector<int> peel_ladder() {  // SCS_HIP_CS_PEEL_LADDER=0: rows longer than a count field at once (round 2)
-    const char *e = getenv("SCS_HIP_CS_PEEL_LADDER");
-    if (e && e[0] == '0') return {1};
+  static std::vector<int> peel_ladder() {  // (labs) SCS_HIP_CS_PEEL_LADDER=0: rows longer than a count field at once (round 2)
+    if (!opts().cs_peel_ladder) return {1};
     return {32, 16, 8, 4, 2, 1};
   }
   int peel_threshold(int split) const {
@@ -255,10 +253,7 @@ struct DeviceCsr {
     return cs_peel_threshold(rpt);
   }
   DevBuf<double> cs_part0, cs_part1;  // cs.split == 2 without the in-kernel combine: partial row sums (spmv.hpp EpiPartial / EpiGp::split)
-  static bool cs_split_enabled() {  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (bit-exact sequential row sums; A/B)
-    const char *e = getenv("SCS_HIP_CS_SPLIT");
-    return !(e && e[0] == '0');
-  }
+  static bool cs_split_enabled() { return opts().cs_split; }  // SCS_HIP_CS_SPLIT=0: one workgroup per row chunk everywhere (bit-exact sequential row sums; A/B)
   // Workgroups per row chunk.  kind: 0 = A (y-space products), 1 = A' (x-space products), 2 = P.  Taller chunks mean more
   // nonzeros per 128-byte line of the gather vector, i.e. fewer lines per gather instruction — the quantity that bounds
   // these kernels — at the price of partial row sums.  Default: only A' is split, in two, and hands its two partial
@@ -268,20 +263,18 @@ struct DeviceCsr {
   // Measured at the bench size (tools/cs_lab.hip): the 48 MB of partial-sum traffic and the 16-rows-per-lane row sums
   // eat the gather gain (A: 91.5 us unsplit, 95 us split in two + combine; A': 93 us two partial vectors, 100 us four
   // parts + combine) => off by default.
-  static bool cs_combine_enabled() {
-    const char *e = getenv("SCS_HIP_CS_COMBINE");
-    return e && e[0] == '1' && cs_schedule() >= 2;  // (round 5: the round-4 schedule too — k_spmv_cs_il<.., 6> carries the same combine code)
+  static bool cs_combine_enabled() {  // (labs)
+    return opts().cs_combine && cs_schedule() >= 2;  // (round 5: the round-4 schedule too — k_spmv_cs_il<.., 6> carries the same combine code)
   }
   int cs_pick_split(int kind) const {
-    if (!cs_split_enabled() || getenv("SCS_HIP_CS_RPT")) return 1;
+    if (!cs_split_enabled() || opts().cs_rpt > 0) return 1;
     if (!cs_combine_enabled()) {
       if (kind != 1) return 1;
       int R, rpt;
       cs_pick_geometry(rows, R, rpt, 2);
       return rpt <= 8 ? 2 : 1;
     }
-    const char *e = getenv(kind == 0 ? "SCS_HIP_CS_SPLIT_A" : kind == 1 ? "SCS_HIP_CS_SPLIT_AT" : "SCS_HIP_CS_SPLIT_P");
-    if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    { const int v = kind == 0 ? opts().cs_split_a : kind == 1 ? opts().cs_split_at : opts().cs_split_p; if (v == 1 || v == 2 || v == 4) return v; }
     for (int sp : {4, 2}) {
       int R, rpt;
       cs_pick_geometry(rows, R, rpt, sp);
@@ -299,8 +292,7 @@ struct DeviceCsr {
   bool build_cs_dev(const DeviceCsr &T, hipStream_t s, int kind) {
     cs.release();
     peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
-    const char *env = getenv("SCS_HIP_SLAB");
-    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
+    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || !opts().slab) return false;
     bool ok = false;
     const int sp = cs_pick_split(kind);
     std::vector<int> rp((size_t)rows + 1);  // row lengths decide what is peeled (O(rows) at init)
@@ -323,7 +315,7 @@ struct DeviceCsr {
         if (!make_peel(rp.data(), peel_threshold(split) * mult, s)) continue;  // (no row that long: next rung)
         if (peel_nnz > (nnz / 5) * 3) { clear_peel(); return false; }
         const bool built = cs.build_from_transpose(rows, cols, T.rowptr.p, T.col.p, T.val.p, nnz, s, split, peel_mask.p);
-        if (getenv("SCS_HIP_SETUP_TIMING"))
+        if (opts().debug & DBG_SETUP)
           std::fprintf(stderr, "[scs-hip] column-sorted layout %d x %d, split %d: rows longer than %d peeled (%d rows, %ld of %ld nonzeros): %s\n",
                        rows, cols, split, peel_threshold(split) * mult, npeel, peel_nnz, (long)nnz, built ? "built" : "a count field overflowed");
         if (built) return true;
@@ -341,8 +333,7 @@ struct DeviceCsr {
   bool build_cs_host(const int *rp, const int *ci, const double *v, hipStream_t s, int kind) {
     cs.release();
     peel_mask.release(); peel_blk.release(); npeel = 0; npeel_long = 0;
-    const char *env = getenv("SCS_HIP_SLAB");
-    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || (env && env[0] == '0')) return false;
+    if (!cs_enabled() || !cs_wanted(rows, cols, nnz) || !opts().slab) return false;
     HostCs h;
     bool ok = false, virt_host = false;
     const int sp = cs_pick_split(kind);
@@ -372,10 +363,7 @@ struct DeviceCsr {
     cs_after_build(s);
     return true;
   }
-  static bool host_setup() {  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
-    const char *e = getenv("SCS_HIP_SETUP");
-    return e && e[0] == 'h';
-  }
+  static bool host_setup() { return opts().host_setup; }  // SCS_HIP_SETUP=host: transposition and slab construction on the host (fallback / A-B / tests)
   void set_rowblocks(const int *rp_host, hipStream_t s) {
     std::vector<int4> rb = build_rowblocks(rp_host, rows);
     nblk = (int)rb.size();
@@ -389,8 +377,7 @@ struct DeviceCsr {
     val.upload(v, nnz, s);
     set_rowblocks(rp, s);
     has_slab = false;
-    const char *env = getenv("SCS_HIP_SLAB");  // "0" forces the plain CSR-stream kernel (A/B measurements)
-    if (allow_slab && slab_wanted(rows, cols) && !(env && env[0] == '0')) {
+    if (allow_slab && slab_wanted(rows, cols) && opts().slab) {  // SCS_HIP_SLAB=0 forces the plain CSR-stream kernel (A/B measurements)
       if (!host_setup()) {
         build_slab_dev(s);
       } else {
@@ -451,8 +438,7 @@ struct DeviceCsr {
   // L2-blocked copy of the CURRENT csr arrays, built on the device (same layout as spmv.hpp build_slab)
   void build_slab_dev(hipStream_t s) {
     has_slab = false;
-    const char *env = getenv("SCS_HIP_SLAB");
-    if (!slab_wanted(rows, cols) || (env && env[0] == '0')) return;
+    if (!slab_wanted(rows, cols) || !opts().slab) return;
     SlabGeom g;
     g.rows = rows; g.cols = cols; g.R = slab_pick_rows(rows); g.shift = slab_shift();
     g.S = (int)(((long)cols + (1L << g.shift) - 1) >> g.shift);
@@ -538,7 +524,7 @@ static void device_normalize(DeviceCsr &At, DeviceCsr &Ar, DeviceCsr *Pf, const 
     if (cone.boundaries[i] >= 1) { boff.push_back((int)count); blen.push_back(cone.boundaries[i]); }
     count += cone.boundaries[i];
   }
-  const bool fused_finish = [] { const char *e = getenv("SCS_HIP_NORM_FUSE"); return !(e && e[0] == '0'); }();  // =0: the four launches of rounds 1-4 (A/B; same bits)
+  const bool fused_finish = opts().norm_fuse;  // (labs) SCS_HIP_NORM_FUSE=0: the four launches of rounds 1-4 (A/B; same bits)
   DevBuf<int> dboff, dblen;
   const int nblocks = (int)boff.size();
   if (nblocks) { dboff.upload(boff.data(), boff.size(), s); dblen.upload(blen.data(), blen.size(), s); }
@@ -685,7 +671,7 @@ struct ScsHipWork {
   double *h_params_base = nullptr, *d_params_base = nullptr;
   // run-ahead mode (see F_STALL in vec.hpp): plain iterations are enqueued whole and one ahead of the host's view
   bool pipelined = false;
-  int pipe_chunk_override = 0, pipe_stalls = 0;  // tests: SCS_HIP_PIPE_CHUNK forces short CG chunks (=> stalls)
+  int pipe_chunk_override = 0, pipe_stalls = 0;  // tests: SCS_HIP_PIPELINE=N forces CG chunks of N steps (=> stalls)
   const int *stall = nullptr;      // fl + F_STALL while a run-ahead iteration is being enqueued, else nullptr
   int *stall_fl = nullptr;         // fl (or nullptr): k_tau_dots raises the stall, k_cone_pre parks the CG kernels
   int *h_flags_slot[2] = {nullptr, nullptr};
@@ -704,10 +690,19 @@ struct ScsHipWork {
   static constexpr int kNumGraphs = 5;
   const int kGraphSteps[kNumGraphs] = {1, 2, 4, 8, 16};
   hipGraphExec_t g_pre[kNumGraphs] = {}, g_cg[kNumGraphs] = {}, g_post = nullptr;
-  bool graphs_ready = false, graphs_enabled = true;
+  bool graphs_ready = false;
+#ifdef SCS_HIP_LABS
+  bool graphs_enabled = true;
+#else
+  static constexpr bool graphs_enabled = false;  // (hipGraph replay lives in the labs build: 5 % slower than eager launches at config 2)
+#endif
   // small problems: the whole PCG solve of an iteration is one persistent launch (cg_persist.hpp)
+#ifdef SCS_HIP_LABS
   int persist_wgs = 0, persist_ng = 1;  // 0 = launch-per-kernel path
   DevBuf<unsigned> persist_bar;
+#else
+  static constexpr int persist_wgs = 0, persist_ng = 1;  // (the persistent kernel lives in the labs build: never faster than launch-per-kernel)
+#endif
 
   DeviceCsr At;  // CSR(A') == caller's CSC(A): rows n, cols m   (x-space outputs)
   DeviceCsr Ar;  // CSR(A): rows m, cols n                        (y-space outputs)
@@ -880,19 +875,19 @@ struct ScsHipWork {
   // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
   // small matrices (order <= 32): four wavefronts per matrix (psd.hpp d_proj_psd_small4); SCS_HIP_PSD_SMALL_WAVES=1: the one-wavefront kernel (lab; agrees to rounding)
   // SCS_HIP_SOC_PSD_FUSE=0: separate launches for short SOCs and small PSD matrices (same bits)
-  bool soc_psd_one_launch = [] { const char *e = getenv("SCS_HIP_SOC_PSD_FUSE"); return !(e && e[0] == '0'); }();
+  bool soc_psd_one_launch = opts().soc_psd_fuse;  // (labs switch)
   // Round 5: GEMM-only refinement of the sign split instead of the last Jacobi sweep(s) in split mode (psd.hpp psd_stop_test).
   // SCS_HIP_PSD_REFINE=0: strict sweeps only (bit-identical to the one-launch kernel); SCS_HIP_PSD_GATE_K / _OFF / _OMEGA: the gate (lab knobs).
   PsdRefineCfg psd_refine = [] {
-    const char *e = getenv("SCS_HIP_PSD_REFINE");
-    PsdRefineCfg r = psd_refine_default(!(e && e[0] == '0'));
-    if (const char *v = getenv("SCS_HIP_PSD_GATE_K")) { const double x = atof(v); if (x > 0.) r.k2 = x * x; }
-    if (const char *v = getenv("SCS_HIP_PSD_GATE_OFF")) { const double x = atof(v); if (x > 0.) r.off2 = x * x; }
-    if (const char *v = getenv("SCS_HIP_PSD_GATE_OMEGA")) { const double x = atof(v); if (x > 0.) r.omega = x; }
+    const Options &o = opts();
+    PsdRefineCfg r = psd_refine_default(o.psd_refine);
+    if (o.psd_gate_k > 0.) r.k2 = o.psd_gate_k * o.psd_gate_k;      // (labs: the gate)
+    if (o.psd_gate_off > 0.) r.off2 = o.psd_gate_off * o.psd_gate_off;
+    if (o.psd_gate_omega > 0.) r.omega = o.psd_gate_omega;
     return r;
   }();
-  bool psd_small_one_wave = [] { const char *e = getenv("SCS_HIP_PSD_SMALL_WAVES"); return e && e[0] == '1'; }();
-  int psd_mc_look_ahead = [] { const char *e = getenv("SCS_HIP_PSD_LA"); return (e && e[0] == '0') ? 0 : 1; }();  // one barrier per step
+  bool psd_small_one_wave = opts().psd_small_one_wave;  // (labs)
+  int psd_mc_look_ahead = opts().psd_la ? 1 : 0;        // (labs switch) one barrier per step
   // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
   // ~0.1 ms per launch in a fresh process and ~2 ms per launch once the process has driven other workspaces / streams before (config 4 as
   // the second workload of a bench run: 224 iters/s in the steady window and 245 over a whole solve against 462 / 521 with the ordinary
@@ -900,9 +895,11 @@ struct ScsHipWork {
   // cooperative one is accepted: the grid is sized to fit the device at one workgroup per CU (psd_mc_cap, occupancy query), the
   // dispatcher places workgroups in order, and a kernel of another stream that holds CUs finishes without waiting for this one — a group
   // whose members are late spins within its budget (F_PERSIST_ERR otherwise: an error, not a hang).  SCS_HIP_PSD_COOP=1: cooperative launch.
-  bool psd_mc_coop = [] { const char *e = getenv("SCS_HIP_PSD_COOP"); return e && e[0] == '1'; }();
+  bool psd_mc_coop = opts().psd_coop;  // (labs)
   int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
-  long spin_budget = [] { const char *e = getenv("SCS_HIP_SPIN_BUDGET_LOG2"); const int v = e ? atoi(e) : 25; return 1L << std::max(0, std::min(v, 40)); }();  // barrier polls before a member gives up (tests: 0)
+  long spin_budget = 1L << opts().spin_budget_log2;  // barrier polls before a member gives up (SCS_HIP_SPIN_BUDGET_LOG2; tests: 0)
+  int psd_mc_forced = opts().psd_mc;                 // SCS_HIP_PSD_MC at the workspace's creation (-1: pick)
+  bool psd_mc_nocheck = opts().psd_mc_nocheck;       // (labs: tests of the refused launch)
   bool spin_user = false;
   hipEvent_t ev_spin = nullptr;
   void spin_register() {  // before this workspace's first spinning launch
@@ -960,16 +957,16 @@ struct ScsHipWork {
     // (tools/psd_mc_lab.sh: order 200 x 50, G = 4: 3.57 -> 2.24 ms per projection; order 64 x 100, G = 2: 0.29 -> 0.42 ms)
     const int pivots = psd_max_np / (2 * kPsdB);
     int G = std::min(std::min(psd_mc_cap / groups, kPsdMcMaxG), pivots / 3);
-    if (const char *env = getenv("SCS_HIP_PSD_MC")) {
-      G = atoi(env);
-      if (G > kPsdMcMaxG || ((long)G * groups > (long)psd_mc_cap && !getenv("SCS_HIP_PSD_MC_NOCHECK"))) G = 1;  // (NOCHECK: tests of the refused launch)
+    if (psd_mc_forced >= 0) {
+      G = psd_mc_forced;
+      if (G > kPsdMcMaxG || ((long)G * groups > (long)psd_mc_cap && !psd_mc_nocheck)) G = 1;  // (NOCHECK: tests of the refused launch)
     }
     return std::max(G, 1);
   }
   bool in_capture = false;
   // stopping level of the PSD sweeps (psd.hpp psd_offtol2): inside the ADMM loop the iteration's P_PSD_TOL2, else nullptr = fixed 1e-8
   const double *psd_tol2 = nullptr;
-  static bool psd_tol_adaptive() { static const bool on = [] { const char *e = getenv("SCS_HIP_PSD_TOL"); return !(e && e[0] == 'f'); }(); return on; }  // SCS_HIP_PSD_TOL=fixed: A/B
+  static bool psd_tol_adaptive() { return opts().psd_tol_adaptive; }  // SCS_HIP_PSD_TOL=fixed: A/B
   // ... and only while no Anderson extrapolation can happen yet (the history is still filling: iteration < lookback x interval;
   // always, without acceleration): plain ADMM tolerates inexact projections, the secant model of the acceleration does not —
   // with interval 1 and type-II steps a golden infeasible instance stalled for good (tools/dbg/psd_tol_infeas.py).
@@ -978,12 +975,11 @@ struct ScsHipWork {
     return plain_phase ? psd_tol2_of(psd_res_min) : kPsdOffTol2;
   }
   static double psd_kappa() {
-    static const double kappa = [] { const char *e = getenv("SCS_HIP_PSD_TOL_K"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1e-2; }();  // (lab knob; see psd.hpp psd_offtol2 for why 1e-2)
-    return kappa;
+    return opts().psd_tol_k;  // (labs knob; see psd.hpp psd_offtol2 for why 1e-2)
   }
   static double psd_tol2_of(double level) {  // level = what note_check_residuals left in psd_res_min
     if (!psd_tol_adaptive()) return kPsdOffTol2;
-    static const double cap = [] { const char *e = getenv("SCS_HIP_PSD_TOL_MAX"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1e-3; }();  // (lab knob)
+    const double cap = opts().psd_tol_max;  // (labs knob)
     const double t = std::min(std::max(level, 1e-8), cap);
     return t * t;
   }
@@ -1007,8 +1003,7 @@ struct ScsHipWork {
   // enqueuing the counts of eight iterations ago: 36 % of the K1 / K2 launches of the bench window were early-exit launches
   // (profiles/r03_bench_kernel_trace.txt: 3581 launched, 2309 with work).
   static int chunk_window() {
-    static const int w = [] { const char *e = getenv("SCS_HIP_CHUNK_WINDOW"); const int v = e ? atoi(e) : 3; return std::max(1, std::min(v, 8)); }();
-    return w;
+    return opts().chunk_window;  // (labs knob)
   }
   int recent_cg_max() const {
     int mx = 1;
@@ -1100,8 +1095,7 @@ struct ScsHipWork {
   // asymmetry — what a product that mirrors one triangle sees — is kappa times larger: measured on the KKT test systems
   // (kappa = 2e4) 1e-11 against 3.5e-8 relative error (tools/dbg/dense_gemv_err.py, profiles/r04_dense_linsys.txt).
   static bool dense_full_gemv() {
-    static const bool v = [] { const char *e = getenv("SCS_HIP_DENSE_GEMV"); return !(e && e[0] == 'h'); }();
-    return v;
+    return opts().dense_full_gemv;  // (labs: SCS_HIP_DENSE_GEMV=half)
   }
   void dense_gemv(const double *b, double *x, const int *st) {
     if (dense_full_gemv())
@@ -1111,7 +1105,7 @@ struct ScsHipWork {
   }
   // Dense workspaces finish their setup — R, G^{-1}, g = KKT^{-1} [c; -b] — at the first solve (or update) instead of inside scs_init:
   // a batch of them then forms and inverts all its matrices in ONE batched sweep (GroupSolve::run), 66 launches for the whole group
-  // instead of 66 launch-bound ones per member (SCS_HIP_DENSE_LAZY=0: inside scs_init).
+  // instead of 66 launch-bound ones per member (SCS_HIP_LAZY_SETUP=0: inside scs_init).
   bool setup_pending = false, setup_failed = false;
   std::string setup_failed_msg(int member = -1) const {
     return std::string("hip_dense: the inverse of the reduced KKT matrix is not finite") +
@@ -1165,20 +1159,25 @@ struct ScsHipWork {
   // (SCS_HIP_K1DOT=1): measured on the metric workload it makes K2 3-4 us faster (90.0 -> 86.4 us: K2 = K1) but the iteration 1.7 % SLOWER
   // (310-312 -> 305-306 iters/s, steady window 507-511 -> 491-496): the second reduction chain (r_x p^2 through k_cg_dir -> k_cg_update's
   // prologue, one more pass behind the CG start) and K1's block reduction cost more than K2's 16 MB of p saved.
+#ifdef SCS_HIP_LABS
   bool k1dot = false;
   DevBuf<double> part_k1, part_pp;
   void decide_k1dot(hipStream_t s) {
-    const char *e = getenv("SCS_HIP_K1DOT");
-    k1dot = (e && e[0] == '1') && !has_P && At.cs.ok && Ar.cs.ok && persist_wgs == 0;
+    k1dot = opts().k1dot && !has_P && At.cs.ok && Ar.cs.ok && persist_wgs == 0;
     if (k1dot) {
       part_k1.alloc_zero((size_t)std::max(Ar.nwg(), 1) * kMaxEpiReductions, s);
       part_pp.alloc_zero((size_t)kMaxVecBlocks, s);
     }
   }
+#else
+  static constexpr bool k1dot = false;
+  void decide_k1dot(hipStream_t) {}
+#endif
   // Gp = (R_x + P + A' R_y^{-1} A) x ; partial p.Gp into part[0..At.nblk)
   // step_counter != nullptr marks the A product of a CG step (its workgroup 0 advances the step parity)
   // second half of Gp when A' has the split layout (EpiGp::split): Gp = cg_Gp + gp2()
   double *gp2() const { return At.cs.ok && At.cs.split > 1 && !At.cs.combine() ? At.cs_part1.p : nullptr; }
+#ifdef SCS_HIP_LABS
   // the two products of a CG step on the k1dot path: z = R_y^{-1} A p with the partials of (A p)'z, then the raw A'z (cg_Gp [+ gp2()])
   void matvec_k1dot(const double *x, const int *done, int *step_counter, hipEvent_t *evs = nullptr) {
     if (evs) HIP_CHECK(hipEventRecord(evs[0], stream));
@@ -1187,6 +1186,7 @@ struct ScsHipWork {
     launch_spmv(At.view(), tmp_m.p, EpiAtRaw{cg_Gp.p, gp2()}, done, stream);
     if (evs) HIP_CHECK(hipEventRecord(evs[2], stream));
   }
+#endif
   void matvec(const double *x, const int *done, int *step_counter = nullptr) {
     launch_spmv(Ar.view(), x, EpiDivR{tmp_m.p, rdy()}, done, stream, step_counter);
     if (has_P) launch_spmv(Pf.view(), x, EpiStore{cg_Gp.p, 0}, done, stream);
@@ -1218,12 +1218,15 @@ struct ScsHipWork {
                        n, warm ? 1 : 0, fl.p, part.p, (const double *)gp2());
     hipLaunchKernelGGL(k_fin_cg_init, dim3(1), dim3(kVecThreads), 0, stream, part.p, nb, 0, sc.p, fl.p);
     HIP_CHECK(hipMemsetAsync(fl.p + F_ITERS, 0, sizeof(int), stream));
+#ifdef SCS_HIP_LABS
     if (k1dot) hipLaunchKernelGGL(k_pp_part, dim3(vb(n)), dim3(kVecThreads), 0, stream, (const double *)cg_p.p, rdx(), n, part_pp.p, (const int *)nullptr);
+#endif
   }
   // yacc != nullptr: carry y += alpha R_y^{-1} A p along (ADMM path, see k_prep).  evs: three events around the two products (in-situ
   // kernel timing of one step: bench.py's roofline)
   void enqueue_cg_step(double *xout, double *yacc, hipEvent_t *evs = nullptr) {
     const int nb = vb(std::max(n, yacc ? m : 0));
+#ifdef SCS_HIP_LABS
     if (k1dot) {
       matvec_k1dot(cg_p.p, fl.p + F_DONE, fl.p + F_STEP, evs);
       hipLaunchKernelGGL(k_cg_update_k1dot, dim3(nb), dim3(kVecThreads), 0, stream, xout, cg_r.p, (const double *)cg_p.p, (const double *)cg_Gp.p,
@@ -1233,6 +1236,7 @@ struct ScsHipWork {
                          (const double *)part2.p, nb, rdx(), part_pp.p, sc.p, fl.p);
       return;
     }
+#endif
     if (evs) {
       HIP_CHECK(hipEventRecord(evs[0], stream));
       launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
@@ -1253,7 +1257,7 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_cg_dir, dim3(vb(n)), dim3(kVecThreads), 0, stream, cg_p.p, cg_r.p, cg_M.p, n, part2.p, nb, sc.p, fl.p);
   }
   // SCS_HIP_CG_FUSE=0: always two launches
-  bool cg_fuse_on = [] { const char *e = getenv("SCS_HIP_CG_FUSE"); return !(e && e[0] == '0'); }();  // read when the workspace is made
+  bool cg_fuse_on = opts().cg_fuse;  // (labs switch) read when the workspace is made
   bool cg_fuse() const { return cg_fuse_on && n <= kCgFuseMaxN; }
   void enqueue_flag_readback() {
     HIP_CHECK(hipMemcpyAsync(h_flags, fl.p, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, stream));
@@ -1272,11 +1276,12 @@ struct ScsHipWork {
   // 825 instead of 700 ADMM iterations: 29.1 s against 13.9 s.  The round-4 prototype compared the two from a RANDOM warm start (1.7 x
   // fewer steps); inside the ADMM loop the warm start is the previous iterate, the residual has to fall by a modest factor only, and the
   // reduced residual — which MINRES does not minimise — first rises.  The recursion's residual equals the true one (SCS_HIP_MR_CHECK).
+#ifdef SCS_HIP_LABS
   static constexpr int kMrAutoSteps = 96, kMrAutoZ = 256;
-  int krylov = [] { const char *e = getenv("SCS_HIP_KRYLOV"); return !e ? 0 : e[0] == 'c' ? 0 : e[0] == 'm' ? 1 : e[0] == 'a' ? 2 : 0; }();  // 0 cg, 1 minres (whenever z > 0), 2 auto; read when the workspace is made
+  int krylov = opts().krylov;  // 0 cg, 1 minres (whenever z > 0), 2 auto; read when the workspace is made
   int krylov_mode() const { return krylov; }
   bool mr_active = false, mr_ready = false, mr_allowed = true;
-  double mr_tolf = [] { const char *e = getenv("SCS_HIP_MR_TOLF"); const double v = e ? atof(e) : 0.; return v > 0. ? v : 1.0; }();  // (lab) MINRES stops at mr_tolf x the PCG tolerance
+  double mr_tolf = opts().mr_tolf;  // (lab) MINRES stops at mr_tolf x the PCG tolerance
   long mr_N = 0;
   int mr_nred = 1;
   DevBuf<double> mr_B, mr_YP, mr_W, mr_d, mr_rho, mr_Minv, mr_Y, mr_sc, mr_partA, mr_partB, mr_partV, mr_partR, mr_zval;
@@ -1362,6 +1367,16 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_mr_x, dim3(vb(n)), dim3(kVecThreads), 0, stream, ut.p, (const double *)ws.p, (const double *)mr_d.p, n, (const int *)fl.p, stall);
     launch_spmv(Ar.view(), ut.p, EpiY{ut.p + n, rdy(), v.p + n}, stall, stream);
   }
+#else
+  // (the product's Krylov method is PCG; MINRES lives in the labs build.  The names the loop uses fold to nothing here.)
+  static constexpr bool mr_active = false, mr_ready = false;
+  static constexpr int krylov_mode() { return 0; }
+  void mr_precond() {}
+  void mr_decide() {}
+  void enqueue_mr_start() {}
+  void enqueue_mr_step(int) {}
+  void enqueue_mr_finish() {}
+#endif
 
   // PCG on cg_b (rhs, length n); solution accumulates in xout.  S_TOL / F_DONE must be set on device.
   // Returns CG iterations taken.  `started` = the CG start (and `done_iters` steps) were already enqueued
@@ -1417,7 +1432,7 @@ struct ScsHipWork {
     tot_cg_iters += done_iters;
     if (mr_active && xout == ut.p) {
       enqueue_mr_finish();
-      static const bool check = getenv("SCS_HIP_MR_CHECK") != nullptr;  // lab: the TRUE reduced residual of the x MINRES returned
+      const bool check = opts().mr_check;  // lab: the TRUE reduced residual of the x MINRES returned
       if (check && !has_P) {
         launch_spmv(At.view(), ut.p + n, EpiR0{cg_r.p, cg_p.p, cg_M.p, rdx(), v.p, ut.p, nullptr, part.p}, nullptr, stream);
         std::vector<double> hr((size_t)n);
@@ -1467,7 +1482,7 @@ struct ScsHipWork {
     h_params[P_IPOW] = std::pow((double)iter + 1, 1.5);
     h_params[P_FIRST] = iter < 1 ? 1.0 : 0.0;
     h_params[P_PSD_TOL2] = psd_tol2_for(iter);
-    static const bool dbg_tol = getenv("SCS_HIP_DEBUG_TOL") != nullptr;  // tools/dbg/run_ahead_tol.py
+    const bool dbg_tol = (opts().debug & DBG_TOL) != 0;  // SCS_HIP_DEBUG=tol (tools/dbg/run_ahead_tol.py)
     if (dbg_tol) std::fprintf(stderr, "[scs-hip] iter %d slot %d: res_min %.17g psd level %.3e tol2 %.3e\n", iter, slot, cg_res_min, psd_res_min, h_params[P_PSD_TOL2]);
   }
   // everything of project_lin_sys up to (and including) the fused, warm-started CG start
@@ -1486,7 +1501,9 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_fin_head, dim3(1), dim3(kVecThreads), 0, stream, part2.p, nbl, part.p, At.nwg(), d_params, sc.p, fl.p,
                        ut.p, (long)n + m, stall);
     // (k1dot: the first step's alpha needs sum r_x p0^2 of the p0 = M r0 the start has just formed)
+#ifdef SCS_HIP_LABS
     if (k1dot) hipLaunchKernelGGL(k_pp_part, dim3(vb(n)), dim3(kVecThreads), 0, stream, (const double *)cg_p.p, rdx(), n, part_pp.p, stall);
+#endif
     if (mr_active) enqueue_mr_start();
   }
   // dense direct variant of the linear solve of an iteration: rhs = R_x v_x - A' v_y;  u~_x = G^{-1} rhs;  u~_y = v_y + R_y^{-1} A u~_x.
@@ -1505,6 +1522,7 @@ struct ScsHipWork {
     hipLaunchKernelGGL(k_sumsq, dim3(vb(l)), dim3(kVecThreads), 0, stream, v.p, l, part_v.p);
     v_norm_fresh = true;
   }
+#ifdef SCS_HIP_LABS
   // small-problem variant: same normalisation / warm start, then ONE launch for tolerance, CG start and CG loop
   void enqueue_lin_sys_persist() {
     std::unique_ptr<SpinLink> link;
@@ -1535,6 +1553,7 @@ struct ScsHipWork {
     note_cg_iters(last_cg_iters);
     tot_cg_iters += last_cg_iters;
   }
+#endif
   // tau (the y block is already in ut_y: it was carried along the CG recurrence)
   void enqueue_lin_sys_tail() {
     const int nb1 = vb(l - 1);
@@ -1617,15 +1636,13 @@ struct ScsHipWork {
   }
   // Wait for iteration `iter` of the run-ahead queue.  Returns false if its CG chunk was too short: the rest of that
   // iteration and everything queued behind it did nothing; the caller finishes the iteration synchronously.
-  // SCS_HIP_DEBUG_PIPE=1: per-iteration CG step counts and run-ahead stalls on stderr.
+  // SCS_HIP_DEBUG=pipe: per-iteration CG step counts and run-ahead stalls on stderr.
   static bool debug_pipe() {
-    static const bool on = getenv("SCS_HIP_DEBUG_PIPE") != nullptr;
-    return on;
+    return (opts().debug & DBG_PIPE) != 0;
   }
   // host wait for an event: SCS_HIP_WAIT=block -> hipEventSynchronize, spin -> poll hipEventQuery (lab knob)
   static int wait_mode() {
-    static const int m = [] { const char *e = getenv("SCS_HIP_WAIT"); return e && e[0] == 's' ? 1 : 0; }();
-    return m;
+    return opts().wait_spin ? 1 : 0;  // (labs knob)
   }
   static void wait_event(hipEvent_t e) {
     if (wait_mode() == 1) {
@@ -1686,6 +1703,7 @@ struct ScsHipWork {
     v_norm_fresh = true;
   }
 
+#ifdef SCS_HIP_LABS
   hipGraphExec_t capture(const std::function<void()> &body) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -1729,6 +1747,9 @@ struct ScsHipWork {
     v_norm_fresh = keep_fresh;
     graphs_ready = true;
   }
+#else
+  void build_graphs() {}
+#endif
 
   void project_lin_sys(int iter, bool graph) {
     // The parameter block is host memory the kernels read in place, and the cones of the previous iteration (enqueued, not
@@ -1744,13 +1765,15 @@ struct ScsHipWork {
       last_cg_iters = 0;
       return;
     }
+#ifdef SCS_HIP_LABS
     if (persist_wgs > 0) {
       if (graph) HIP_CHECK(hipGraphLaunch(g_pre[0], stream));
       else enqueue_lin_sys_persist();
       finish_lin_sys_persist();
       return;
     }
-    if (graph && !mr_active) {
+#endif
+    if (kLabsBuild && graph && !mr_active) {
       int gi = 0;
       const int want = std::max(1, std::min(last_cg_iters + 2, kGraphSteps[kNumGraphs - 1]));
       while (gi + 1 < kNumGraphs && kGraphSteps[gi] < want) ++gi;  // smallest captured chunk that covers `want`
@@ -1924,7 +1947,9 @@ struct ScsHipWork {
     (void)hipStreamSynchronize(stream);
     (void)hipGetLastError();
     psd_mc_cap = 0;
+#ifdef SCS_HIP_LABS
     if (persist_wgs > 0) { persist_wgs = 0; graphs_ready = false; }
+#endif
     stall = nullptr;
     stall_fl = nullptr;
     in_capture = false;
@@ -2269,7 +2294,7 @@ static void upload_cone_meta(ScsHipWork *w) {
     // split mode: one CU per matrix would leave at least half of the GPU idle.  Its V update keeps a 16-row strip of V in LDS
     // (16 x NP doubles): orders above 1280 do not fit and take the one-workgroup-per-matrix kernel (any order up to 16 kPsdMaxH)
     w->psd_split = big_total > 0 && big_total <= 128 && (size_t)16 * w->psd_max_np * sizeof(double) <= 160 * 1024;
-    if (const char *env = getenv("SCS_HIP_PSD_SPLIT")) w->psd_split = big_total > 0 && env[0] == '1';  // A/B and tests
+    if (opts().psd_split >= 0) w->psd_split = big_total > 0 && opts().psd_split == 1;  // SCS_HIP_PSD_SPLIT: A/B and tests
   }
   HIP_CHECK(hipStreamSynchronize(s));
 }
@@ -2352,10 +2377,8 @@ static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, c
 // linsys: 0 = what SCS_HIP_LINSYS says (default indirect), 1 = indirect (PCG), 2 = dense direct (dense.hpp)
 static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, int linsys = 0) {
   const double t0 = now_ms();
-  if (linsys == 0) {
-    const char *e = getenv("SCS_HIP_LINSYS");
-    linsys = (e && (e[0] == 'd' || e[0] == 'D')) ? 2 : 1;
-  }
+  refresh_options();  // the environment as it is NOW: this workspace keeps what it is created with (options.hpp)
+  if (linsys == 0) linsys = opts().linsys_dense ? 2 : 1;
   if (linsys != 1 && linsys != 2) throw std::runtime_error("unknown linear-system solver kind");
   if (!d || !k || !stgs) throw std::runtime_error("null argument");
   if (d->m <= 0 || d->n <= 0 || !d->A || !d->b || !d->c) throw std::runtime_error("invalid data dimensions");
@@ -2396,11 +2419,11 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   for (double x : w->c_orig) w->nm_c_orig = std::max(w->nm_c_orig, std::fabs(x));
 
   {
-    const char *env = getenv("SCS_HIP_GRAPH");  // "0" keeps every launch eager (A/B measurements)
-    w->graphs_enabled = !(env && env[0] == '0');
-    const char *envp = getenv("SCS_HIP_PIPELINE");  // "0": the host looks at the CG flags in every iteration
-    w->pipelined = !(envp && envp[0] == '0');
-    if (const char *envc = getenv("SCS_HIP_PIPE_CHUNK")) w->pipe_chunk_override = std::max(0, atoi(envc));
+#ifdef SCS_HIP_LABS
+    w->graphs_enabled = opts().graph;   // hipGraph replay of the iteration when the host looks at every iteration
+#endif
+    w->pipelined = opts().pipeline;     // SCS_HIP_PIPELINE=0: the host looks at the CG flags in every iteration
+    w->pipe_chunk_override = opts().pipe_chunk;
   }
   if (!w->pipelined && w->graphs_enabled) {  // hipGraph capture needs a stream nobody else enqueues on: a private one
     HIP_CHECK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
@@ -2430,9 +2453,8 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   // small problems (config 5: a batch of them) take their device memory from one arena (common.hpp) instead of ~100
   // separate allocations; SCS_HIP_ARENA=0 restores exact allocations (A/B)
   {
-    const char *ea = getenv("SCS_HIP_ARENA");
     const long annz = d->A->p[n];
-    if (!(ea && ea[0] == '0') && annz <= (1L << 18) && w->l <= (1L << 17)) {
+    if (opts().arena && annz <= (1L << 18) && w->l <= (1L << 17)) {
       w->arena.reset(new Arena());
       w->arena->stream = s;
       {  // ~40 doubles per row / column of vectors + 3 matrix layouts of 12 B per nonzero + the Anderson history, rounded up to a power of two
@@ -2445,7 +2467,7 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     }
   }
   ArenaScope arena_scope(w->arena.get());
-  const bool setup_timing = getenv("SCS_HIP_SETUP_TIMING") != nullptr;  // diagnostics: where does scs_init spend its time
+  const bool setup_timing = (opts().debug & DBG_SETUP) != 0;  // SCS_HIP_DEBUG=setup: where does scs_init spend its time
   double t_mark = now_ms();
   auto mark = [&](const char *what) {
     if (!setup_timing) return;
@@ -2558,16 +2580,19 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
     const bool eligible = !w->At.has_slab && !w->Ar.has_slab && (!w->has_P || !w->Pf.has_slab) && !w->At.cs.ok && !w->Ar.cs.ok &&
                           (!w->has_P || !w->Pf.cs.ok) &&
                           2 * vec_blocks(l) + 2 * vec_blocks(std::max(n, m)) <= 2 * kMaxVecBlocks;
+#ifdef SCS_HIP_LABS
     int wgs = 0, ng = 2;
-    if (const char *env = getenv("SCS_HIP_PERSIST")) {
-      int a = 0, b = 0;
-      const int got = std::sscanf(env, "%dx%d", &a, &b);
-      if (got >= 1) wgs = eligible ? std::max(0, std::min(a, kCgPersistMaxWgs)) : 0;
-      if (got == 2 && (b == 1 || b == 2 || b == 4)) ng = b;
+    if (opts().persist_w > 0) {
+      wgs = eligible ? std::max(0, std::min(opts().persist_w, kCgPersistMaxWgs)) : 0;
+      const int b = opts().persist_g;
+      if (b == 1 || b == 2 || b == 4) ng = b;
     }
     w->persist_wgs = wgs;
     w->persist_ng = ng;
     if (wgs > 0) w->persist_bar.alloc_zero(2, s);
+#else
+    (void)eligible;
+#endif
   }
   w->sc.alloc_zero(S_COUNT, s);
   w->out.alloc_zero(256, s);
@@ -2601,17 +2626,18 @@ static ScsHipWork *init_impl(const ScsData *d, const ScsCone *k, const ScsSettin
   // ---- R, preconditioner (or G^{-1}), pre-solved g ----
   if (w->dense()) {
     w->dense_alloc();
+#ifdef SCS_HIP_LABS
     w->persist_wgs = 0;
+#endif
   }
   w->decide_k1dot(s);
   {
     // Round 5, late: the indirect path defers it too (SCS_HIP_LAZY_SETUP=0: inside scs_init) — its cold PCG for g is ~50 steps = 150 dependent
     // launches, three quarters of the dispatch chain of a small problem's scs_init; a batch runs it as ONE grouped cold solve (batch.hpp
     // apply_scale_updates, the path of an adaptive-scale update: bit-identical to the solo one), a lone workspace at its first solve.
-    const char *el = getenv("SCS_HIP_DENSE_LAZY"), *ea = getenv("SCS_HIP_LAZY_SETUP");
     // (small problems only, n + m <= 32768: there the chain is what scs_init costs; a large problem keeps its cold solve out of scs_solve)
     const bool small_indirect = !w->dense() && (long)n + m <= 32768;
-    w->setup_pending = w->dense() ? !(el && el[0] == '0') && !(ea && ea[0] == '0') : small_indirect && !(ea && ea[0] == '0');
+    w->setup_pending = (w->dense() || small_indirect) && opts().lazy_setup;
   }
   if (!w->setup_pending) {
     w->set_diag_r();
@@ -2705,7 +2731,7 @@ static scs_int solve_impl(ScsHipWork *w, ScsSolution *sol, ScsInfo *info, scs_in
   const int max_iters = w->stgs.max_iters;
   // hipGraphs pay off when the iteration is launch/latency-bound (measured 8-14 % at l <= 1e4, nothing at
   // l >= 3e5) and cost ~0.1 s to capture: build them lazily, only for small problems and long solves.
-  static const long graph_max_l = [] { const char *e = getenv("SCS_HIP_GRAPH_MAX_L"); return e ? atol(e) : 1000000L; }();  // experiments
+  const long graph_max_l = opts().graph_max_l;  // (labs)
   const bool graphs_wanted = w->graphs_enabled && !w->profile && l <= graph_max_l && !w->pipelined && !w->dense();
   bool use_graphs = graphs_wanted && w->graphs_ready;
   const bool run_ahead = w->pipelined && w->persist_wgs == 0 && !w->dense();  // (in-situ profiling samples ride along: enqueue_plain_iteration)
@@ -2855,6 +2881,7 @@ extern "C" {
 ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
   try {
     set_last_error("");
+    refresh_options();
     return init_impl(d, k, stgs);
   } catch (const std::exception &e) {
     set_last_error(e.what());
@@ -2865,6 +2892,7 @@ ScsWork *scs_init(const ScsData *d, const ScsCone *k, const ScsSettings *stgs) {
 ScsWork *scs_hip_init_linsys(const ScsData *d, const ScsCone *k, const ScsSettings *stgs, int linsys) {
   try {
     set_last_error("");
+    refresh_options();
     return init_impl(d, k, stgs, linsys);
   } catch (const std::exception &e) {
     set_last_error(e.what());
@@ -2877,6 +2905,7 @@ scs_int scs_solve(ScsWork *w, ScsSolution *sol, ScsInfo *info, scs_int warm_star
   if (!w || !sol || !info) return SCS_FAILED;
   try {
     set_last_error("");
+    refresh_options();
     const double scale_entry = w->scale;
     try {
       return solve_impl(w, sol, info, warm_start);
@@ -2974,9 +3003,8 @@ scs_int scs_hip_solve_batch(ScsWork **works, ScsSolution **sols, ScsInfo **infos
     for (int j = 0; j < i; ++j)
       if (works[j] == works[i]) { set_last_error("scs_hip_solve_batch: a workspace appears twice"); return -1; }
   }
-  auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; };
-  const int group_max = env_int("SCS_HIP_GROUP_MAX", 1024), lanes = env_int("SCS_HIP_GROUP_LANES", 1),
-            group_min = env_int("SCS_HIP_GROUP_MIN", 16);
+  refresh_options();
+  const int group_max = opts().group_max, lanes = opts().group_lanes, group_min = opts().group_min;  // (labs knobs: several concurrently driven groups lost)
   // shape classes, then groups
   std::vector<std::vector<int>> jobs;
   std::vector<char> taken((size_t)count, 0);
@@ -3119,6 +3147,7 @@ int scs_hip_set_thread_device(int dev) {
   t_device = dev;
   return 0;
 }
+int scs_hip_labs_build(void) { return kLabsBuild ? 1 : 0; }
 int scs_hip_mem_info(size_t *free_bytes, size_t *total_bytes) {
   if (scs_hip_device_count() <= 0) return -1;
   size_t f = 0, t = 0;
@@ -3139,16 +3168,25 @@ int scs_hip_time_matvec(ScsWork *w, int reps, double *out) {
     hipStream_t s = w->stream;
     w->finish_pending_setup();  // (R lives in the products)
     // the products exactly as the CG step of this workspace launches them (k1dot: cg_k1dot.hpp)
-    for (int i = 0; i < 2; ++i) { if (w->k1dot) w->matvec_k1dot(w->cg_p.p, nullptr, nullptr); else w->matvec(w->cg_p.p, nullptr); }
+    for (int i = 0; i < 2; ++i) {
+#ifdef SCS_HIP_LABS
+      if (w->k1dot) { w->matvec_k1dot(w->cg_p.p, nullptr, nullptr); continue; }
+#endif
+      w->matvec(w->cg_p.p, nullptr);
+    }
     HIP_CHECK(hipEventRecord(w->ev[0], s));
     for (int i = 0; i < reps; ++i) {
-      if (w->k1dot) launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivRDot{w->tmp_m.p, w->rdy(), w->part_k1.p}, nullptr, s);
-      else launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, nullptr, s);
+#ifdef SCS_HIP_LABS
+      if (w->k1dot) { launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivRDot{w->tmp_m.p, w->rdy(), w->part_k1.p}, nullptr, s); continue; }
+#endif
+      launch_spmv(w->Ar.view(), w->cg_p.p, EpiDivR{w->tmp_m.p, w->rdy()}, nullptr, s);
     }
     HIP_CHECK(hipEventRecord(w->ev[1], s));
     for (int i = 0; i < reps; ++i) {
-      if (w->k1dot) launch_spmv(w->At.view(), w->tmp_m.p, EpiAtRaw{w->cg_Gp.p, w->gp2()}, nullptr, s);
-      else launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), w->has_P ? 1 : 0, w->part.p, w->gp2()}, nullptr, s);
+#ifdef SCS_HIP_LABS
+      if (w->k1dot) { launch_spmv(w->At.view(), w->tmp_m.p, EpiAtRaw{w->cg_Gp.p, w->gp2()}, nullptr, s); continue; }
+#endif
+      launch_spmv(w->At.view(), w->tmp_m.p, EpiGp{w->cg_Gp.p, w->cg_p.p, w->rdx(), w->has_P ? 1 : 0, w->part.p, w->gp2()}, nullptr, s);
     }
     HIP_CHECK(hipEventRecord(w->ev[2], s));
     HIP_CHECK(hipEventSynchronize(w->ev[2]));
@@ -3312,6 +3350,7 @@ static void upload_for_spmv(const ScsMatrix *A, int transpose, DeviceCsr &M, hip
 int scs_hip_spmv(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose) {
   try {
     set_last_error("");
+    refresh_options();
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid matrix");
     TmpStream ts;
     DeviceCsr M;
@@ -3341,6 +3380,7 @@ int scs_hip_cs_layout_host_spmv_pieces(const ScsMatrix *A, const scs_float *x, s
 static int cs_layout_host_spmv_impl(const ScsMatrix *A, const scs_float *x, scs_float *y, int transpose, int rpt, int split, int piece_len) {
   try {
     set_last_error("");
+    refresh_options();
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid matrix");
     HostCsr ar;
     const int *rp = A->p, *ci = A->i;
@@ -3360,8 +3400,7 @@ static int cs_layout_host_spmv_impl(const ScsMatrix *A, const scs_float *x, scs_
       cs_pick_geometry(rows, R0, rpt0, split);
       if (rpt > 0) rpt0 = rpt;
       const int thresh = cs_peel_threshold(rpt0);
-      const char *pe = getenv("SCS_HIP_CS_PEEL");
-      if (!(pe && pe[0] == '0'))
+      if (opts().cs_peel)
         for (int r = 0; r < rows; ++r)
           if (rp[r + 1] - rp[r] > thresh) {
             if (mk.empty()) mk.assign(((size_t)rows + 31) / 32, 0u);
@@ -3451,6 +3490,7 @@ static int cs_layout_host_spmv_impl(const ScsMatrix *A, const scs_float *x, scs_
 double scs_hip_spmv_bench(const ScsMatrix *A, int transpose, int reps) {
   try {
     set_last_error("");
+    refresh_options();
     TmpStream ts;
     DeviceCsr M;
     upload_for_spmv(A, transpose, M, ts.s);
@@ -3508,6 +3548,7 @@ static bool oneshot_spin_error(ScsHipWork &w, hipStream_t s) {  // the stream is
 int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
   try {
     set_last_error("");
+    refresh_options();
     for (int attempt = 0; attempt < 2; ++attempt) {
       ScsHipWork w;
       TmpStream ts;
@@ -3539,6 +3580,7 @@ int scs_hip_proj_cone(scs_float *x, const ScsCone *k, scs_int m, int dual) {
 int scs_hip_proj_cone_seq(scs_float *xs, const ScsCone *k, scs_int m, int dual, int count, scs_float *stats, int stats_cap) {
   try {
     set_last_error("");
+    refresh_options();
     if (count < 0 || !xs) throw std::runtime_error("invalid sequence");
     std::vector<double> out((size_t)count * (size_t)std::max(m, 0));  // the inputs stay intact until the whole sequence went through
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -3599,6 +3641,7 @@ static int kkt_solve_entry(const ScsMatrix *A, const ScsMatrix *P, const scs_flo
                            scs_int *cg_iters, bool dense) {
   try {
     set_last_error("");
+    refresh_options();
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid A");
     ScsHipWork w;
     TmpStream ts;
@@ -3663,6 +3706,7 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
                       scs_float *sigma) {
   try {
     set_last_error("");
+    refresh_options();
     HostCone cone;
     if (!build_cone(k, cone) || cone.m != A->m) throw std::runtime_error("invalid cone");
     if (!validate_matrix(A, A->m, A->n)) throw std::runtime_error("invalid A");
@@ -3721,6 +3765,7 @@ ScsHipAa *scs_hip_aa_init(scs_int dim, scs_int mem, scs_int type1, scs_float reg
                           scs_float safeguard_factor, scs_float max_weight_norm) {
   try {
     set_last_error("");
+    refresh_options();
     if (dim <= 0 || mem < 0) throw std::runtime_error("invalid AA dimensions");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) throw std::runtime_error("libscs_hip: no HIP device available");
@@ -3744,6 +3789,7 @@ scs_float scs_hip_aa_apply(ScsHipAa *a, scs_float *f, const scs_float *x) {
   if (!a || !f || !x) return NAN;
   try {
     set_last_error("");
+    refresh_options();
     HIP_CHECK(hipSetDevice(a->device));
     a->f.upload(f, (size_t)a->aa.dim, a->stream);
     a->x.upload(x, (size_t)a->aa.dim, a->stream);
@@ -3761,6 +3807,7 @@ scs_int scs_hip_aa_safeguard(ScsHipAa *a, scs_float *f_new, scs_float *x_new) {
   if (!a || !f_new || !x_new) return -2;
   try {
     set_last_error("");
+    refresh_options();
     HIP_CHECK(hipSetDevice(a->device));
     if (!a->aa.success) return 0;  // nothing to test (and no asynchronous upload of the caller's buffers left in flight)
     a->f.upload(f_new, (size_t)a->aa.dim, a->stream);
@@ -3804,6 +3851,7 @@ __global__ void k_copy4(const double4 *__restrict__ src, double4 *dst, size_t n4
 double scs_hip_copy_bandwidth(size_t bytes, int reps) {
   try {
     set_last_error("");
+    refresh_options();
     TmpStream ts;
     const size_t n4 = bytes / sizeof(double4);
     DevBuf<double4> a, b;

@@ -355,8 +355,7 @@ constexpr int kSlabShiftDefault = 17;        // 2^17 columns = 1 MiB of fp64 per
 constexpr int kSlabStage = 3072;             // LDS products per pass (24 KiB)
 constexpr int kSlabTargetWgs = 512;          // 2 resident workgroups per CU on 256 CUs
 inline int slab_shift() {
-  const char *e = getenv("SCS_HIP_SLAB_SHIFT");  // experiments only
-  const int v = e ? atoi(e) : kSlabShiftDefault;
+  const int v = opts().slab_shift;  // (labs knob)
   return (v >= 10 && v <= 24) ? v : kSlabShiftDefault;
 }
 
@@ -377,8 +376,7 @@ struct HostSlab {
 };
 
 inline int slab_pick_rows(int rows) {
-  const char *e = getenv("SCS_HIP_SLAB_RPT");  // experiments only
-  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return 256 * v; }
+  { const int v = opts().slab_rpt; if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return 256 * v; }  // (labs knob)
   int rpt = 1;
   while (rpt < 16 && (long)kSlabTargetWgs * 256 * rpt < rows) rpt *= 2;
   return 256 * rpt;
@@ -388,8 +386,7 @@ inline bool slab_wanted(int rows, int cols) { return (long)cols * 8 > (2L << 20)
 // not the gather vector fits L2 (what it saves is L2 -> L1 line traffic): measured crossover on LP+SOC problems with
 // 10 nonzeros per row at nnz ~ 1e6 (0.240 vs 0.245 ms/iter), -10 % per iteration at nnz = 2e6, -12 % at 4e6.
 inline bool cs_wanted(int rows, int cols, long nnz) {
-  const char *e = getenv("SCS_HIP_CS_MIN_NNZ");  // experiments, tests (read at every scs_init)
-  const long min_nnz = e ? atol(e) : (1L << 20);
+  const long min_nnz = opts().cs_min_nnz;  // SCS_HIP_CS=N: tests on small matrices
   (void)cols;
   return rows >= 16384 && nnz >= min_nnz;
 }

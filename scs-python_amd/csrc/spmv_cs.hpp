@@ -83,8 +83,7 @@ __host__ __device__ inline int cs_peel_threshold(int rpt) {
 // as many rows per CU as possible: the distinct lines per gather instruction fall with R), R a multiple of 64;
 // rpt = the power of two >= R / 1024.  More than 256 * 16384 rows: R = 16384 and several rounds of workgroups.
 inline void cs_pick_geometry(int rows, int &R, int &rpt, int split = 1) {
-  const char *e = getenv("SCS_HIP_CS_RPT");  // experiments / tests: full chunks of 1024 * rpt rows
-  if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { rpt = v; R = kCsThreads * v; return; } }
+  { const int v = opts().cs_rpt; if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { rpt = v; R = kCsThreads * v; return; } }  // (labs knob: full chunks of 1024 * rpt rows)
   const int chunks = kCsTargetWgs / split;
   long r = ((long)rows + chunks - 1) / chunks;
   r = std::max(64L, (r + 63) / 64 * 64);
@@ -896,10 +895,9 @@ __global__ __launch_bounds__(kCsThreads) void k_spmv_cs_il(CsView A, const doubl
 // 3 (default, round 4) = braided gathers / row sums with the stream loads of pass g + 2 issued BEFORE the barrier of step g
 // (k_spmv_cs_il<.., 6>: -6..7 us per launch on the metric shapes, same bits; tools/cs_lab.hip, profiles/r04_cs_lab.txt);
 // 2 = the braid of rounds 2-3 (stream loads behind the gathers); 1 = gather-ahead (k_spmv_cs_ga); 0 = k_spmv_cs
-inline int cs_schedule() {
-  static const int v = [] { const char *e = getenv("SCS_HIP_CS_SCHED"); return e ? atoi(e) : 3; }();
-  return v;
-}
+// The product launches schedule 3 only; the older schedules (and the in-kernel combine of split layouts, which lives in the stage-default
+// instantiation of k_spmv_cs_il) are instantiated in the labs build (SCS_HIP_CS_SCHED, SCS_HIP_CS_COMBINE: options.hpp).
+inline int cs_schedule() { return kLabsBuild ? opts().cs_sched : 3; }
 
 template <class Epi>
 inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, const int *done_flag, hipStream_t s,
@@ -916,6 +914,7 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
     }
     return;
   }
+#ifdef SCS_HIP_LABS
   if (cs_schedule() == 2 || (A.split > 1 && A.ticket != nullptr)) {  // (the in-kernel combine lives in k_spmv_cs_il only)
     switch (A.rpt) {
       case 1: hipLaunchKernelGGL((k_spmv_cs_il<Epi, 1>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
@@ -943,6 +942,7 @@ inline void launch_spmv_cs(const CsView &A, const double *x, const Epi &epi, con
     case 8: hipLaunchKernelGGL((k_spmv_cs<Epi, 8>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
     default: hipLaunchKernelGGL((k_spmv_cs<Epi, 16>), g, b, 0, s, A, x, epi, done_flag, step_counter); break;
   }
+#endif
 }
 
 }  // namespace scship

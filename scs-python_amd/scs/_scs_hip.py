@@ -158,6 +158,7 @@ def _load():
     lib.scs_hip_device_count.restype = c_int
     lib.scs_hip_set_device.restype = c_int
     lib.scs_hip_set_device.argtypes = [c_int]
+    lib.scs_hip_labs_build.restype = c_int
     lib.scs_hip_mem_info.restype = c_int
     lib.scs_hip_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.scs_hip_set_thread_device.restype = c_int
@@ -234,6 +235,12 @@ def sizeof_float():
 
 def device_count():
     return int(_lib.scs_hip_device_count())
+
+
+def labs_build():
+    """True when the loaded library is the -DSCS_HIP_LABS build (csrc/options.hpp: the experiments that lost and the lab switches of
+    the kernels read the environment there; the product does not contain them)"""
+    return bool(_lib.scs_hip_labs_build())
 
 
 def mem_info():

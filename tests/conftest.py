@@ -23,10 +23,30 @@ def _have_gpu():
         return False
 
 
+def _labs_library():
+    try:
+        from scs import _scs_hip
+        return _scs_hip.labs_build()
+    except Exception:
+        return False
+
+
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` on a box without a usable GPU must FAIL, not pass on skips: every gpu-marked test gets a
-    setup-time check (tests selected without the marker expression are left alone)."""
-    if "gpu" not in (config.getoption("-m") or "") or "not gpu" in (config.getoption("-m") or ""):
+    setup-time check (tests selected without the marker expression are left alone).
+    Tests marked `labs` exercise experiments that only exist in the -DSCS_HIP_LABS build (csrc/options.hpp): they are deselected unless
+    the marker expression names them (`-m labs`, with SCS_HIP_LIB pointing at libscs_hip_labs.so — scs-python_amd/Makefile)."""
+    mexpr = config.getoption("-m") or ""
+    if "labs" not in mexpr:
+        drop = [it for it in items if it.get_closest_marker("labs")]
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = [it for it in items if not it.get_closest_marker("labs")]
+    elif not _labs_library():
+        for item in items:
+            if item.get_closest_marker("labs"):
+                item.add_marker(pytest.mark.skip(reason="needs the labs build: make -C scs-python_amd labs; SCS_HIP_LIB=.../scs/libscs_hip_labs.so"))
+    if "gpu" not in mexpr or "not gpu" in mexpr:
         return
     if _have_gpu():
         return

@@ -203,3 +203,14 @@ def cone_violation(v, K, dual=False):
         o += 3 * pw.size
     assert o == v.size, (o, v.size)
     return out
+
+
+def oracle_solve_many(oracle, jobs, workers=8):
+    """[oracle.solve(data, K, **kw) for (data, K, kw) in jobs], the solves running side by side in threads: the oracle is a plain C
+    library without global state and ctypes releases the GIL around it, so eight CPU solves of ~6 s take ~6 s on the GPU box's host
+    cores instead of ~50 (the GPU suite's wall time is mostly the checker's CPU time: VERDICT r05 weak 8).  Same solves, same answers."""
+    from concurrent.futures import ThreadPoolExecutor
+    oracle.lib()  # (loaded once, before the threads ask for it)
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(jobs)))) as pool:
+        futs = [pool.submit(oracle.solve, d, K, **kw) for d, K, kw in jobs]
+        return [f.result() for f in futs]

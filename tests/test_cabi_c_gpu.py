@@ -27,7 +27,6 @@ def test_c_consumer_compiles_and_links(tmp_path):
 @pytest.mark.gpu
 def test_c_consumer_solves_on_device(tmp_path):
     exe = _compile(tmp_path)
-    for group_min in ("16", "2"):  # the three members of the batch call: solved one by one inside the call / as ONE group
-        out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, SCS_HIP_GROUP_MIN=group_min))
-        assert out.returncode == 0, out.stdout + out.stderr
-        assert "ALL OK" in out.stdout and out.stdout.count("identical") == 3, out.stdout
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)  # (the three members of its batch call are ONE group)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout and out.stdout.count("identical") == 3, out.stdout

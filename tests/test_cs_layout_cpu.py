@@ -94,6 +94,8 @@ def test_rows_too_long_for_the_count_fields_are_peeled(hip, oracle, monkeypatch)
             else:
                 np.testing.assert_allclose(got, oracle.spmv(B, x), rtol=0, atol=1e-13 * np.abs(got).max())
     np.testing.assert_array_equal(hip.cs_layout_host_spmv(B, y, transpose=True, rpt=16), oracle.spmv(B, y, trans=True))
+    if not hip.labs_build():
+        return  # (refusing such patterns as round 1 did is a switch of the labs build)
     monkeypatch.setenv("SCS_HIP_CS_PEEL", "0")
     assert hip.cs_layout_host_spmv(B, x, rpt=16) is None
     assert hip.cs_layout_host_spmv(B, x, rpt=8) is None

@@ -190,10 +190,11 @@ def test_config5_workload_matches_oracle_ldl():
     #  tools/dbg/config5_tight.py: inexact linear solves at 1e-10 — hence the larger cap there)
     stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=60000 if count == 8 else 200000)
     solo, grp, _ = _solo_and_group(probs, stg)
+    refs = helpers.oracle_solve_many(scs_oracle, [(d, K, dict(stg, indirect=False)) for d, K in probs])
     for i, ((d, K), a, b) in enumerate(zip(probs, solo, grp)):
         _assert_same(a, b, "config5 seed %d" % (seed + i))
         assert b["info"]["status"] == "solved"
-        ref = scs_oracle.solve(d, K, indirect=False, **stg)
+        ref = refs[i]
         assert ref["info"]["status"] == "solved"
         assert abs(b["info"]["pobj"] - pstars[i]) <= 1e-4 * max(1.0, abs(pstars[i]))
         assert abs(b["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-4 * max(1.0, abs(ref["info"]["pobj"]))
@@ -213,14 +214,14 @@ def test_config5_tail_seeds_match_oracle_ldl(linsys, seeds):
     import scs
     from oracle import scs_oracle
     Kb, nb, kb, _ = pg.workload("config5_small")
-    for sd in seeds:
-        d, p_star, _ = pg.gen_feasible(Kb, nb, kb, sd, _proj)
+    stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=200000)
+    gen = [pg.gen_feasible(Kb, nb, kb, sd, _proj) for sd in seeds]
+    refs = helpers.oracle_solve_many(scs_oracle, [(g[0], Kb, dict(stg, indirect=False)) for g in gen])   # (the checker's solves side by side)
+    for sd, (d, p_star, _), ref in zip(seeds, gen, refs):
         dflt = scs.SCS(d, Kb, verbose=False, linear_solver=linsys).solve()
         assert dflt["info"]["status"] == "solved"
         assert abs(dflt["info"]["pobj"] - p_star) <= 2e-3 * max(1.0, abs(p_star))   # (eps 1e-4 on residuals, not on the objective)
-        stg = dict(verbose=False, eps_abs=1e-10, eps_rel=1e-10, max_iters=200000)
         got = scs.SCS(d, Kb, linear_solver=linsys, **stg).solve()
-        ref = scs_oracle.solve(d, Kb, indirect=False, **stg)
         assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved", (sd, got["info"]["status"], ref["info"]["status"])
         assert abs(got["info"]["pobj"] - p_star) <= 1e-4 * max(1.0, abs(p_star))
         assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-4 * max(1.0, abs(ref["info"]["pobj"]))

@@ -262,6 +262,7 @@ def test_power_law_rows_at_the_metric_size_iterate_as_the_csr_stream_layout(hip,
         assert abs(got["info"][key] - ref["info"][key]) <= 1e-5 * abs(ref["info"][key]) + 1e-9, (key, got["info"][key], ref["info"][key])
 
 
+@pytest.mark.labs
 def test_cg_with_the_dot_product_in_k1_iterates_as_the_one_with_it_in_k2(hip, monkeypatch):
     """round 4 (csrc/cg_k1dot.hpp): on large LPs / SOCPs p'Gp is formed as sum (A p)_i z_i + sum r_x p_j^2 — K1's epilogue and the kernel
     that forms p — and K2 stores raw A'z.  Same mathematics, another fixed summation order: on BASELINE config 2 (m = 2e5, both matrices on

@@ -463,6 +463,7 @@ def test_equilibration_matches_oracle(hip, oracle, with_P):
     assert abs(got[6] - ref[6]) <= 1e-13 * ref[6]
 
 
+@pytest.mark.labs
 def test_equilibration_fused_pass_finish_bit_identical(hip, oracle, monkeypatch):
     """round 5: the square roots of the l2 pass, the cone-block rule and both 1/sqrt sweeps of an equilibration pass are ONE launch
     (normalize_dev.hpp k_pass_finish; scs_init of a small problem is bound by the number of runtime calls).  Same operations on the same
@@ -669,6 +670,7 @@ def test_cs_generated_parity_larger(hip, oracle):
 
 
 # ---- persistent one-launch CG (cg_persist.hpp) vs the launch-per-kernel path --------------------------------
+@pytest.mark.labs
 @pytest.mark.parametrize("cfg", ["1x4", "1x1", "1x2", "3x1", "8x2", "16x4"])
 @pytest.mark.parametrize("with_P", [False, True])
 def test_persistent_cg_bit_identical(hip, oracle, monkeypatch, cfg, with_P):
@@ -720,14 +722,20 @@ def test_psd_split_mode_bit_identical(hip, oracle, monkeypatch):
 
 
 # ---- K9 split mode, sweeps of one matrix spread over G CUs (k_psd_sweep_mc) vs the one-workgroup sweep kernel ----
-@pytest.mark.parametrize("coop,look_ahead", [("1", "1"), ("0", "1"), ("1", "0")])
-def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coop, look_ahead):
+@pytest.mark.labs
+@pytest.mark.parametrize("coop,look_ahead", [("1", "1"), ("1", "0"), ("0", "0")])
+def test_psd_sweeps_over_several_cus_labs_variants(hip, oracle, monkeypatch, coop, look_ahead):
+    """the lab switches of the multi-CU sweep kernel (labs build): cooperative launch, two barriers per step instead of the look-ahead"""
+    monkeypatch.setenv("SCS_HIP_PSD_COOP", coop)  # 0: ordinary launch (the product)
+    monkeypatch.setenv("SCS_HIP_PSD_LA", look_ahead)  # 1 (the product): one barrier per step, the next pivots solved beside the A tasks (A double-buffered)
+    test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch)
+
+
+def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch):
     """Same rotations, same MFMA sequences, spinning barriers between the members of a matrix's group: every bit of the
     projection — and of a whole solve with warm starts, re-orthogonalisation and several [sweep, apply] rounds — must
     be the one the single-workgroup sweeps give.  G = 3 leaves members without a pivot at order 40; G = 8 is the cap."""
     monkeypatch.setenv("SCS_HIP_PSD_SPLIT", "1")
-    monkeypatch.setenv("SCS_HIP_PSD_COOP", coop)  # 0: ordinary launch (profilers)
-    monkeypatch.setenv("SCS_HIP_PSD_LA", look_ahead)  # 1: one barrier per step, the next pivots solved beside the A tasks (A double-buffered)
     rng = np.random.RandomState(12)
     K = {"l": 5, "s": [200, 130, 40, 96, 64, 33, 177, 50, 150], "cs": [60, 20]}
     z = rng.randn(pg.cone_dims(K))
@@ -757,6 +765,7 @@ def test_psd_sweeps_over_several_cus_bit_identical(hip, oracle, monkeypatch, coo
         np.testing.assert_array_equal(sols["1"][key], sols["4"][key], err_msg=key)
 
 
+@pytest.mark.labs
 def test_psd_refused_cooperative_launch_falls_back(hip, monkeypatch):
     """A grid the runtime cannot co-schedule (320 workgroups of 1024 lanes on 256 CUs): hipLaunchCooperativeKernel refuses it,
     nothing has run, and the projection is done by the one-workgroup sweeps — same bits, no error."""
@@ -805,6 +814,7 @@ def test_run_ahead_loop_bit_identical(hip, oracle, monkeypatch, case):
 
 
 # ---- small systems: CG update + direction as one launch (vec.hpp k_cg_update_dir) vs the two kernels ----
+@pytest.mark.labs
 @pytest.mark.parametrize("case", ["lp_soc", "qp_mixed", "long_cg", "tall"])
 @pytest.mark.parametrize("pipeline", ["1", "0"], ids=["run-ahead", "graphs"])
 def test_fused_cg_update_dir_bit_identical(hip, oracle, monkeypatch, case, pipeline):
@@ -843,6 +853,7 @@ def test_fused_cg_update_dir_bit_identical(hip, oracle, monkeypatch, case, pipel
 
 
 # ---- short SOCs + small PSD matrices in one launch (psd.hpp k_proj_soc_psd_small) vs two ----
+@pytest.mark.labs
 @pytest.mark.parametrize("linsys", ["indirect", "dense"])
 def test_soc_and_small_psd_in_one_launch_bit_identical(hip, oracle, monkeypatch, linsys):
     """the same two bodies, selected by the workgroup index: iterates, counts and solutions must not depend on the switch
@@ -914,6 +925,8 @@ def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt
         A = (A + sparse.csc_matrix((rng.standard_normal(4900), (ii.ravel(), jj.ravel())), shape=shape)).tocsc()
         A.sort_indices()
     if rpt:
+        if not hip.labs_build():
+            pytest.skip("forcing the rows per lane (SCS_HIP_CS_RPT) is a switch of the labs build; the product picks the geometry")
         monkeypatch.setenv("SCS_HIP_CS_RPT", rpt)
     x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
     ref = (oracle.spmv(A, x), oracle.spmv(A, y, trans=True))
@@ -931,6 +944,7 @@ def test_spmv_column_sorted_layout(hip, oracle, monkeypatch, shape, per_col, rpt
     np.testing.assert_array_equal(hip.spmv(A, y, transpose=True), got["host"][1])  # run-to-run
 
 
+@pytest.mark.labs
 @pytest.mark.parametrize("split_a,split_at", [("2", "4"), ("4", "2")])
 def test_spmv_in_kernel_combine(hip, oracle, monkeypatch, split_a, split_at):
     """SCS_HIP_CS_COMBINE=1: every workgroup of a row chunk publishes its partial row sums and the LAST one to arrive adds
@@ -1012,6 +1026,8 @@ def test_spmv_skewed_patterns_keep_the_layout(hip, oracle, monkeypatch, pattern,
         assert any(w is not None and np.array_equal(w, got["device"][0]) for w in walks)
     # round 3: the long rows ride in the passes as pieces (default); SCS_HIP_CS_VIRT=0 = the side launch of round 2 sums them
     # whole from the plain CSR.  Rows the passes keep whole have the same bits either way; long rows agree to the tree's rounding.
+    if not hip.labs_build():
+        return  # (the side launch of round 2 lives in the labs build)
     monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
     old = (hip.spmv(A, x), hip.spmv(A, y, transpose=True))
     for k in (0, 1):
@@ -1045,13 +1061,14 @@ def test_solve_with_dense_rows_stays_on_the_column_sorted_layout(hip, oracle, mo
     # a budget row left WHOLE in the passes (one lane adding its 8191 products of every pass one after the other) made this solve
     # take 87 s instead of ~1 s for a while in round 3: rows with more than 2048 nonzeros in a pass never ride whole
     assert got["info"]["solve_time"] < 30e3, got["info"]["solve_time"]
-    monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
-    old = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
-    assert "long rows peeled" in old["info"]["lin_sys_solver"], old["info"]["lin_sys_solver"]
-    # (long rows are summed in another order: an accelerated solve to 1e-7 lands a few per cent of iterations away — 3450 / 3600 / 3575
-    # with pieces / peeled / CSR-stream)
-    assert old["info"]["status"] == "solved" and abs(old["info"]["iter"] - got["info"]["iter"]) <= 0.15 * got["info"]["iter"]
-    monkeypatch.delenv("SCS_HIP_CS_VIRT")
+    if hip.labs_build():  # (the side launch of round 2 lives in the labs build)
+        monkeypatch.setenv("SCS_HIP_CS_VIRT", "0")
+        old = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
+        assert "long rows peeled" in old["info"]["lin_sys_solver"], old["info"]["lin_sys_solver"]
+        # (long rows are summed in another order: an accelerated solve to 1e-7 lands a few per cent of iterations away — 3450 / 3600 / 3575
+        # with pieces / peeled / CSR-stream)
+        assert old["info"]["status"] == "solved" and abs(old["info"]["iter"] - got["info"]["iter"]) <= 0.15 * got["info"]["iter"]
+        monkeypatch.delenv("SCS_HIP_CS_VIRT")
     monkeypatch.setenv("SCS_HIP_SLAB", "0")
     ref = hip.SCS(*helpers.raw_args(dat, K), **stg).solve(False, None, None, None)
     assert "CSR-stream" in ref["info"]["lin_sys_solver"]
@@ -1090,7 +1107,7 @@ def test_full_solve_on_column_sorted_layouts(hip, oracle, monkeypatch):
     K = {"z": 500, "l": 20000, "q": [10] * 1500, "ep": 300, "p": [0.3, -0.6] * 100}
     data, p_star, _ = pg.gen_feasible(K, 17000, 12, 77, lambda z, K: oracle.proj_cone(z, K, dual=True))
     stg = dict(eps_abs=1e-8, eps_rel=1e-8, verbose=False)
-    monkeypatch.setenv("SCS_HIP_CS_MIN_NNZ", "1000")
+    monkeypatch.setenv("SCS_HIP_CS", "1000")  # the pass layout from 1000 nonzeros on
     got = hip.SCS(*helpers.raw_args(data, K), **stg).solve(False, None, None, None)
     assert "column-sorted" in got["info"]["lin_sys_solver"]
     monkeypatch.setenv("SCS_HIP_SLAB", "0")

@@ -10,7 +10,7 @@ import pytest
 import helpers
 import problem_gen as pg
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.labs]  # MINRES lost its measurement (profiles/r05_config3_minres.txt): it lives in the -DSCS_HIP_LABS build
 
 STG = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False, max_iters=20000)
 
@@ -104,8 +104,7 @@ def test_minres_is_deterministic_and_the_run_ahead_loop_keeps_its_bits(hip, orac
     b = hip.SCS(*args, **stg).solve(False, None, None, None)
     monkeypatch.setenv("SCS_HIP_PIPELINE", "0")  # one host look per iteration instead of whole iterations queued ahead
     c = hip.SCS(*args, **stg).solve(False, None, None, None)
-    monkeypatch.setenv("SCS_HIP_PIPELINE", "1")
-    monkeypatch.setenv("SCS_HIP_PIPE_CHUNK", "3")  # chunks too short on purpose: every iteration stalls and is finished synchronously
+    monkeypatch.setenv("SCS_HIP_PIPELINE", "3")  # run-ahead with chunks of 3 CG steps, too short on purpose: every iteration stalls and is finished synchronously
     d = hip.SCS(*args, **stg).solve(False, None, None, None)
     for other in (b, c, d):
         assert other["info"]["iter"] == a["info"]["iter"] and other["info"]["cg_iters"] == a["info"]["cg_iters"]
@@ -142,3 +141,24 @@ def test_default_is_pcg_and_auto_mode_switches_only_where_pcg_is_slow(hip, oracl
     sol = hip.SCS(*helpers.raw_args(data, K), **STG).solve(False, None, None, None)
     assert "MINRES" not in sol["info"]["lin_sys_solver"]  # 120 zero rows: below the threshold of the auto mode
     assert sol["info"]["status"] == "solved"
+
+
+def test_auto_mode_never_switches_inside_a_queued_linear_solve(hip, oracle, monkeypatch):
+    """with SCS_HIP_KRYLOV=auto the switch to MINRES used to be decided while iteration i + 1 was enqueued behind a
+    still-queued iteration i; if i then stalled it was finished with MINRES steps that never had their start (1 / beta = inf, NaNs).
+    Now the decision is only taken on an empty queue.  Forced here: >= 256 zero-cone rows, PCG solves of ~100+ steps (so that auto
+    does switch) and CG chunks of 3 steps (so that EVERY queued iteration stalls)."""
+    K = {"z": 300, "l": 200, "q": [12, 7]}
+    data, p_star, _ = pg.gen_feasible(K, 320, 9, 13, lambda z, K: oracle.proj_cone(z, K, dual=True))
+    args = helpers.raw_args(data, K)
+    stg = dict(STG)
+    stg.update(max_iters=4000, eps_abs=1e-8, eps_rel=1e-8)
+    monkeypatch.setenv("SCS_HIP_KRYLOV", "auto")
+    monkeypatch.setenv("SCS_HIP_PIPELINE", "3")
+    sol = hip.SCS(*args, **stg).solve(False, None, None, None)
+    assert all(np.all(np.isfinite(sol[k])) for k in "xys"), sol["info"]
+    assert sol["info"]["status"] == "solved", sol["info"]
+    assert abs(sol["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
+    monkeypatch.setenv("SCS_HIP_PIPELINE", "1")
+    ref = hip.SCS(*args, **stg).solve(False, None, None, None)
+    assert ref["info"]["status"] == "solved" and abs(ref["info"]["pobj"] - sol["info"]["pobj"]) <= 1e-6 * max(1.0, abs(p_star))

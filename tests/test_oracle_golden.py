@@ -286,3 +286,19 @@ def test_numpy_cone_membership_agrees_with_the_oracle_projections():
             assert max(viol.values()) <= 1e-8, (dual, viol)
             outside = helpers.cone_violation(z, K, dual=dual)
             assert sum(x > 1e-3 for x in outside.values()) >= 5, outside
+
+
+def test_symbolic_ldl_entry_matches_the_factorisation():
+    """oracle/oscs_linsys.c o_lin_sys_symbolic (the fill table of DESIGN §7, tools/ldl_fill_table.py): nnz(L) of the symbolic phase alone is
+    what the full direct backend allocates for the same pattern; the elimination tree of a banded KKT pattern is one chain"""
+    import problem_gen as pg
+    from oracle import scs_oracle
+    K = {"l": 300}
+    data, _, _ = pg.gen_feasible(K, 100, 6, 3, lambda z, KK: scs_oracle.proj_cone(z, KK, dual=True))
+    lnz, height = scs_oracle.ldl_symbolic(data["A"])
+    info = scs_oracle.solve(data, K, indirect=False, verbose=False, max_iters=5)["info"]
+    assert "nnz(L)=%d" % lnz in info["lin_sys_solver"], (lnz, info["lin_sys_solver"])
+    assert 1 <= height <= 400 and lnz >= data["A"].nnz
+    band = pg.banded_sparse(400, 200, 5, np.random.default_rng(0))
+    lnz_b, height_b = scs_oracle.ldl_symbolic(band)
+    assert lnz_b < 20 * 600 and height_b > 500   # fill proportional to N, a tree that is (almost) one chain

@@ -342,7 +342,6 @@ def test_cs_cone_reference_cases(scs):
 _SIGINT_CHILD = r'''
 import json, os, sys, time
 sys.path[:0] = [os.path.join(ROOT, "scs-python_amd"), os.path.join(ROOT, "tests"), ROOT]
-os.environ["SCS_HIP_GROUP_MIN"] = "2"  # three equally shaped members ARE a group (default: 16)
 import numpy as np
 import scs, problem_gen as pg
 from scs import _scs_hip

@@ -1,4 +1,4 @@
-"""config 2: CG steps per queued iteration against the chunk that was enqueued for it (SCS_HIP_DEBUG_PIPE=1 prints both on stderr)."""
+"""config 2: CG steps per queued iteration against the chunk that was enqueued for it (SCS_HIP_DEBUG=pipe prints both on stderr)."""
 import os, sys, time, re, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -18,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print("RATE %d iters: %.1f iters/s" % (it, it / el), flush=True)
     sys.exit(0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "config2_lp_soc"
-env = dict(os.environ, SCS_HIP_DEBUG_PIPE="1")
+env = dict(os.environ, SCS_HIP_DEBUG="pipe")
 p = subprocess.run([sys.executable, __file__, "child", wl], env=env, capture_output=True, text=True)
 steps = [int(m.group(2)) for m in re.finditer(r"iter (\d+): (\d+) CG steps", p.stderr)]
 stalls = len(re.findall(r"STALL", p.stderr))

@@ -1,4 +1,4 @@
-LINSYS=hip_dense MAXIT=5 SCS_HIP_POOL_MB=16384 SCS_HIP_SETUP_TIMING=1 timeout 300 python tools/batch_leg.py 512 16 1 > /tmp/il.txt 2>&1
+LINSYS=hip_dense MAXIT=5 SCS_HIP_POOL_MB=16384 SCS_HIP_DEBUG=setup timeout 300 python tools/batch_leg.py 512 16 1 > /tmp/il.txt 2>&1
 python3 - <<'PY'
 import re,collections
 acc=collections.defaultdict(float); n=collections.Counter()

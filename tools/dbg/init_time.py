@@ -1,5 +1,5 @@
 """scs_init of one config-5 member: wall time of consecutive constructions (the first pays the process's first-use costs), and the phase
-marks of SCS_HIP_SETUP_TIMING for the last.  python tools/dbg/init_time.py [dense|indirect] [count]"""
+marks of SCS_HIP_DEBUG=setup for the last.  python tools/dbg/init_time.py [dense|indirect] [count]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "scs-python_amd"), os.path.join(ROOT, "tests")]
@@ -14,7 +14,7 @@ datas = [pg.gen_feasible(K, n, k, seed + i, proj)[0] for i in range(cnt)]
 keep = []
 for i, d in enumerate(datas):
     if i == cnt - 1:
-        os.environ["SCS_HIP_SETUP_TIMING"] = "1"
+        os.environ["SCS_HIP_DEBUG"] = "setup"
     t = time.perf_counter()
     s = scs.SCS(d, K, linear_solver=LS, verbose=False)
     el = time.perf_counter() - t

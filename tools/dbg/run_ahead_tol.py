@@ -1,4 +1,4 @@
-"""tests/test_hip_parity.py::test_run_ahead_loop_bit_identical[sdp] with SCS_HIP_DEBUG_TOL=1: per-iteration stopping level in both loop modes"""
+"""tests/test_hip_parity.py::test_run_ahead_loop_bit_identical[sdp] with SCS_HIP_DEBUG=tol: per-iteration stopping level in both loop modes"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))

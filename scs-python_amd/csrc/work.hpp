@@ -1,0 +1,464 @@
+// work.hpp — ScsHipWork: the workspace behind the C-ABI handle (device buffers, cone metadata and launches, spin chain, per-solve state); its member functions continue in the .inl files included at the end of the struct
+// (one of the units csrc/scs_hip.hip is assembled from — ONE translation unit, in this order: runtime.hpp, device_csr.hpp, work.hpp
+// [+ work_linsys.inl, work_admm.inl, work_residuals.inl, work_solve_ends.inl], io.hpp, setup.hpp, loop.hpp, batch.hpp, the C ABI in scs_hip.hip,
+// lab_entries.hpp; split out of the 3 800-line file of rounds 1-5 in round 6 — VERDICT r05 item 6 — without moving a line of code)
+#pragma once
+using namespace scship;
+
+static void write_csv_row(FILE *f, int iter, const Residuals &r, double scale, const double *diffs, double aa_norm,
+                          double time_s);
+
+// A spinning multi-workgroup kernel (k_psd_sweep_mc, k_cg_persist) gave up at a barrier: scs_solve restarts the solve without them
+struct SpinTimeout : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+static std::atomic<long> g_spin_fallbacks{0};  // scs_hip_spin_fallbacks(): tests
+// Spinning kernels need ALL their workgroups on the device at once.  One workspace alone sizes its grid for that; two workspaces of a
+// device that launch such grids on different streams at the same time (threads with their own SCS objects: R:test/test_thread_safety.py:78-93)
+// could each get half of theirs placed and wait for the other half for good.  So inside a process the spinning launches of a device
+// form a chain: once more than one workspace of the device uses them, each launch waits for the event recorded behind the previous one
+// (hipStreamWaitEvent: nothing on the host waits) and leaves its own.  A lone user pays nothing.
+struct SpinChain {
+  std::mutex mu;
+  int users = 0;
+  hipEvent_t last = nullptr;
+  hipStream_t last_stream = nullptr;
+};
+static SpinChain &spin_chain(int device) {
+  static SpinChain c[64];
+  return c[device & 63];
+}
+
+// ============================================================== workspace
+struct ScsHipWork {
+  // first member = destroyed last: ends the window in which this workspace's device blocks go to the block pool (common.hpp DevPool)
+  struct PoolWindowEnd {
+    bool armed = false;
+    ~PoolWindowEnd() { if (armed) --t_pool_release; }
+  } pool_window_end;
+  std::unique_ptr<Arena> arena;  // small problems: all device buffers of the workspace come from here (FIRST member: destroyed last)
+  int device = 0;  // the HIP device this workspace (stream, buffers, events) lives on
+  int n = 0, m = 0;
+  long l = 0;
+  ScsSettings stgs{};
+  double scale = 0.1;
+  HostCone cone;
+  HostScaling scal;
+  bool normalized = false, has_P = false;
+  std::vector<double> b_orig, c_orig;
+  double nm_b_orig = 0, nm_c_orig = 0;
+  double setup_time = 0;
+  std::string log_csv_filename, write_data_filename;
+
+  hipStream_t stream = nullptr;
+  bool owns_stream = true, pooled_stream = false, stream_shared = false;
+  void *pinned_block = nullptr;  // all pinned host scalars / flags of the workspace (g_pinned)
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  double *h_pin = nullptr;  // pinned scalars
+  int *h_flags = nullptr;   // pinned flags
+  double *h_params = nullptr, *d_params = nullptr;  // mapped pinned per-iteration scalars (P_*), slot in use (2 slots)
+  double *h_params_base = nullptr, *d_params_base = nullptr;
+  // run-ahead mode (see F_STALL in vec.hpp): plain iterations are enqueued whole and one ahead of the host's view
+  bool pipelined = false;
+  int pipe_chunk_override = 0, pipe_stalls = 0;  // tests: SCS_HIP_PIPELINE=N forces CG chunks of N steps (=> stalls)
+  const int *stall = nullptr;      // fl + F_STALL while a run-ahead iteration is being enqueued, else nullptr
+  int *stall_fl = nullptr;         // fl (or nullptr): k_tau_dots raises the stall, k_cone_pre parks the CG kernels
+  int *h_flags_slot[2] = {nullptr, nullptr};
+  hipEvent_t ev_iter[2] = {nullptr, nullptr};
+  hipEvent_t ev_prof[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // in-situ K1/K2 samples of the run-ahead loop
+  int prof_step[2] = {-1, -1};  // CG step (0-based) bracketed by ev_prof[slot], -1 = none
+  hipEvent_t ev_cone[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // in-situ: the cone kernels of a queued iteration
+  bool cone_sampled[2] = {false, false};
+  double prof_cone_ms = 0;
+  long prof_cone_n = 0;
+
+  // hipGraphs of the launch-bound inner loop (built lazily at the first solve):
+  //   g_pre[i] : iterate normalisation, rhs, CG start + kGraphSteps[i] CG steps + flag read-back
+  //   g_cg[i]  : kGraphSteps[i] further CG steps + flag read-back
+  //   g_post   : y recovery, tau, cone projections, dual update (iterations without a convergence check)
+  static constexpr int kNumGraphs = 5;
+  const int kGraphSteps[kNumGraphs] = {1, 2, 4, 8, 16};
+  hipGraphExec_t g_pre[kNumGraphs] = {}, g_cg[kNumGraphs] = {}, g_post = nullptr;
+  bool graphs_ready = false;
+#ifdef SCS_HIP_LABS
+  bool graphs_enabled = true;
+#else
+  static constexpr bool graphs_enabled = false;  // (hipGraph replay lives in the labs build: 5 % slower than eager launches at config 2)
+#endif
+  // small problems: the whole PCG solve of an iteration is one persistent launch (cg_persist.hpp)
+#ifdef SCS_HIP_LABS
+  int persist_wgs = 0, persist_ng = 1;  // 0 = launch-per-kernel path
+  DevBuf<unsigned> persist_bar;
+#else
+  static constexpr int persist_wgs = 0, persist_ng = 1;  // (the persistent kernel lives in the labs build: never faster than launch-per-kernel)
+#endif
+
+  DeviceCsr At;  // CSR(A') == caller's CSC(A): rows n, cols m   (x-space outputs)
+  DeviceCsr Ar;  // CSR(A): rows m, cols n                        (y-space outputs)
+  DeviceCsr Pf;  // full symmetric CSR(P)
+  DevBuf<double> Pdiag;
+
+  DevBuf<double> v, v_prev, u, ut, rsk, g, h, diag_r, D, E, Dinv, Einv;
+  DevBuf<double> cg_b, cg_p, cg_r, cg_Gp, cg_M, tmp_m, ws, px;
+  DevBuf<double> part, part2, sc, out;  // part2: partials of k_cg_update (read by k_cg_dir while `part` is reused), of k_prep
+  DevBuf<double> part_v;                // sum-of-squares partials of v for the next k_prep
+  bool v_norm_fresh = false;
+  DevBuf<int> fl;
+  DevBuf<double> solx, soly, sols;
+  bool sol_on_device = false;  // solx/soly/sols hold the final (x, y, s) of the last solve
+  // large solutions leave through a pinned mirror owned by the workspace (the caller's arrays are never handed to the runtime,
+  // see scs_hip_runtime_env): three DMA copies in flight, each array moved on by a few host threads as soon as it has landed
+  double *sol_pin = nullptr;
+  bool sol_pin_refused = false;
+  hipEvent_t sol_ev[3] = {nullptr, nullptr, nullptr};
+  static constexpr size_t kSolMirrorMin = (size_t)1 << 20;  // bytes of x | y | s from which the mirror is used
+  static void spread_memcpy(void *dst, const void *src, size_t bytes) {
+    const int nt = bytes >= ((size_t)8 << 20) ? 4 : 1;
+    if (nt == 1) { std::memcpy(dst, src, bytes); return; }
+    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    for (int t = 1; t < nt; ++t) {
+      const size_t o = std::min(bytes, part * t), c = std::min(bytes - o, part);
+      th[t - 1] = std::thread([=] { if (c) std::memcpy((char *)dst + o, (const char *)src + o, c); });
+    }
+    std::memcpy(dst, src, std::min(bytes, part));
+    for (int t = 1; t < nt; ++t) th[t - 1].join();
+  }
+  void ensure_solution_mirror() {  // (scs_init calls this: pinning 40 MB costs milliseconds)
+    const size_t bytes = sizeof(double) * ((size_t)n + 2 * (size_t)m);
+    if (sol_pin || sol_pin_refused || bytes < kSolMirrorMin) return;
+    if (hipHostMalloc((void **)&sol_pin, bytes, hipHostMallocDefault) != hipSuccess) {  // (no pinned memory left: the runtime's own staging)
+      (void)hipGetLastError();
+      sol_pin = nullptr;
+      sol_pin_refused = true;
+      return;
+    }
+    for (auto &e : sol_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  void download_solution(ScsSolution *sol) {
+    ensure_solution_mirror();
+    if (!sol_pin) {
+      solx.download(sol->x, n, stream);
+      soly.download(sol->y, m, stream);
+      sols.download(sol->s, m, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      return;
+    }
+    double *hx = sol_pin, *hy = sol_pin + n, *hs = sol_pin + n + m;
+    solx.download(hx, n, stream); HIP_CHECK(hipEventRecord(sol_ev[0], stream));
+    soly.download(hy, m, stream); HIP_CHECK(hipEventRecord(sol_ev[1], stream));
+    sols.download(hs, m, stream); HIP_CHECK(hipEventRecord(sol_ev[2], stream));
+    HIP_CHECK(hipEventSynchronize(sol_ev[0])); spread_memcpy(sol->x, hx, sizeof(double) * n);
+    HIP_CHECK(hipEventSynchronize(sol_ev[1])); spread_memcpy(sol->y, hy, sizeof(double) * m);
+    HIP_CHECK(hipEventSynchronize(sol_ev[2])); spread_memcpy(sol->s, hs, sizeof(double) * m);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  int part_len = 0;
+
+  // cones
+  DevBuf<int> soc_off, soc_dim, soc_big;
+  int n_soc = 0, n_soc_big = 0, soc_G = 64;  // soc_G: lanes per cone in k_proj_soc_wave (cones.hpp soc_group)
+  DevBuf<double> pow_a, box_bl, box_bu;
+  DevBuf<double> box_bl_orig, box_bu_orig, box_parts;
+  DevBuf<unsigned> cg_ticket;  // k_cg_update_dir's arrival counter (0 between launches)
+  DevBuf<unsigned> box_ticket;  // the caller's bounds (the working copies follow the row scaling): footer diagnostics
+  DevBuf<int> psd_off, psd_order;    // orders > kPsdSmallMax first (n_psd_big of them), then the small ones
+  DevBuf<long> psd_woff;
+  std::vector<long> psd_woff_h;  // host copies (scs_hip_psd_refine_stats)
+  std::vector<int> psd_order_h;
+  DevBuf<double> psd_scratch;
+  int n_psd = 0, n_psd_big = 0;
+  // split mode of the block kernel (psd.hpp): worth it when the large matrices alone leave most CUs idle
+  static constexpr int kPsdSplitRounds = 2;  // x kPsdLogSweeps = 6 sweeps: a cold start needs ~9; the LAST round is the one behind the refinement stage
+  bool psd_split = false;
+  int psd_max_np = 0, psd_max_tiles = 0;
+  // complex PSD cones: projected through the packed 2k x 2k real embedding held in cs_stage (psd.hpp)
+  DevBuf<int> cs_off, cs_order, cs_poff, cs_porder;  // same ordering: embeddings of order > kPsdSmallMax first
+  DevBuf<long> cs_soff, cs_woff;
+  DevBuf<double> cs_stage;
+  int n_cs = 0, n_cs_big = 0;
+
+  // batched PSD projection of `count` packed matrices (the first `big` of order > kPsdSmallMax): K9 + its one-wave variant
+  void launch_psd(double *base, const int *off, const int *order, const long *woff, int count, int big) {
+    if (big > 0) {
+      PsdBatch B{off, order, woff, big};
+      if (psd_split) {
+        // few large matrices: sweeps (A only) -> V updates over 16-row strips on the idle CUs -> reconstruction
+        const int gper = psd_gemm_tasks(std::max(psd_max_tiles, 1));  // tasks (= workgroups of one wavefront) per matrix, dealt to the XCDs in runs
+        const dim3 gg(psd_gemm_grid(gper, big)), gb(kPsdGemmThreads);
+        const dim3 gt(psd_xcd_grid(std::max(psd_max_tiles, 1), big));
+        // front: unpack, V = I / V' on many CUs; orders 0 / 1 and the periodic re-orthogonalisation of V in the one-workgroup kernel
+        hipLaunchKernelGGL(k_psd_front, gt, dim3(kPsdFrontThreads), 0, stream,
+                           (const double *)base, B, psd_scratch.p, psd_warm, stall);
+        hipLaunchKernelGGL(k_proj_psd<3>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
+                           psd_refine_default(false), 0);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_G2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+        int mc = (in_capture || !fl.p) ? 1 : psd_mc_members(big);  // (the multi-CU kernel polls the workspace's error flag at its barriers)
+        PsdRefineCfg R = psd_refine;
+        if ((size_t)32 * psd_max_np * sizeof(double) > 160 * 1024) R.on = 0;  // k_psd_apply_q keeps two 16-row strips in LDS
+        std::unique_ptr<SpinLink> link;
+        if (mc > 1) link.reset(new SpinLink(this));  // spinning launches of this device, one grid at a time (SpinChain)
+        for (int round = 0; round < kPsdSplitRounds; ++round) {
+          const int post = (R.on && round == kPsdSplitRounds - 1) ? 1 : 0;
+          if (post) {
+            // the refinement stage (psd.hpp psd_stop_test): matrices the sweeps left REFINABLE get the mixed-sign part of S = V'AV
+            // removed by GEMMs; the round behind it re-tests them (and goes on sweeping whatever is not done: nothing is lost)
+            hipLaunchKernelGGL(k_psd_gemm<PSD_COMM>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_KK>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_T>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_gemm<PSD_S1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+            hipLaunchKernelGGL(k_psd_apply_q, gt, dim3(kPsdApplyThreads), (size_t)32 * psd_max_np * sizeof(double), stream, B,
+                               psd_scratch.p, stall);
+          }
+          if (mc > 1) {  // sweeps of one matrix over `mc` CUs (k_psd_sweep_mc): cooperative launch, spinning barriers
+            double *scr = psd_scratch.p;
+            int G = mc, rnd = round;
+            int *err = fl.p + F_PERSIST_ERR;
+            const int *st = stall;
+            int la = psd_mc_look_ahead;
+            const double *tl = psd_tol2;
+            PsdRefineCfg Rr = R;
+            int pst = post;
+            long budget = spin_budget;
+            void *args[] = {&B, &scr, &rnd, &G, &la, &err, &st, &tl, &Rr, &pst, &budget};
+            if (psd_mc_coop) {
+              const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_psd_sweep_mc), dim3((unsigned)psd_mc_grid(big, mc)),
+                                                             dim3(kPsdThreads), args, (unsigned)kPsdMcLdsBytes, stream);
+              if (e != hipSuccess) {  // the runtime cannot co-schedule the grid (it only refuses the FIRST round: nothing ran yet)
+                (void)hipGetLastError();
+                if (round > 0) HIP_CHECK(e);
+                psd_mc_cap = 0;  // from now on: one workgroup per matrix
+                mc = 1;
+              }
+            } else  // SCS_HIP_PSD_COOP=0: ordinary launch (rocprofv3 7.2 crashes at exit after a cooperative launch)
+              hipLaunchKernelGGL(k_psd_sweep_mc, dim3((unsigned)psd_mc_grid(big, mc)), dim3(kPsdThreads), kPsdMcLdsBytes, stream, B, scr, rnd, G,
+                                 la, err, st, tl, Rr, pst, budget);
+          }
+          if (mc <= 1)
+          hipLaunchKernelGGL(k_proj_psd<1>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, round, stall, psd_tol2,
+                             R, post);
+          hipLaunchKernelGGL(k_psd_apply_v, gt, dim3(kPsdApplyThreads), (size_t)16 * psd_max_np * sizeof(double),
+                             stream, B, psd_scratch.p, stall);
+        }
+        link.reset();
+        hipLaunchKernelGGL(k_psd_fmap, gt, dim3(256), 0, stream, B, psd_scratch.p, stall);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R1>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+        hipLaunchKernelGGL(k_psd_gemm<PSD_R2>, gg, gb, 0, stream, base, B, psd_scratch.p, psd_warm, stall, gper);
+      } else {
+        hipLaunchKernelGGL(k_proj_psd<0>, dim3(big), dim3(kPsdThreads), kPsdLdsBytes, stream, base, B, psd_scratch.p, psd_warm, 0, stall, psd_tol2,
+                           psd_refine_default(false), 0);
+      }
+    }
+    if (count > big) {
+      PsdBatch B{off + big, order + big, woff + big, count - big};
+      if (psd_small_one_wave)
+        hipLaunchKernelGGL(k_proj_psd_small, dim3(count - big), dim3(64), 0, stream, base, B, psd_scratch.p, psd_warm, stall, psd_tol2);
+      else
+        hipLaunchKernelGGL(k_proj_psd_small4, dim3(count - big), dim3(kPsdSmallThreads), 0, stream, base, B, psd_scratch.p, psd_warm, stall,
+                           psd_tol2);
+    }
+  }
+  // Members (CUs) per matrix for the split-mode sweeps: as many as fit when every matrix gets the same number and a
+  // group stays inside one XCD (grid = 8 * G * ceil(count / 8) workgroups, all co-resident: cooperative launch).
+  // SCS_HIP_PSD_MC=G forces G (0 / 1: the one-workgroup sweep kernel).
+  // small matrices (order <= 32): four wavefronts per matrix (psd.hpp d_proj_psd_small4); SCS_HIP_PSD_SMALL_WAVES=1: the one-wavefront kernel (lab; agrees to rounding)
+  // SCS_HIP_SOC_PSD_FUSE=0: separate launches for short SOCs and small PSD matrices (same bits)
+  bool soc_psd_one_launch = opts().soc_psd_fuse;  // (labs switch)
+  // Round 5: GEMM-only refinement of the sign split instead of the last Jacobi sweep(s) in split mode (psd.hpp psd_stop_test).
+  // SCS_HIP_PSD_REFINE=0: strict sweeps only (bit-identical to the one-launch kernel); SCS_HIP_PSD_GATE_K / _OFF / _OMEGA: the gate (lab knobs).
+  PsdRefineCfg psd_refine = [] {
+    const Options &o = opts();
+    PsdRefineCfg r = psd_refine_default(o.psd_refine);
+    if (o.psd_gate_k > 0.) r.k2 = o.psd_gate_k * o.psd_gate_k;      // (labs: the gate)
+    if (o.psd_gate_off > 0.) r.off2 = o.psd_gate_off * o.psd_gate_off;
+    if (o.psd_gate_omega > 0.) r.omega = o.psd_gate_omega;
+    return r;
+  }();
+  bool psd_small_one_wave = opts().psd_small_one_wave;  // (labs)
+  int psd_mc_look_ahead = opts().psd_la ? 1 : 0;        // (labs switch) one barrier per step
+  // Round 4: ORDINARY launch by default.  hipLaunchCooperativeKernel guarantees co-residency of the grid, but on this runtime it costs
+  // ~0.1 ms per launch in a fresh process and ~2 ms per launch once the process has driven other workspaces / streams before (config 4 as
+  // the second workload of a bench run: 224 iters/s in the steady window and 245 over a whole solve against 462 / 521 with the ordinary
+  // launch; cold window 495 vs 522; tools/dbg/c4_after.py, profiles/r04_psd_coop.txt).  The ordinary launch is safe for the same reason the
+  // cooperative one is accepted: the grid is sized to fit the device at one workgroup per CU (psd_mc_cap, occupancy query), the
+  // dispatcher places workgroups in order, and a kernel of another stream that holds CUs finishes without waiting for this one — a group
+  // whose members are late spins within its budget (F_PERSIST_ERR otherwise: an error, not a hang).  SCS_HIP_PSD_COOP=1: cooperative launch.
+  bool psd_mc_coop = opts().psd_coop;  // (labs)
+  int psd_mc_cap = -1;  // co-resident workgroups of k_psd_sweep_mc on this device (0: no cooperative launch)
+  long spin_budget = 1L << opts().spin_budget_log2;  // barrier polls before a member gives up (SCS_HIP_SPIN_BUDGET_LOG2; tests: 0)
+  int psd_mc_forced = opts().psd_mc;                 // SCS_HIP_PSD_MC at the workspace's creation (-1: pick)
+  bool psd_mc_nocheck = opts().psd_mc_nocheck;       // (labs: tests of the refused launch)
+  bool spin_user = false;
+  hipEvent_t ev_spin = nullptr;
+  void spin_register() {  // before this workspace's first spinning launch
+    if (spin_user) return;
+    SpinChain &c = spin_chain(device);
+    bool others;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      others = ++c.users >= 2;
+    }
+    spin_user = true;
+    HIP_CHECK(hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming));
+    if (others) HIP_CHECK(hipDeviceSynchronize());  // what the others launched before they had to leave events is done now
+  }
+  void spin_unregister() {
+    if (!spin_user) return;
+    SpinChain &c = spin_chain(device);
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      --c.users;
+      if (c.last == ev_spin) c.last = nullptr;
+    }
+    if (ev_spin) (void)hipEventDestroy(ev_spin);
+    ev_spin = nullptr;
+    spin_user = false;
+  }
+  // around the spinning launches of one call (held while they are enqueued: the chain is a total order)
+  struct SpinLink {
+    ScsHipWork *w;
+    SpinChain &c;
+    std::unique_lock<std::mutex> lk;
+    explicit SpinLink(ScsHipWork *w_) : w(w_), c(spin_chain(w_->device)) {
+      w->spin_register();
+      lk = std::unique_lock<std::mutex>(c.mu);
+      if (c.users >= 2 && c.last && c.last_stream != w->stream) HIP_CHECK(hipStreamWaitEvent(w->stream, c.last, 0));
+    }
+    ~SpinLink() {
+      if (c.users >= 2 && hipEventRecord(w->ev_spin, w->stream) == hipSuccess) {
+        c.last = w->ev_spin;
+        c.last_stream = w->stream;
+      }
+    }
+  };
+  int psd_mc_members(int big) {
+    if (psd_mc_cap < 0) {
+      int coop = 0, per_cu = 0, cus = 0;
+      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_psd_sweep_mc), kPsdThreads, kPsdMcLdsBytes) != hipSuccess)
+        per_cu = 0;
+      psd_mc_cap = coop ? std::min(per_cu, 1) * cus : 0;  // one member per CU: the pivot solves want a SIMD each
+    }
+    const int groups = 8 * ((big + 7) / 8);
+    // at least ~3 pivots per member and step: below that the barriers cost more than the spread saves
+    // (tools/psd_mc_lab.sh: order 200 x 50, G = 4: 3.57 -> 2.24 ms per projection; order 64 x 100, G = 2: 0.29 -> 0.42 ms)
+    const int pivots = psd_max_np / (2 * kPsdB);
+    int G = std::min(std::min(psd_mc_cap / groups, kPsdMcMaxG), pivots / 3);
+    if (psd_mc_forced >= 0) {
+      G = psd_mc_forced;
+      if (G > kPsdMcMaxG || ((long)G * groups > (long)psd_mc_cap && !psd_mc_nocheck)) G = 1;  // (NOCHECK: tests of the refused launch)
+    }
+    return std::max(G, 1);
+  }
+  bool in_capture = false;
+  // stopping level of the PSD sweeps (psd.hpp psd_offtol2): inside the ADMM loop the iteration's P_PSD_TOL2, else nullptr = fixed 1e-8
+  const double *psd_tol2 = nullptr;
+  static bool psd_tol_adaptive() { return opts().psd_tol_adaptive; }  // SCS_HIP_PSD_TOL=fixed: A/B
+  // ... and only while no Anderson extrapolation can happen yet (the history is still filling: iteration < lookback x interval;
+  // always, without acceleration): plain ADMM tolerates inexact projections, the secant model of the acceleration does not —
+  // with interval 1 and type-II steps a golden infeasible instance stalled for good (tools/dbg/psd_tol_infeas.py).
+  double psd_tol2_for(int iter) const {
+    const bool plain_phase = aa.mem <= 0 || (long)iter < (long)aa.mem * stgs.acceleration_interval;
+    return plain_phase ? psd_tol2_of(psd_res_min) : kPsdOffTol2;
+  }
+  static double psd_kappa() {
+    return opts().psd_tol_k;  // (labs knob; see psd.hpp psd_offtol2 for why 1e-2)
+  }
+  static double psd_tol2_of(double level) {  // level = what note_check_residuals left in psd_res_min
+    if (!psd_tol_adaptive()) return kPsdOffTol2;
+    const double cap = opts().psd_tol_max;  // (labs knob)
+    const double t = std::min(std::max(level, 1e-8), cap);
+    return t * t;
+  }
+  int psd_warm = 1;  // warm-start the eigen-solves from the previous call's eigenvectors (0 in the one-shot test entry)
+
+  // AA (aa.hpp): f = v (map output), x = v_prev (map input); the safeguard verdict rides along with the CG flags
+  DeviceAa aa;
+  double aa_norm = 0;
+  int rejected_accel = 0, accepted_accel = 0;
+
+  // per-solve state
+  Residuals r;
+  double sum_log_scale_factor = 0;
+  int n_log_scale_factor = 0, last_scale_update_iter = 0, scale_updates = 0;
+  long tot_cg_iters = 0;
+  int last_cg_iters = 8;
+  int cg_hist[8] = {8, 8, 8, 8, 8, 8, 8, 8}, cg_hist_pos = 0;  // CG steps of the last 8 linear solves (chunk sizing)
+  void note_cg_iters(int it) { cg_hist[cg_hist_pos++ & 7] = it; }
+  // largest step count of the last `chunk_window()` linear solves (SCS_HIP_CHUNK_WINDOW, 1..8): what a queued iteration's CG chunk is sized
+  // for.  Round 4: 3 instead of 8 — in the cold-start phase the counts FALL from iteration to iteration, and a window of 8 kept
+  // enqueuing the counts of eight iterations ago: 36 % of the K1 / K2 launches of the bench window were early-exit launches
+  // (profiles/r03_bench_kernel_trace.txt: 3581 launched, 2309 with work).
+  static int chunk_window() {
+    return opts().chunk_window;  // (labs knob)
+  }
+  int recent_cg_max() const {
+    int mx = 1;
+    for (int k = 1; k <= chunk_window(); ++k) mx = std::max(mx, cg_hist[(cg_hist_pos - k) & 7]);
+    return mx;
+  }
+  int recent_cg_q3() const {  // third quartile of the last 8 linear solves (the grouped loop's prediction: a short round is cheap there)
+    int h[8];
+    std::copy(cg_hist, cg_hist + 8, h);
+    std::sort(h, h + 8);
+    return std::max(1, h[5]);
+  }
+  double cg_res_min = 0;
+  // what the PSD stopping level follows (psd_tol2_of): the smallest of the residuals ANY termination test looks at —
+  // primal / dual residual and, for a problem drifting towards a certificate, the certificate's own residuals
+  double psd_res_min = 0;
+  void note_check_residuals() {
+    cg_res_min = std::min(r.nm_pri_n, r.nm_dual_n);
+    psd_res_min = psd_kappa() * cg_res_min;
+    if (std::isfinite(r.res_infeas)) psd_res_min = std::min(psd_res_min, r.res_infeas);
+    // (an unboundedness certificate needs BOTH of its residuals small; |Px| / -c'x is identically 0 for an LP)
+    if (std::isfinite(r.res_unbdd_a) && std::isfinite(r.res_unbdd_p)) psd_res_min = std::min(psd_res_min, std::max(r.res_unbdd_a, r.res_unbdd_p));
+  }
+  // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
+  bool profile = false;
+  double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
+  long prof_n[2] = {0, 0};
+  // bench.py: a timestamp INSIDE a solve (scs_hip_set_mark): when iteration mark_iter is about to start the stream is
+  // drained and the elapsed time / counters are recorded, so a window that starts past the cold start can be timed
+  int mark_iter = -1;
+  double mark_ms = -1;
+  long mark_cg = 0;
+  int mark_aa_calls = 0, mark_aa_accept = 0;
+  std::mutex mtx;
+
+  ~ScsHipWork() {
+    // nothing of this workspace is in flight once its stream is idle: its blocks may be handed to the next workspace without hipFree
+    // (real workspaces only: the stack workspaces of the kernel-level entry points borrow a stream that is gone by now)
+    if (stream && (pooled_stream || owns_stream) && hipStreamSynchronize(stream) == hipSuccess) {
+      pool_window_end.armed = true;
+      ++t_pool_release;
+    }
+    spin_unregister();
+    for (auto &g : g_pre) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &g : g_cg) if (g) (void)hipGraphExecDestroy(g);
+    if (g_post) (void)hipGraphExecDestroy(g_post);
+    if (pinned_block) {
+      g_pinned.release(pinned_block);
+    } else {  // (stack workspaces of the kernel-level entry points allocate what they need themselves)
+      if (h_pin) (void)hipHostFree(h_pin);
+      if (h_flags) (void)hipHostFree(h_flags);
+      if (h_params_base) (void)hipHostFree(h_params_base);
+      for (auto &hf : h_flags_slot) if (hf) (void)hipHostFree(hf);
+    }
+    if (sol_pin) (void)hipHostFree(sol_pin);
+    for (auto &e : sol_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ev_iter) if (e) (void)hipEventDestroy(e);
+    for (auto &es : ev_prof) for (auto &e : es) if (e) (void)hipEventDestroy(e);
+    for (auto &es : ev_cone) for (auto &e : es) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream && pooled_stream) g_streams.release(device, stream);
+    else if (stream && owns_stream) (void)hipStreamDestroy(stream);
+  }
+
+#include "work_linsys.inl"
+#include "work_admm.inl"
+#include "work_residuals.inl"
+#include "work_solve_ends.inl"
+};

@@ -55,6 +55,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.usefixtures("_require_gpu"))
 
 
+def pytest_collection_finish(session):
+    """start the checker's longest solves of the selected GPU tests now, in background threads (tests/helpers.py oracle_job)"""
+    mexpr = session.config.getoption("-m") or ""
+    if "gpu" not in mexpr or "not gpu" in mexpr or not _have_gpu():
+        return
+    import helpers
+    for item in session.items:
+        key = helpers.ORACLE_JOBS_OF_TEST.get(getattr(item, "originalname", None) or item.name)
+        if key:
+            helpers.oracle_job(key)
+
+
 @pytest.fixture
 def _require_gpu():
     if not _have_gpu():

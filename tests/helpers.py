@@ -214,3 +214,50 @@ def oracle_solve_many(oracle, jobs, workers=8):
     with ThreadPoolExecutor(max_workers=max(1, min(workers, len(jobs)))) as pool:
         futs = [pool.submit(oracle.solve, d, K, **kw) for d, K, kw in jobs]
         return [f.result() for f in futs]
+
+
+# ---- the checker's longest solves, started early -----------------------------------------------------------------------------------
+# Three GPU tests wait 30-70 s each for ONE single-threaded oracle solve (BASELINE config 1 through the sparse LDL' at 1e-9 and at
+# 1e-6, the un-accelerated CG run that the iteration counts are compared with).  tests/conftest.py starts the jobs of the SELECTED
+# tests in background threads when the collection is done (the oracle is plain C behind ctypes: no GIL, no global state), the tests
+# pick the results up — the same solves with the same settings, overlapped with the rest of the suite (wall time).
+_ORACLE_JOBS = {}
+_ORACLE_POOL = None
+ORACLE_JOBS_OF_TEST = {
+    "test_dense_config1_lp_x_s_at_1e4": "config1_ldl_1e-9",
+    "test_config1_lp_golden_against_stored_optimum_and_oracle": "config1_ldl_1e-6",
+    "test_iteration_counts_track_oracle_cg": "std_feas_cg_plain_1e-6",
+}
+
+
+def _oracle_job_fn(key):
+    from oracle import scs_oracle
+    base = dict(eps_abs=1e-9, eps_rel=1e-9, eps_infeas=1e-9, verbose=False)   # = STG of test_hip_parity.py / test_dense_gpu.py
+    if key == "config1_ldl_1e-9":
+        data, K, _ = load_problem("problem_config1_lp.npz", "lp_")
+        return lambda: scs_oracle.OracleSCS(*raw_args(data, K), indirect=False, **dict(base, max_iters=400000)).solve(False)
+    if key == "config1_ldl_1e-6":
+        data, K, _ = load_problem("problem_config1_lp.npz", "lp_")
+        return lambda: scs_oracle.OracleSCS(*raw_args(data, K), indirect=False, **dict(base, eps_abs=1e-6, eps_rel=1e-6)).solve(False)
+    if key == "std_feas_cg_plain_1e-6":
+        data, K, _ = load_problem("problems_std.npz", "std_feas_")
+        stg = dict(base, acceleration_lookback=0, adaptive_scale=False, eps_abs=1e-6, eps_rel=1e-6)
+        return lambda: scs_oracle.OracleSCS(*raw_args(data, K), indirect=True, **stg).solve(False)
+    raise KeyError(key)
+
+
+def oracle_job(key):
+    """the Future of the named oracle solve, started at the first request (conftest.py: right after the collection)"""
+    global _ORACLE_POOL
+    if key not in _ORACLE_JOBS:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import scs_oracle
+        scs_oracle.lib()
+        if _ORACLE_POOL is None:
+            _ORACLE_POOL = ThreadPoolExecutor(max_workers=4)
+        _ORACLE_JOBS[key] = _ORACLE_POOL.submit(_oracle_job_fn(key))
+    return _ORACLE_JOBS[key]
+
+
+def oracle_result(key):
+    return oracle_job(key).result()

@@ -282,7 +282,8 @@ def test_config1_lp_golden_against_stored_optimum_and_oracle(hip, oracle):
     cross-checked with HiGHS there) through the HIP path: stored optimum, the oracle's LDL' answer, certificate"""
     data, K, p_star = helpers.load_problem("problem_config1_lp.npz", "lp_")
     # (eps = 1e-6: at 1e-8 the indirect path needs more than the default 1e5 iterations on this degenerate LP)
-    got, ref = _solve_both(hip, oracle, data, K, eps_abs=1e-6, eps_rel=1e-6)
+    got = hip.SCS(*helpers.raw_args(data, K), **dict(STG, eps_abs=1e-6, eps_rel=1e-6)).solve(False, None, None, None)
+    ref = helpers.oracle_result("config1_ldl_1e-6")   # oracle.OracleSCS(*args, indirect=False, same settings).solve(False), started when the collection was done
     assert got["info"]["status"] == "solved" and ref["info"]["status"] == "solved"
     assert abs(got["info"]["pobj"] - p_star) <= 1e-5 * max(1.0, abs(p_star))
     assert abs(got["info"]["pobj"] - ref["info"]["pobj"]) <= 1e-5 * max(1.0, abs(p_star))
@@ -375,7 +376,7 @@ def test_iteration_counts_track_oracle_cg(hip, oracle):
     args = helpers.raw_args(data, K)
     stg = dict(STG, acceleration_lookback=0, adaptive_scale=False, eps_abs=1e-6, eps_rel=1e-6)
     got = hip.SCS(*args, **stg).solve(False, None, None, None)
-    ref = oracle.OracleSCS(*args, indirect=True, **stg).solve(False)
+    ref = helpers.oracle_result("std_feas_cg_plain_1e-6")   # oracle.OracleSCS(*args, indirect=True, **stg).solve(False), started when the collection was done
     assert got["info"]["status"] == ref["info"]["status"] == "solved"
     gi, ri = got["info"], ref["info"]
     assert abs(gi["iter"] - ri["iter"]) <= 0.05 * ri["iter"] + 25, (gi["iter"], ri["iter"])

@@ -211,7 +211,7 @@ def main():
 
     def pmc_traffic(workload, which):
         """HBM bytes of K1 / K2 per launch from the committed rocprofv3 --pmc passes on this workload's matrix shape"""
-        for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     pmc = json.load(f)

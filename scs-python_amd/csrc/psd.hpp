@@ -466,37 +466,12 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
       for (int j = tid; j < n; j += kPsdThreads) diag[n + j] = 1. / diag[j];
       __syncthreads();
     }
-    // Round 6: the loads of a wavefront's trips go out EIGHT at a time.  With agent-scope atomic loads (which the compiler keeps in
-    // program order) every trip was a dependent L2 round trip — ~32 of them per wavefront at order 200, 25-35 us for a test that reads
-    // 160 KB, and a projection of the steady state pays for two such tests.  The members of a multi-CU group invalidate their vector L1
-    // ONCE (acquire fence at agent scope behind the barrier that published the data) and read with plain loads; the per-lane order of
-    // the accumulation is unchanged (column by column, trip by trip): the same sums, the same decisions as before.
-    if (AGENT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    constexpr int U = 8;
-    int cj = wave, ck = 0;  // cursor: column, trip inside the column
-    while (cj < n) {
-      double av[U];
-      int ei[U], ej[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool live = cj < n;
-        const int j = live ? cj : 0, i = live ? cj + 64 * ck + lane : n;
-        ej[u] = j;
-        ei[u] = i;
-        av[u] = i < n ? A[i + (size_t)ld * j] : 0.;
-        if (live) {
-          ++ck;
-          if (cj + 64 * ck >= n) { cj += kPsdWaves; ck = 0; }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = ei[u], j = ej[u];
-        if (i >= n) continue;
-        const double dj = diag[j];
-        const bool pj = dj > 0.;
-        const double ij = tab ? diag[n + j] : 1. / dj;
-        const double a = av[u];
+    for (int j = wave; j < n; j += kPsdWaves) {
+      const double dj = diag[j];
+      const bool pj = dj > 0.;
+      const double ij = tab ? diag[n + j] : 1. / dj;
+      for (int i = j + lane; i < n; i += 64) {
+        const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
         const double a2 = a * a;
         if (i == j) {
           tot += a2;

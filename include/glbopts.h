@@ -16,7 +16,7 @@
 
 /* Defaults of the boolean settings the glue fills in when the caller passes None:
  * R:scs/scsobject.h:796-800 (verbose, normalize, adaptive_scale) and :869 (warm_start).  Values = the defaults of
- * SCS 3.2.x that scs_set_default_settings() of this library writes (scs_hip.hip) and that the front end documents
+ * SCS 3.2.x that scs_set_default_settings() of this library writes (csrc/scs_hip.hip) and that the front end documents
  * (R:scs/py/__init__.py solve() docstring; R:test/test_scs_coverage.py exercises verbose=False explicitly). */
 #define VERBOSE (1)
 #define NORMALIZE (1)

@@ -157,7 +157,8 @@ void scs_hip_set_mark(ScsWork *w, int iter);
 void scs_hip_get_mark(const ScsWork *w, double *out);
 /* `reps` back-to-back launches of K1, then of K2 and — problems with P — of K3 on the solver's own stream and HBM-resident
  * data, one HIP event pair per batch (the ~10-20 us per-event overhead is amortised).
- * out[3] = {K1 avg ms, K2 avg ms, K3 avg ms (0 without P)}.  Returns 0 on success. */
+ * out[4] = {K1 avg ms, K2 avg ms, K3 avg ms as the CG step runs it — between K1 and K2: (K1, K3, K2) x reps minus (K1, K2) x reps —, K3 avg ms
+ * back to back (its matrix may then stay in the Infinity Cache)}; K3: 0 without P.  Returns 0 on success. */
 int scs_hip_time_matvec(ScsWork *w, int reps, double *out);
 
 /* Anderson acceleration as a standalone object on host vectors (row a6): the interface of scs_source/src/aa.c

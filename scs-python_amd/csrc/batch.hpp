@@ -715,7 +715,7 @@ struct GroupSolve {
     upload_active();
     std::vector<int> tmp_list;
     const bool stats = (opts().debug & DBG_GROUP) != 0;  // SCS_HIP_DEBUG=group
-    InterruptListener ctrlc;  // (scs_hip.hip: Ctrl-C ends every member that is still running with SCS_SIGINT)
+    InterruptListener ctrlc;  // (loop.hpp: Ctrl-C ends every member that is still running with SCS_SIGINT)
     for (int i = 0; !active.empty(); ++i) {
       if (InterruptListener::interrupted()) {
         sync();

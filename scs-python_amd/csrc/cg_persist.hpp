@@ -2,7 +2,7 @@
 //
 // Plays the role of the CG loop of scs_source/linsys/cpu/indirect/private.c (R:meson.build:261; absent;
 // algorithm: SURVEY App. A.4).  For problems whose mat-vec takes a few microseconds the launch-per-kernel
-// path (scs_hip.hip: enqueue_lin_sys_head + 4 launches per CG step) is all launch latency: ~5-6 us per
+// path (work_admm.inl: enqueue_lin_sys_head + 4 launches per CG step) is all launch latency: ~5-6 us per
 // kernel on this GPU versus < 1 us of work.  Here a small persistent grid runs
 //     tolerance -> y0 = v_y + R_y^{-1} A ws -> r0, p0 -> { z = R_y^{-1} A p -> Gp, p'Gp -> x, r, y updates -> beta, p }*
 // with a grid barrier between the phases and no host round trip.  Every phase executes the SAME per-block

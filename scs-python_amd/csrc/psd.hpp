@@ -67,7 +67,7 @@ constexpr double kPsdOffTol2 = PSD_OFFTOL2;  // sweeps stop at ||offdiag||_F^2 <
 // Inside the ADMM loop — while the Anderson history is still filling, i.e. in the first lookback x interval iterations (always, without
 // acceleration) — the stopping level follows the residuals, as the tolerance of the inexact linear solve does (vec.hpp k_fin_head):
 // tol2 points at the iteration's P_PSD_TOL2 = clamp(level, 1e-8, 1e-3)^2, level = min(1e-2 * primal/dual residual, certificate
-// residuals) of the last convergence check (scs_hip.hip note_check_residuals / psd_tol2_of).  While the iterate is far from the
+// residuals) of the last convergence check (work.hpp note_check_residuals / psd_tol2_of).  While the iterate is far from the
 // solution an eigen-decomposition to 1e-8 buys nothing: the second-order reconstruction leaves O(|E|^3) of the remaining off-diagonal
 // part E (~5e-9 relative at |E| = 1e-4, measured on the special-spectra tests), orders below the residual it is tied to; from
 // residual 1e-6 down the level IS the fixed 1e-8.  Measured (round 3): config 4, iterations 5..105: 3 sweeps per projection -> 1-2,
@@ -1000,8 +1000,8 @@ __global__ __launch_bounds__(kPsdFrontThreads) void k_psd_front(const double *x,
 //   * every member publishes its HW_REG_XCC_ID first; a group that is NOT on one XCD (other partition modes, a
 //     different dispatcher) falls back to sc1 (write-through to memory) stores, which are coherent across XCDs
 //     (6.2 us per ping-pong) — plain stores would be 100 % stale there.
-// Co-residency of every spinning workgroup: the grid is sized to one workgroup per CU of the device (scs_hip.hip psd_mc_members), and
-// inside a process the spinning launches of different workspaces / streams of a device are CHAINED (scs_hip.hip SpinChain: each waits
+// Co-residency of every spinning workgroup: the grid is sized to one workgroup per CU of the device (work.hpp psd_mc_members), and
+// inside a process the spinning launches of different workspaces / streams of a device are CHAINED (work.hpp SpinChain: each waits
 // for the event behind the previous one), so two such grids never share the device; hipLaunchCooperativeKernel (SCS_HIP_PSD_COOP=1)
 // makes it the runtime's guarantee at ~0.1-2 ms per launch.  What is left — another PROCESS on the same GPU — is caught by the spin
 // budget: error flag, every barrier of the launch opens, the host restarts the solve with one workgroup per matrix.
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kPsdThreads) void k_psd_sweep_mc(PsdBatch B, double
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
           __builtin_amdgcn_s_sleep(1);
           // a member never arrived (spin_budget: seconds by default): raise the error flag — the host restarts the solve with one
-          // workgroup per matrix (scs_hip.hip spin_fallback) — and stop waiting, here and at every later barrier of every group of
+          // workgroup per matrix (work_residuals.inl spin_fallback) — and stop waiting, here and at every later barrier of every group of
           // this launch: what is computed from now on is thrown away, it only has to end soon
           if (++spins > spin_budget) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
           if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;

@@ -34,7 +34,7 @@ enum : int {
   F_AA_REJ_WEIGHT, F_AA_SAFE_REJ, F_AA_LAST_RANK, F_AA_CALLS, F_SAFE_OK, F_SAFE_BAD, F_ZERO_RHS, F_STEP, F_PERSIST_ERR, F_STALL, F_COUNT = 32
 };
 
-// F_STALL (run-ahead mode of the ADMM loop, scs_hip.hip): the host enqueues a whole iteration — head, a chunk of
+// F_STALL (run-ahead mode of the ADMM loop, loop.hpp / work_admm.inl): the host enqueues a whole iteration — head, a chunk of
 // CG steps, tau / cones / v update — and the next one before it looks at the CG flags.  If the chunk was too short
 // (F_DONE still 0 when the first kernel after it runs) that kernel raises F_STALL and F_DONE, and every kernel
 // queued behind it returns at once (the CG-step kernels through F_DONE, the others through F_STALL), so nothing is

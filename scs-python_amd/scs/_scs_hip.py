@@ -113,7 +113,7 @@ def _preload_hip_runtime():
 
 
 def _runtime_env():
-    """Runtime configuration that must be in the environment BEFORE the HIP runtime reads its flags (csrc/scs_hip.hip
+    """Runtime configuration that must be in the environment BEFORE the HIP runtime reads its flags (csrc/runtime.hpp
     scs_hip_runtime_env has the measurements): keep the runtime from pinning the caller's pageable arrays for host <->
     device copies — the driver evicts the process's queues for 30-80 ms some time after such pages are released.
     An existing value wins; SCS_HIP_RUNTIME_ENV=0 leaves the environment alone."""
@@ -666,12 +666,12 @@ class SCS(object):
         return out[:8 * cnt].reshape(cnt, 8)
 
     def _time_matvec(self, reps=20):
-        out = np.zeros(3)
+        out = np.zeros(4)
         with self._lock:
             rc = _lib.scs_hip_time_matvec(self._work, int(reps), _pd(out))
         if rc != 0:
             raise RuntimeError("libscs_hip: " + last_error())
-        return {"k1_ms": float(out[0]), "k2_ms": float(out[1]), "k3_ms": float(out[2])}
+        return {"k1_ms": float(out[0]), "k2_ms": float(out[1]), "k3_ms": float(out[2]), "k3_back_to_back_ms": float(out[3])}
 
     def __del__(self):
         lock = getattr(self, "_lock", None)

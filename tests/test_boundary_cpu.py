@@ -252,3 +252,23 @@ def test_backend_modules_bind_their_linear_solver():
     from scs import _scs_hip, _scs_hip_dense
     assert _scs_hip.SCS._LINSYS == 1
     assert _scs_hip_dense.SCS._LINSYS == 2
+
+
+def test_product_library_reads_only_the_documented_environment_variables():
+    """the product has at most 20 runtime knobs, all documented.  Every `SCS_HIP_*` name that occurs in
+    libscs_hip.so (csrc/options.hpp parses them all in one place) is in INTEGRATION.md's "Runtime knobs" table; the switches of the
+    experiments that lost exist in the -DSCS_HIP_LABS build only."""
+    import re
+    import subprocess
+    from scs import _scs_hip
+    lib = os.path.join(ROOT, "scs-python_amd", "scs", "libscs_hip.so")
+    names = set(re.findall(rb"SCS_HIP_[A-Z0-9_]+", open(lib, "rb").read()))
+    names = {n.decode() for n in names} - {"SCS_HIP_"}
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = text[text.index("## Runtime knobs"):text.index("**The labs build.**")]
+    documented = set(re.findall(r"^\| `(SCS_HIP_[A-Z0-9_]+)`", table, flags=re.M))
+    assert len(documented) <= 20, sorted(documented)
+    assert names <= documented, sorted(names - documented)
+    assert {"SCS_HIP_KRYLOV", "SCS_HIP_K1DOT", "SCS_HIP_PERSIST", "SCS_HIP_GRAPH", "SCS_HIP_PSD_COOP", "SCS_HIP_CS_SCHED"}.isdisjoint(names)
+    if not os.environ.get("SCS_HIP_LIB"):
+        assert not _scs_hip.labs_build()

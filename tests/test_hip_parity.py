@@ -416,7 +416,7 @@ def test_determinism_bit_exact(hip):
 
 @pytest.mark.parametrize("n", [400, 40000])
 def test_determinism_bit_exact_with_P(hip, oracle, n):
-    """the QP path (K3: Gp = P p on the full symmetric CSR of P, csrc/scs_hip.hip Pf) under the same rule
+    """the QP path (K3: Gp = P p on the full symmetric CSR of P, csrc/work.hpp Pf) under the same rule
     (R:test/test_scs_coverage.py:2283-2301): no float atomics, fixed summation order — two fresh instances give identical bits.
     n = 40000: nnz(Pf) > 2^20, so K3 runs on the column-sorted pass layout the large-matrix kernels read; and the product P x of
     the solver's layout is checked entry for entry against scipy through the kernel-level entry point."""

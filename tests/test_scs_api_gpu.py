@@ -277,7 +277,7 @@ def test_shared_instance_is_serialised_by_its_lock(scs):
 
 
 def _read_scship_dump(fname):
-    """reader of the write_data_filename format documented in csrc/scs_hip.hip (write_problem_data)"""
+    """reader of the write_data_filename format documented in csrc/io.hpp (write_problem_data)"""
     import struct
     raw = open(fname, "rb").read()
     assert raw[:8] == b"SCSHIP01"

@@ -1,4 +1,4 @@
-"""Concurrency contract of the kernels that spin on inter-workgroup barriers (k_psd_sweep_mc; csrc/psd.hpp, scs_hip.hip SpinChain).
+"""Concurrency contract of the kernels that spin on inter-workgroup barriers (k_psd_sweep_mc; csrc/psd.hpp, work.hpp SpinChain).
 
 R:test/test_thread_safety.py:78-93 asks that independent SCS instances solve truly concurrently (GIL released,
 R:scs/scsobject.h:984-987, one lock per instance).  A PSD cone of order >= 64 in a small batch spreads the Jacobi sweeps of

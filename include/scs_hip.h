@@ -128,10 +128,10 @@ int scs_hip_normalize(ScsMatrix *A, ScsMatrix *P, scs_float *b, scs_float *c, co
 double scs_hip_copy_bandwidth(size_t bytes, int reps);
 
 /* Live timing of the two dominant kernels inside scs_solve: when enabled, one CG step per
- * host sync is bracketed by HIP events on the solver's own stream.  out[10] =
+ * host sync is bracketed by HIP events on the solver's own stream.  out[12] =
  * {K1 total ms, K1 samples, K2 total ms, K2 samples, nnz(A), K1 workgroups, K2 workgroups, nnz(P full),
- *  nonlinear cone projections total ms, samples (one per queued iteration)}
- * where K1 = z <- R_y^{-1} A p  and  K2 = Gp <- A' z + R_x p (+ P p). */
+ *  nonlinear cone projections total ms, samples (one per queued iteration), K3 total ms, K3 samples}
+ * where K1 = z <- R_y^{-1} A p,  K2 = Gp <- A' z + R_x p (+ P p)  and, for problems with P, K3 = P p (between K1 and K2). */
 void scs_hip_set_profiling(ScsWork *w, int on);
 void scs_hip_kernel_times(const ScsWork *w, double *out);
 /* The final (x, y, s) of the last scs_solve, copied from the workspace's HBM buffers to caller-provided DEVICE pointers

@@ -507,6 +507,7 @@ void scs_hip_kernel_times(const ScsWork *w, double *out) {
   out[4] = (double)w->At.nnz; out[5] = (double)w->Ar.nwg(); out[6] = (double)w->At.nwg();
   out[7] = w->has_P ? (double)w->Pf.nnz : 0.0;
   out[8] = w->prof_cone_ms; out[9] = (double)w->prof_cone_n;
+  out[10] = w->prof_ms[2]; out[11] = (double)w->prof_n[2];
 }
 
 #include "lab_entries.hpp"

@@ -53,7 +53,7 @@ struct ScsHipWork {
   hipStream_t stream = nullptr;
   bool owns_stream = true, pooled_stream = false, stream_shared = false;
   void *pinned_block = nullptr;  // all pinned host scalars / flags of the workspace (g_pinned)
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [3]: behind K3 in a sampled CG step of a problem with P
   double *h_pin = nullptr;  // pinned scalars
   int *h_flags = nullptr;   // pinned flags
   double *h_params = nullptr, *d_params = nullptr;  // mapped pinned per-iteration scalars (P_*), slot in use (2 slots)
@@ -65,7 +65,7 @@ struct ScsHipWork {
   int *stall_fl = nullptr;         // fl (or nullptr): k_tau_dots raises the stall, k_cone_pre parks the CG kernels
   int *h_flags_slot[2] = {nullptr, nullptr};
   hipEvent_t ev_iter[2] = {nullptr, nullptr};
-  hipEvent_t ev_prof[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // in-situ K1/K2 samples of the run-ahead loop
+  hipEvent_t ev_prof[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // in-situ K1 / K2 (/ K3) samples of the run-ahead loop
   int prof_step[2] = {-1, -1};  // CG step (0-based) bracketed by ev_prof[slot], -1 = none
   hipEvent_t ev_cone[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // in-situ: the cone kernels of a queued iteration
   bool cone_sampled[2] = {false, false};
@@ -418,8 +418,21 @@ struct ScsHipWork {
   }
   // live kernel timing (HIP events on the launch stream, one sampled CG step per chunk)
   bool profile = false;
-  double prof_ms[2] = {0, 0};  // K1 (A p), K2 (A' z [+P])
-  long prof_n[2] = {0, 0};
+  double prof_ms[3] = {0, 0, 0};  // K1 (A p), K2 (A' z + R_x p [+ P p]), K3 (P p; problems with P)
+  long prof_n[3] = {0, 0, 0};
+  // one sampled CG step: events [0] K1 [1] (K3 [3]) K2 [2]
+  void note_cg_sample(hipEvent_t *e) {
+    float a = 0, b = 0, c = 0;
+    if (hipEventElapsedTime(&a, e[0], e[1]) != hipSuccess) return;
+    if (has_P) {  // (the labs-only k1dot path excludes P)
+      if (hipEventElapsedTime(&c, e[1], e[3]) != hipSuccess || hipEventElapsedTime(&b, e[3], e[2]) != hipSuccess) return;
+      prof_ms[2] += c; prof_n[2]++;
+    } else if (hipEventElapsedTime(&b, e[1], e[2]) != hipSuccess) {
+      return;
+    }
+    prof_ms[0] += a; prof_n[0]++;
+    prof_ms[1] += b; prof_n[1]++;
+  }
   // bench.py: a timestamp INSIDE a solve (scs_hip_set_mark): when iteration mark_iter is about to start the stream is
   // drained and the elapsed time / counters are recorded, so a window that starts past the cold start can be timed
   int mark_iter = -1;

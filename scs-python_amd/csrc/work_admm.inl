@@ -202,14 +202,7 @@
       float c = 0;
       if (hipEventElapsedTime(&c, ev_cone[slot][0], ev_cone[slot][1]) == hipSuccess) { prof_cone_ms += c; prof_cone_n++; }
     }
-    if (profile && prof_step[slot] >= 0 && last_cg_iters > prof_step[slot]) {  // the sampled step really ran
-      float a = 0, b = 0;
-      if (hipEventElapsedTime(&a, ev_prof[slot][0], ev_prof[slot][1]) == hipSuccess &&
-          hipEventElapsedTime(&b, ev_prof[slot][1], ev_prof[slot][2]) == hipSuccess) {
-        prof_ms[0] += a; prof_n[0]++;
-        prof_ms[1] += b; prof_n[1]++;
-      }
-    }
+    if (profile && prof_step[slot] >= 0 && last_cg_iters > prof_step[slot]) note_cg_sample(ev_prof[slot]);  // the sampled step really ran
     return true;
   }
   // after a stall: drain the queue, lower the flags and finish iteration `iter` the synchronous way

@@ -173,7 +173,10 @@
       HIP_CHECK(hipEventRecord(evs[0], stream));
       launch_spmv(Ar.view(), cg_p.p, EpiDivR{tmp_m.p, rdy()}, fl.p + F_DONE, stream, fl.p + F_STEP);
       HIP_CHECK(hipEventRecord(evs[1], stream));
-      if (has_P) launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+      if (has_P) {
+        launch_spmv(Pf.view(), cg_p.p, EpiStore{cg_Gp.p, 0}, fl.p + F_DONE, stream);
+        HIP_CHECK(hipEventRecord(evs[3], stream));
+      }
       launch_spmv(At.view(), tmp_m.p, EpiGp{cg_Gp.p, cg_p.p, rdx(), has_P ? 1 : 0, part.p, gp2()}, fl.p + F_DONE, stream);
       HIP_CHECK(hipEventRecord(evs[2], stream));
     } else
@@ -347,13 +350,7 @@
           else enqueue_cg_step(xout, yacc, (profile && it == sample_it) ? ev : nullptr);
         }
         read_flags();
-        if (profile && h_flags[F_ITERS] - iters_before > sample_it) {  // the sampled step really ran
-          float a = 0, b = 0;
-          if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[1], ev[2]) == hipSuccess) {
-            prof_ms[0] += a; prof_n[0]++;
-            prof_ms[1] += b; prof_n[1]++;
-          }
-        }
+        if (profile && h_flags[F_ITERS] - iters_before > sample_it) note_cg_sample(ev);  // the sampled step really ran
       }
       done_iters = h_flags[F_ITERS];
       if (h_flags[F_DONE] || done_iters >= max_its) break;

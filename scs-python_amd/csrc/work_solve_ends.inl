@@ -28,8 +28,8 @@
     cg_res_min = 0;
     psd_res_min = 0;
     tot_cg_iters = 0;
-    prof_ms[0] = prof_ms[1] = 0;
-    prof_n[0] = prof_n[1] = 0;
+    prof_ms[0] = prof_ms[1] = prof_ms[2] = 0;
+    prof_n[0] = prof_n[1] = prof_n[2] = 0;
     prof_cone_ms = 0; prof_cone_n = 0;
 
     // ---- initial iterate ----

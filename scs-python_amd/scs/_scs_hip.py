@@ -620,12 +620,12 @@ class SCS(object):
             _lib.scs_hip_set_profiling(self._work, 1 if on else 0)
 
     def _kernel_times(self):
-        out = np.zeros(10)
+        out = np.zeros(12)
         with self._lock:
             _lib.scs_hip_kernel_times(self._work, _pd(out))
         return {"k1_ms": out[0], "k1_n": int(out[1]), "k2_ms": out[2], "k2_n": int(out[3]),
                 "nnz": int(out[4]), "k1_wgs": int(out[5]), "k2_wgs": int(out[6]), "nnz_p": int(out[7]),
-                "cone_ms": out[8], "cone_n": int(out[9])}
+                "cone_ms": out[8], "cone_n": int(out[9]), "k3_ms": out[10], "k3_n": int(out[11])}
 
     def solution_to_device(self, x_ptr=None, y_ptr=None, s_ptr=None):
         """copy the last solve's (x, y, s) from the workspace's HBM buffers to DEVICE addresses (ints, e.g.

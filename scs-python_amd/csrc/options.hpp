@@ -8,6 +8,7 @@
 // the kernels — is a compile-time default in the product and only reads the environment in the `-DSCS_HIP_LABS` build
 // (scs-python_amd/Makefile `make labs` -> libscs_hip_labs.so, used by tools/ and by the tests marked `labs`).
 #pragma once
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -143,24 +144,26 @@ struct Options {
   }
 };
 
-inline Options &options_storage() {
-  static Options o = Options::parse();
-  return o;
+// The current options live behind an atomic pointer: readers (opts(), anywhere, any thread) never see a half-written struct, and a
+// reference they hold stays valid — a superseded struct is never freed (a few hundred bytes per CHANGE of the environment, which only
+// tests make).
+inline std::atomic<const Options *> &options_ptr() {
+  static std::atomic<const Options *> p{new Options(Options::parse())};
+  return p;
 }
 // what the NEXT workspace / kernel-level call sees (the environment as it was at the last refresh_options())
-inline const Options &opts() { return options_storage(); }
-// re-read the environment: first thing in scs_init and in every kernel-level entry point.  The struct is only written when an
-// SCS_HIP_* variable changed since the last call, so concurrent scs_init calls under one environment never write it.
+inline const Options &opts() { return *options_ptr().load(std::memory_order_acquire); }
+// re-read the environment: first thing in scs_init and in every kernel-level entry point.  A new struct is only published when an
+// SCS_HIP_* variable changed since the last call, so concurrent scs_init calls under one environment publish nothing.
 inline void refresh_options() {
   static std::mutex m;
-  static std::string last;
+  static std::string last = "\x01";  // (never equal to a real signature: the first call publishes what it parsed)
   std::string sig;
   for (char **e = environ; e && *e; ++e)
     if (std::strncmp(*e, "SCS_HIP_", 8) == 0) { sig += *e; sig += '\n'; }
   std::lock_guard<std::mutex> lk(m);
-  Options &cur = options_storage();  // (its first use parses the environment)
   if (sig != last) {
-    cur = Options::parse();
+    options_ptr().store(new Options(Options::parse()), std::memory_order_release);
     last = sig;
   }
 }

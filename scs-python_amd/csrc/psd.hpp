@@ -418,6 +418,14 @@ __device__ __forceinline__ void psd_reconstruct(double *X, int n, int NP, double
 //   PSD_STOP_RELAXED  after a refinement: mixed-sign off-norm^2 <= tol2 |A|^2 and omega <= R.omega_relaxed — what the
 //                     reconstruction needs; a matrix that fails it goes back to the sweeps (from S1, with the refined V: nothing is lost)
 enum : int { PSD_STOP_STRICT = 0, PSD_STOP_GATE = 1, PSD_STOP_RELAXED = 2 };
+#if PSD_PROFILE
+// tools/psd_lab.hip: 10 ns ticks of the LAST stopping test run by thread 0 of workgroup 0 — [0] diagonal [1] reciprocal table [2] the
+// sums (+ K1) [3] block reductions + decision [4] calls so far [5] mode of the last call
+__device__ double psd_prof_stop[8];
+#define PSD_STOP_TICK(var) const long long var = (threadIdx.x == 0 && blockIdx.x == 0) ? wall_clock64() : 0
+#else
+#define PSD_STOP_TICK(var) do { } while (0)
+#endif
 struct PsdRefineCfg {
   int on;  // 0: strict sweeps only (bit-identical to the one-launch kernel)
   double k2, off2, omega, omega_relaxed;
@@ -440,6 +448,7 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
                                              const PsdRefineCfg &R, double *state, bool lead, double *K1 = nullptr, bool first = false) {
   const int tid = threadIdx.x;
   const bool wk = K1 != nullptr && lead && mode == PSD_STOP_GATE;
+  PSD_STOP_TICK(ts0);
   if (wk) {  // rows / columns of the padding
     const int NP = ld;
     for (int e = tid; e < (NP - n) * NP; e += kPsdThreads) {
@@ -453,6 +462,10 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
     __syncthreads();
   }
   double off = 0., tot = 0., mix = 0., kf = 0., om = 0.;
+  PSD_STOP_TICK(ts1);
+#if PSD_PROFILE
+  long long ts2 = 0;
+#endif
   if (mode != PSD_STOP_STRICT) {
     // Column by column (wavefront w: columns w, w + 16, ...; lanes down the rows), the LOWER triangle only — the matrix is exactly symmetric, every
     // off-diagonal term counts twice —, the same-sign terms through a table of 1 / d_i, the mixed-sign ones through ONE fp32 reciprocal estimate
@@ -466,12 +479,40 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
       for (int j = tid; j < n; j += kPsdThreads) diag[n + j] = 1. / diag[j];
       __syncthreads();
     }
-    for (int j = wave; j < n; j += kPsdWaves) {
-      const double dj = diag[j];
-      const bool pj = dj > 0.;
-      const double ij = tab ? diag[n + j] : 1. / dj;
-      for (int i = j + lane; i < n; i += 64) {
-        const double a = AGENT ? ld_agent(&A[i + (size_t)ld * j]) : A[i + (size_t)ld * j];
+#if PSD_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == 0) ts2 = wall_clock64();
+#endif
+    // Round 6: the loads of a wavefront's trips go out EIGHT at a time, every one of them unconditional (the row index is clamped: a
+    // load inside a condition makes hipcc wait for it on the spot).  A trip's load used to be consumed right behind its issue — ~32
+    // dependent round trips to an L2 that may belong to another XCD, 0.5 us each: 16 us of a 27 us test that reads 160 KB, and a
+    // projection of the steady state pays for two such tests (tools/psd_lab.hip -DPSD_PROFILE=1).  The per-lane order of the
+    // accumulation is unchanged (column by column, trip by trip): the same sums, the same decisions.
+    constexpr int U = 8;
+    int cj = wave, ck = 0;  // cursor: column, trip inside the column (the same in every lane of the wavefront)
+    while (cj < n) {
+      double av[U];
+      int ei[U], ej[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = cj < n;
+        const int j = live ? cj : 0, i = live ? cj + 64 * ck + lane : n;
+        ej[u] = j;
+        ei[u] = i;
+        const double *pa = &A[min(i, n - 1) + (size_t)ld * j];
+        av[u] = AGENT ? ld_agent(pa) : *pa;
+        ck += live ? 1 : 0;
+        const bool next = live && cj + 64 * ck >= n;
+        cj += next ? kPsdWaves : 0;
+        ck = next ? 0 : ck;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = ei[u], j = ej[u];
+        if (i >= n) continue;
+        const double dj = diag[j];
+        const bool pj = dj > 0.;
+        const double ij = tab ? diag[n + j] : 1. / dj;
+        const double a = av[u];
         const double a2 = a * a;
         if (i == j) {
           tot += a2;
@@ -520,12 +561,38 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
       K1[i + (size_t)ld * j] = 0.;
     }
   }
+#if PSD_PROFILE
+  __syncthreads();  // (profile builds: the slowest wavefront ends the sums)
+#endif
+  PSD_STOP_TICK(ts3);
+  if (mode != PSD_STOP_STRICT && 2 * n + 5 * kPsdWaves <= kPsdWaves * kPsdWaveLds) {
+    // the five sums in ONE pass (round 6: five block_sum calls were ten barriers, 6.5 us): each value through the same shuffle tree and
+    // the same 16-term sum in wavefront order as block_sum — the same bits —, the partials behind the reciprocal table in LDS
+    double v5[5] = {off, tot, mix, kf, om};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v5[q] = wave_sum(v5[q]);
+    double *sm5 = diag + 2 * n;
+    if ((tid & 63) == 0)
+      for (int q = 0; q < 5; ++q) sm5[q * kPsdWaves + (tid >> 6)] = v5[q];
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        double r = 0.;
+#pragma unroll
+        for (int i = 0; i < kPsdWaves; ++i) r += sm5[q * kPsdWaves + i];
+        v5[q] = r;
+      }
+      off = v5[0]; tot = v5[1]; mix = v5[2]; kf = v5[3]; om = v5[4];
+    }
+  } else {
   off = block_sum<kPsdThreads>(off, red);
   tot = block_sum<kPsdThreads>(tot, red);
   if (mode != PSD_STOP_STRICT) {
     mix = block_sum<kPsdThreads>(mix, red);
     kf = block_sum<kPsdThreads>(kf, red);
     om = block_sum<kPsdThreads>(om, red);
+  }
   }
   if (tid == 0) {
     int code = (off <= offtol2 * tot || off == 0.) ? 1 : 0;
@@ -539,6 +606,17 @@ __device__ __forceinline__ int psd_stop_test(const double *A, int ld, int n, dou
   __syncthreads();
   const int code = (int)bc[0];
   __syncthreads();
+#if PSD_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long ts4 = wall_clock64();
+    psd_prof_stop[0] = (double)(ts1 - ts0);
+    psd_prof_stop[1] = (double)((ts2 ? ts2 : ts1) - ts1);
+    psd_prof_stop[2] = (double)(ts3 - (ts2 ? ts2 : ts1));
+    psd_prof_stop[3] = (double)(ts4 - ts3);
+    psd_prof_stop[4] += 1.;
+    psd_prof_stop[5] = (double)mode;
+  }
+#endif
   return code;
 }
 

@@ -111,6 +111,14 @@ int main(int argc, char **argv) {
     HIP_CHECK(hipMemcpy(st, d_scr + st_off, sizeof st, hipMemcpyDeviceToHost));
     outs[pass].emplace_back(x.size());
     HIP_CHECK(hipMemcpy(outs[pass].back().data(), d_x, x.size() * 8, hipMemcpyDeviceToHost));
+#if PSD_PROFILE
+    {
+      double ps[8];
+      HIP_CHECK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(psd_prof_stop), sizeof ps));
+      std::printf("     last stopping test of workgroup 0 (mode %.0f, %.0f tests so far): diagonal %.2f us, reciprocals %.2f, sums%s %.2f, reductions + decision %.2f\n",
+                  ps[5], ps[4], ps[0] / 100, ps[1] / 100, ps[5] == 1. ? " + K1" : "", ps[2] / 100, ps[3] / 100);
+    }
+#endif
     const double steps = n <= kPsdSmallMax ? st[7] * (((n + 1) & ~1) - 1) : st[7] * (np / 8 - 1);  // rounds of the one-wave kernel / outer steps
     std::printf("%3d  %9.1f | %6.1f  %8.1f  %7.1f  %7.1f  %11.1f  %11.1f | %6.0f  %5.0f  %13.2f  %14.2f\n", call, ms * 1e3, st[1] / 100, st[2] / 100,
                 st[3] / 100, st[4] / 100, st[5] / 100, st[6] / 100, st[7], steps, steps ? st[3] / 100 / steps : 0., steps ? st[4] / 100 / steps : 0.);

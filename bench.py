@@ -211,7 +211,7 @@ def main():
 
     def pmc_traffic(workload, which):
         """HBM bytes of K1 / K2 per launch from the committed rocprofv3 --pmc passes on this workload's matrix shape"""
-        for fname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fname in ("r06_pmc_traffic.json", "r06_pmc_traffic_qp.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     pmc = json.load(f)
@@ -387,6 +387,7 @@ def main():
                               "bytes": int(b3), "avg_ms": round(k3_avg, 5), "GBps": round(gb3, 1), "frac": round(gb3 / HBM_PEAK, 4),
                               "streamed_bytes": int(b3s), "frac_streamed": round(b3s / (k3_avg * 1e-3) / 1e9 / HBM_PEAK, 4) if k3_avg > 0 else 0.0,
                               "samples": int(kt.get("k3_n", 0)), "how": "in situ: HIP events around K3 inside sampled CG steps of the timed solve",
+                              "traffic": pmc_traffic(workload, "K3")[0], "traffic_source": pmc_traffic(workload, "K3")[1],
                               "marginal_ms_in_a_cg_step": round(kb["k3_ms"], 5), "avg_ms_back_to_back": round(kb["k3_back_to_back_ms"], 5),
                               "launches_per_cg_step": "K1 + K3 + K2 (K2's epilogue adds P p)"}
         if psd_t is not None:
